@@ -1,0 +1,63 @@
+// Fused multi-tensor Adam: one launch updates every parameter tensor of a network.
+// torch.optim.Adam single-tensor semantics (no weight decay, no amsgrad), reference call site
+// trainers/base_trainer.py:75-89 (betas (0.5, 0.999), eps 1e-8):
+//   m += (1-b1)(g-m); v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+#include <hip/hip_runtime.h>
+
+#include "../../include/dei2i_hip.h"
+#include "launch.h"
+
+namespace dei2i {
+
+__global__ __launch_bounds__(256) void adam_kernel(const dei2i_adam_rec* __restrict__ table, float lr, float beta1,
+                                                   float beta2, float eps, float bias_c1, float bias_c2_sqrt,
+                                                   float grad_scale) {
+  const dei2i_adam_rec rec = table[blockIdx.y];
+  const float step_size = lr / bias_c1;
+  const float inv_c2 = 1.f / bias_c2_sqrt;
+  const int64_t n = rec.n;
+  const int64_t n4 = ((reinterpret_cast<uintptr_t>(rec.p) | reinterpret_cast<uintptr_t>(rec.g) |
+                       reinterpret_cast<uintptr_t>(rec.m) | reinterpret_cast<uintptr_t>(rec.v)) & 15) == 0 ? n / 4 : 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 p = reinterpret_cast<float4*>(rec.p)[i];
+    const float4 g = reinterpret_cast<const float4*>(rec.g)[i];
+    float4 m = reinterpret_cast<float4*>(rec.m)[i];
+    float4 v = reinterpret_cast<float4*>(rec.v)[i];
+    float* pp = &p.x; const float* gp = &g.x; float* mp = &m.x; float* vp = &v.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gv = gp[e] * grad_scale;
+      mp[e] = mp[e] + (1.f - beta1) * (gv - mp[e]);
+      vp[e] = beta2 * vp[e] + (1.f - beta2) * gv * gv;
+      const float denom = sqrtf(vp[e]) * inv_c2 + eps;
+      pp[e] = pp[e] - step_size * (mp[e] / denom);
+    }
+    reinterpret_cast<float4*>(rec.p)[i] = p;
+    reinterpret_cast<float4*>(rec.m)[i] = m;
+    reinterpret_cast<float4*>(rec.v)[i] = v;
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float gv = rec.g[i] * grad_scale;
+    const float m = rec.m[i] + (1.f - beta1) * (gv - rec.m[i]);
+    const float v = beta2 * rec.v[i] + (1.f - beta2) * gv * gv;
+    rec.m[i] = m;
+    rec.v[i] = v;
+    rec.p[i] = rec.p[i] - step_size * (m / (sqrtf(v) * inv_c2 + eps));
+  }
+}
+
+}  // namespace dei2i
+
+using namespace dei2i;
+
+extern "C" int dei2i_adam_step(const dei2i_adam_rec* table_dev, int count, int64_t max_n, float lr, float beta1, float beta2,
+                               float eps, float bias_c1, float bias_c2_sqrt, float grad_scale, dei2i_stream s) {
+  if (!table_dev || count <= 0 || max_n <= 0) return DEI2I_ERR_BAD_ARG;
+  int64_t bx = (max_n / 4 + 255) / 256;
+  if (bx < 1) bx = 1;
+  if (bx > 512) bx = 512;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)bx, (unsigned)count), dim3(256), 0, (hipStream_t)s, table_dev, lr, beta1, beta2,
+                     eps, bias_c1, bias_c2_sqrt, grad_scale);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,116 @@
+// Shared device/host helpers for the dei2i HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define DEI2I_HD __host__ __device__ __forceinline__
+#define DEI2I_D __device__ __forceinline__
+#else
+#define DEI2I_HD inline
+#endif
+
+namespace dei2i {
+
+enum DType : int { DT_BF16 = 0, DT_F32 = 1 };
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2 };
+enum PadMode : int { PAD_ZERO = 0, PAD_REFLECT = 1 };
+
+// Division by a launch-invariant 32-bit divisor (numerator < 2^31): q = (mulhi(n, m) + n) >> l.
+struct FastDiv {
+  uint32_t m;
+  uint32_t l;
+  uint32_t d;
+};
+
+inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;
+  f.l = l;
+  f.m = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+  return f;
+}
+
+DEI2I_HD uint32_t fd_div(uint32_t n, const FastDiv& f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (__umulhi(n, f.m) + n) >> f.l;
+#else
+  return (uint32_t)((((uint64_t)n * f.m) >> 32) + n) >> f.l;
+#endif
+}
+
+#if defined(__HIPCC__)
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+typedef uint16_t bf16_t;  // storage type
+
+DEI2I_D float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even; NaN stays NaN (plain cast lowers to v_cvt_pk_bf16_f32 on gfx950)
+DEI2I_D bf16_t f32_to_bf16(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(uint16_t, b);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int VEC = 4;  // elements per 16-byte vector
+  static DEI2I_D float load(const float* p) { return *p; }
+  static DEI2I_D void store(float* p, float v) { *p = v; }
+  static DEI2I_D void unpack(const u32x4& v, float* f) {
+    f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y);
+    f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+  }
+  static DEI2I_D u32x4 pack(const float* f) {
+    u32x4 v;
+    v.x = __float_as_uint(f[0]); v.y = __float_as_uint(f[1]);
+    v.z = __float_as_uint(f[2]); v.w = __float_as_uint(f[3]);
+    return v;
+  }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int VEC = 8;
+  static DEI2I_D float load(const bf16_t* p) { return bf16_to_f32(*p); }
+  static DEI2I_D void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+  static DEI2I_D void unpack(const u32x4& v, float* f) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+  }
+  static DEI2I_D u32x4 pack(const float* f) {
+    u32x4 v;
+    v.x = (uint32_t)f32_to_bf16(f[0]) | ((uint32_t)f32_to_bf16(f[1]) << 16);
+    v.y = (uint32_t)f32_to_bf16(f[2]) | ((uint32_t)f32_to_bf16(f[3]) << 16);
+    v.z = (uint32_t)f32_to_bf16(f[4]) | ((uint32_t)f32_to_bf16(f[5]) << 16);
+    v.w = (uint32_t)f32_to_bf16(f[6]) | ((uint32_t)f32_to_bf16(f[7]) << 16);
+    return v;
+  }
+};
+
+DEI2I_D float apply_act(float v, int act) {
+  if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == ACT_LRELU) return v >= 0.f ? v : 0.2f * v;
+  return v;
+}
+// derivative of the activation expressed through its OUTPUT z (valid for relu / lrelu(0.2): sign(z) == sign(pre))
+DEI2I_D float act_grad_from_out(float z, int act) {
+  if (act == ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  if (act == ACT_LRELU) return z >= 0.f ? 1.f : 0.2f;
+  return 1.f;
+}
+
+DEI2I_D float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+#endif  // __HIPCC__
+
+}  // namespace dei2i

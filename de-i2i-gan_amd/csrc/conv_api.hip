@@ -1,0 +1,238 @@
+// C ABI for the convolution family: descriptor construction, weight (re)packing, fold of the dgrad halo.
+#include <hip/hip_runtime.h>
+
+#include "../../include/dei2i_hip.h"
+#include "launch.h"
+
+namespace dei2i {
+
+static ConvShape to_shape(const dei2i_conv* c) {
+  ConvShape s;
+  s.N = c->N; s.H = c->H; s.W = c->W; s.Cin = c->Cin; s.Cout = c->Cout;
+  s.kh = c->kh; s.kw = c->kw; s.stride = c->stride; s.pad = c->pad; s.pad_mode = c->pad_mode; s.up = c->up;
+  return s;
+}
+
+static bool valid_conv(const dei2i_conv* c) {
+  if (!c) return false;
+  const int vec = c->dtype == DT_BF16 ? 8 : 4;
+  if (c->dtype != DT_BF16 && c->dtype != DT_F32) return false;
+  if (c->N <= 0 || c->H <= 0 || c->W <= 0 || c->Cin <= 0 || c->Cout <= 0) return false;
+  if (c->CinS < c->Cin || c->CoutS < c->Cout || c->CinS % vec || c->CoutS % vec) return false;
+  if (c->kh <= 0 || c->kw <= 0 || c->stride <= 0 || c->pad < 0 || c->up < 0 || c->up > 1) return false;
+  if (c->kh < c->stride || c->kw < c->stride) return false;          // every dgrad parity class needs a tap
+  if (c->pad_mode == PAD_REFLECT && (c->pad >= (c->H << c->up) || c->pad >= (c->W << c->up))) return false;
+  if (((c->H << c->up) + 2 * c->pad) < c->kh || ((c->W << c->up) + 2 * c->pad) < c->kw) return false;
+  return true;
+}
+
+// ---- weight packing ------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_fwd_kernel(const float* __restrict__ w, T* __restrict__ dst, int Cout, int Cin, int CinS, int kh, int kw) {
+  const size_t total = (size_t)Cout * kh * kw * CinS;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const long long si = packed_fwd_src((long long)i, Cin, CinS, kh * kw);
+    Elem<T>::store(dst + i, si >= 0 ? w[si] : 0.f);
+  }
+}
+
+// class (ay,ax): rows = Cin, K = th*tw*CoutS, element [ci][(jy*tw+jx)][co] = w[co][ci][ay+s*jy][ax+s*jx]
+template <typename T>
+__global__ void pack_dgrad_kernel(const float* __restrict__ w, T* __restrict__ dst, int Cout, int Cin, int CoutS, int kh,
+                                  int kw, int s, int ay, int ax, int th, int tw) {
+  const size_t total = (size_t)Cin * th * tw * CoutS;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const long long si = packed_dgrad_src((long long)i, Cout, Cin, CoutS, kh, kw, s, ay, ax, th, tw);
+    Elem<T>::store(dst + i, si >= 0 ? w[si] : 0.f);
+  }
+}
+
+__global__ void unpack_wgrad_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin, int CinS,
+                                    int taps, float beta) {
+  const size_t total = (size_t)Cout * Cin * taps;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int t = (int)(i % taps);
+    const size_t r = i / taps;
+    const int ci = (int)(r % Cin);
+    const int co = (int)(r / Cin);
+    const float v = src[((size_t)co * taps + t) * CinS + ci];
+    dst[i] = beta != 0.f ? beta * dst[i] + v : v;
+  }
+}
+
+// ---- fold: gradient of reflect padding + nearest upsample ------------------------------------------
+// dx[n,hs,ws,:] = sum over logical (hl,wl) in the 2^up x 2^up cell of sum over padded positions that map to it.
+template <typename T>
+__global__ void fold_pad_kernel(const T* __restrict__ ext, const T* __restrict__ addend, T* __restrict__ dx, int N, int H,
+                                int W, int C, int pad, int reflect, int up) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int Hl = H << up, Wl = W << up;
+  const int off = reflect ? pad : 0;
+  const int OH = Hl + 2 * off, OW = Wl + 2 * off;
+  const int cv = C / VEC;
+  const size_t total = (size_t)N * H * W * cv;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) * VEC;
+    size_t r = i / cv;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H);
+    const int n = (int)(r / H);
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    if (addend != nullptr) {
+      float t[VEC];
+      Elem<T>::unpack(*reinterpret_cast<const u32x4*>(addend + i * VEC), t);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] = t[e];
+    }
+    // candidate rows/cols in the extended frame
+    int ys[6], xs[6];
+    const int ny = fold_sources(h, up, Hl, pad, reflect, ys);
+    const int nx = fold_sources(w, up, Wl, pad, reflect, xs);
+    for (int a = 0; a < ny; ++a)
+      for (int b = 0; b < nx; ++b) {
+        float t[VEC];
+        Elem<T>::unpack(*reinterpret_cast<const u32x4*>(ext + (((size_t)n * OH + ys[a]) * OW + xs[b]) * C + c), t);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += t[e];
+      }
+    *reinterpret_cast<u32x4*>(dx + i * VEC) = Elem<T>::pack(acc);
+  }
+}
+
+}  // namespace dei2i
+
+using namespace dei2i;
+
+extern "C" {
+
+size_t dei2i_packed_fwd_elems(const dei2i_conv* c) { return (size_t)c->Cout * c->kh * c->kw * c->CinS; }
+
+size_t dei2i_packed_dgrad_elems(const dei2i_conv* c) {
+  size_t n = 0;
+  for (int ay = 0; ay < c->stride; ++ay)
+    for (int ax = 0; ax < c->stride; ++ax)
+      n += (size_t)c->Cin * dgrad_taps(c->kh, c->stride, ay) * dgrad_taps(c->kw, c->stride, ax) * c->CoutS;
+  return n;
+}
+
+int dei2i_pack_weight_fwd(const dei2i_conv* c, const float* w, void* packed, dei2i_stream s) {
+  if (!valid_conv(c) || !w || !packed) return DEI2I_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)s;
+  const size_t total = dei2i_packed_fwd_elems(c);
+  const unsigned grid = grid_for(total, 256);
+  if (c->dtype == DT_BF16)
+    hipLaunchKernelGGL(pack_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, w, (bf16_t*)packed, c->Cout, c->Cin, c->CinS, c->kh, c->kw);
+  else
+    hipLaunchKernelGGL(pack_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, w, (float*)packed, c->Cout, c->Cin, c->CinS, c->kh, c->kw);
+  return (int)hipGetLastError();
+}
+
+int dei2i_pack_weight_dgrad(const dei2i_conv* c, const float* w, void* packed, dei2i_stream s) {
+  if (!valid_conv(c) || !w || !packed) return DEI2I_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)s;
+  const size_t esz = c->dtype == DT_BF16 ? 2 : 4;
+  size_t off = 0;
+  for (int ay = 0; ay < c->stride; ++ay)
+    for (int ax = 0; ax < c->stride; ++ax) {
+      const int th = dgrad_taps(c->kh, c->stride, ay), tw = dgrad_taps(c->kw, c->stride, ax);
+      const size_t total = (size_t)c->Cin * th * tw * c->CoutS;
+      if (total == 0) continue;
+      const unsigned grid = grid_for(total, 256);
+      void* dst = (char*)packed + off * esz;
+      if (c->dtype == DT_BF16)
+        hipLaunchKernelGGL(pack_dgrad_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, w, (bf16_t*)dst, c->Cout, c->Cin, c->CoutS,
+                           c->kh, c->kw, c->stride, ay, ax, th, tw);
+      else
+        hipLaunchKernelGGL(pack_dgrad_kernel<float>, dim3(grid), dim3(256), 0, st, w, (float*)dst, c->Cout, c->Cin, c->CoutS,
+                           c->kh, c->kw, c->stride, ay, ax, th, tw);
+      off += total;
+    }
+  return (int)hipGetLastError();
+}
+
+int dei2i_unpack_wgrad(const dei2i_conv* c, const float* dw_packed, float* dw_oihw, float beta, dei2i_stream s) {
+  if (!valid_conv(c) || !dw_packed || !dw_oihw) return DEI2I_ERR_BAD_ARG;
+  const size_t total = (size_t)c->Cout * c->Cin * c->kh * c->kw;
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)s, dw_packed, dw_oihw,
+                     c->Cout, c->Cin, c->CinS, c->kh * c->kw, beta);
+  return (int)hipGetLastError();
+}
+
+void dei2i_conv2d_out_shape(const dei2i_conv* c, int* Ho, int* Wo) {
+  *Ho = conv_out_dim(c->H << c->up, c->kh, c->stride, c->pad);
+  *Wo = conv_out_dim(c->W << c->up, c->kw, c->stride, c->pad);
+}
+
+void dei2i_conv2d_dgrad_shape(const dei2i_conv* c, int* OH, int* OW) {
+  ConvShape s = to_shape(c);
+  *OH = dgrad_out_h(s);
+  *OW = dgrad_out_w(s);
+}
+
+size_t dei2i_conv2d_workspace_bytes(const dei2i_conv* c) {
+  int Ho, Wo, OH, OW;
+  dei2i_conv2d_out_shape(c, &Ho, &Wo);
+  dei2i_conv2d_dgrad_shape(c, &OH, &OW);
+  const size_t f = (size_t)c->N * Ho * Wo * c->CoutS, d = (size_t)c->N * OH * OW * c->CinS;
+  return (f > d ? f : d) * sizeof(float);
+}
+
+int dei2i_conv2d_fwd(const dei2i_conv* c, const void* x, const void* w_packed, const float* bias, int act, void* y, float* ws,
+                     size_t ws_bytes, dei2i_stream s) {
+  if (!valid_conv(c) || !x || !w_packed || !y) return DEI2I_ERR_BAD_ARG;
+  GatherDesc g = make_fwd_desc(to_shape(c), c->CinS);
+  if (g.Ho <= 0 || g.Wo <= 0) return DEI2I_ERR_BAD_ARG;
+  return (int)gather_gemm(c->dtype, g, x, w_packed, c->Cout, bias, y, ws, ws_bytes, c->CoutS, act, (hipStream_t)s);
+}
+
+int dei2i_conv2d_dgrad(const dei2i_conv* c, const void* dy, const void* wd_packed, void* dx_ext, float* ws, size_t ws_bytes,
+                       dei2i_stream s) {
+  if (!valid_conv(c) || !dy || !wd_packed || !dx_ext) return DEI2I_ERR_BAD_ARG;
+  const ConvShape sh = to_shape(c);
+  const size_t esz = c->dtype == DT_BF16 ? 2 : 4;
+  const int ncls = c->stride * c->stride;
+  size_t off = 0;
+  for (int ay = 0; ay < c->stride; ++ay)
+    for (int ax = 0; ax < c->stride; ++ax) {
+      GatherDesc g = make_dgrad_desc(sh, c->CoutS, ay, ax);
+      const size_t welems = (size_t)c->Cin * g.th * g.tw * c->CoutS;
+      const void* wcls = (const char*)wd_packed + off * esz;
+      off += welems;
+      if (g.M <= 0) continue;
+      // split-K finalises the WHOLE output tensor, so it is only usable when one class covers it
+      hipError_t e = gather_gemm(c->dtype, g, dy, wcls, c->Cin, nullptr, dx_ext, ncls == 1 ? ws : nullptr,
+                                 ncls == 1 ? ws_bytes : 0, c->CinS, ACT_NONE, (hipStream_t)s);
+      if (e != hipSuccess) return (int)e;
+    }
+  return 0;
+}
+
+int dei2i_conv2d_wgrad(const dei2i_conv* c, const void* x, const void* dy, float* dw_packed, dei2i_stream s) {
+  if (!valid_conv(c) || !x || !dy || !dw_packed) return DEI2I_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)s;
+  GatherDesc g = make_fwd_desc(to_shape(c), c->CinS);
+  hipError_t e = hipMemsetAsync(dw_packed, 0, dei2i_packed_fwd_elems(c) * sizeof(float), st);
+  if (e != hipSuccess) return (int)e;
+  return (int)wgrad_gemm(c->dtype, g, x, dy, c->Cout, c->CoutS, dw_packed, st);
+}
+
+int dei2i_fold_pad(int dtype, int N, int H, int W, int C, int pad, int pad_mode, int up, const void* dx_ext,
+                   const void* addend, void* dx, dei2i_stream s) {
+  const int vec = dtype == DT_BF16 ? 8 : 4;
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % vec || pad < 0 || pad > 3 || up < 0 || up > 1 || !dx_ext || !dx)
+    return DEI2I_ERR_BAD_ARG;
+  const size_t total = (size_t)N * H * W * (C / vec);
+  const unsigned grid = grid_for(total, 256, 256u * 16u);
+  const int reflect = (pad_mode == PAD_REFLECT && pad > 0) ? 1 : 0;
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(fold_pad_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const bf16_t*)dx_ext,
+                       (const bf16_t*)addend, (bf16_t*)dx, N, H, W, C, pad, reflect, up);
+  else
+    hipLaunchKernelGGL(fold_pad_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const float*)dx_ext,
+                       (const float*)addend, (float*)dx, N, H, W, C, pad, reflect, up);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,567 @@
+// Implicit-GEMM convolution kernels for gfx950 (CDNA4): forward / dgrad ("gather GEMM") and wgrad.
+//
+// Layout: activations NHWC with the channel count padded to a 16-byte vector (8 bf16 / 4 f32); packed
+// weights [rows][K] with K = taps*Cs contiguous, so BOTH GEMM operands of the gather GEMM are K-contiguous
+// and are staged as [row][128 B] LDS tiles with an XOR swizzle that makes the ds_read_b128 fragment reads
+// conflict-free.  64-wide wavefronts, 4 waves per workgroup, 32x32 MFMA blocks:
+//   bf16: v_mfma_f32_32x32x16_bf16 (one 16-byte fragment per lane = 8 k-values)
+//   f32 : v_mfma_f32_32x32x2_f32, four per 16-byte fragment (exact f32 FMA chain; parity mode)
+// The k order inside a 16-byte fragment pair is the same permutation for A and B, so the sum is unchanged.
+//
+// wgrad reduces over pixels, which is the slow index of both operands; the tiles are staged pixel-major
+// (coalesced 16-byte loads) and the bf16 fragments are fetched with ds_read_b64_tr_b16 (hardware transpose),
+// the f32 fragments with ds_read_b32.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "common.h"
+#include "geom.h"
+#include "launch.h"
+
+namespace dei2i {
+
+// ------------------------------------------------------------------------------------------------
+// MFMA wrappers: one call consumes a 16-byte A fragment and a 16-byte B fragment per lane.
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static DEI2I_D void run(const u32x4& a, const u32x4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static DEI2I_D void run(const u32x4& a, const u32x4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  }
+};
+
+DEI2I_D u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+DEI2I_D u32x4 zero16() { u32x4 z = {0u, 0u, 0u, 0u}; return z; }
+
+// bijective XCD-aware remap of the linear workgroup id (cdna_hip_programming.md T1)
+DEI2I_D int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gather GEMM:  out[m][n] = act( sum_k  gather(src)[m][k] * wgt[n][k] + bias[n] )
+// ------------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherDesc g, const T* __restrict__ src,
+                                                          const T* __restrict__ wgt, const int wrows,
+                                                          const float* __restrict__ bias, T* __restrict__ out,
+                                                          float* __restrict__ ws, const int ldc, const int act,
+                                                          const int tiles_n, const int ksteps_per_split) {
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int BKE = 128 / (int)sizeof(T);      // k elements per 128-byte LDS row
+  constexpr int RA = BM / 32, RB = BN / 32;      // 16-byte vectors per thread per k-step
+  constexpr int WTM = BM / WM, WTN = BN / WN;    // wave tile
+  constexpr int TM = WTM / 32, TN = WTN / 32;    // 32x32 MFMA blocks per wave
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 block");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int TILE_BYTES = (BM + BN) * 128;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int nwg = gridDim.x;
+  const int bid = xcd_remap(blockIdx.x, nwg);
+  const int tile_n = bid % tiles_n;
+  const int tile_m = bid / tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int nk_total = (g.K + BKE - 1) / BKE;
+  const int kbeg = blockIdx.z * ksteps_per_split;
+  const int kend = min(nk_total, kbeg + ksteps_per_split);
+  if (kbeg >= kend) return;
+
+  // ---- per-thread load assignment ----
+  const int kv = tid & 7;       // 16-byte chunk within the 128-byte k-row
+  const int r0 = tid >> 3;      // 0..31
+  int a_nb[RA], a_by[RA], a_bx[RA];
+#pragma unroll
+  for (int i = 0; i < RA; ++i) {
+    const int m = m0 + r0 + 32 * i;
+    if (m < g.M) {
+      int n, oy, ox;
+      decode_m(g, m, n, oy, ox);
+      a_nb[i] = n;
+      a_by[i] = oy * g.sh + g.by0;
+      a_bx[i] = ox * g.sw + g.bx0;
+    } else {
+      a_nb[i] = -1; a_by[i] = 0; a_bx[i] = 0;
+    }
+  }
+  int b_row[RB];
+#pragma unroll
+  for (int j = 0; j < RB; ++j) {
+    const int n = n0 + r0 + 32 * j;
+    b_row[j] = n < wrows ? n : -1;
+  }
+
+  u32x4 areg[RA], breg[RB];
+  int cur_tap = -1;
+  int a_pix[RA];
+
+  auto load_tile = [&](int kstep) {
+    const int k = kstep * BKE + kv * VEC;
+    const bool kval = k < g.K;
+    int tap, ci;
+    decode_k(g, k, tap, ci);
+    if (tap != cur_tap) {
+      cur_tap = tap;
+      const int ty = (int)fd_div((uint32_t)tap, g.fd_tw);
+      const int tx = tap - ty * g.tw;
+      const int dy = ty * g.ys, dx = tx * g.xs;
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        const int y = bound_coord(a_by[i] + dy, g.Hl, g.pad_mode);
+        const int x = bound_coord(a_bx[i] + dx, g.Wl, g.pad_mode);
+        const int pix = (a_nb[i] * g.Hs + (y >> g.up)) * g.Ws + (x >> g.up);
+        a_pix[i] = ((y | x | a_nb[i]) < 0) ? -1 : pix;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      areg[i] = (kval && a_pix[i] >= 0) ? ld16(src + (size_t)a_pix[i] * g.Cs + ci) : zero16();
+    }
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      breg[j] = (kval && b_row[j] >= 0) ? ld16(wgt + (size_t)b_row[j] * g.K + k) : zero16();
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+    unsigned char* base = smem + buf * TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int row = r0 + 32 * i;
+      *reinterpret_cast<u32x4*>(base + row * 128 + ((kv ^ ((row >> 1) & 7)) << 4)) = areg[i];
+    }
+    unsigned char* bb = base + BM * 128;
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      const int row = r0 + 32 * j;
+      *reinterpret_cast<u32x4*>(bb + row * 128 + ((kv ^ ((row >> 1) & 7)) << 4)) = breg[j];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int lr = lane & 31, lh = lane >> 5;
+
+  auto compute_tile = [&](int buf) {
+    const unsigned char* ab = smem + buf * TILE_BYTES;
+    const unsigned char* bb = ab + BM * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 af[TM], bf[TN];
+      const int chunk = ks * 2 + lh;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * WTM + i * 32 + lr;
+        af[i] = *reinterpret_cast<const u32x4*>(ab + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wn * WTN + j * 32 + lr;
+        bf[j] = *reinterpret_cast<const u32x4*>(bb + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Mma<T>::run(af[i], bf[j], acc[i][j]);
+    }
+  };
+
+  // ---- main loop: register-staged, double-buffered LDS, one barrier per k-step ----
+  load_tile(kbeg);
+  store_tile(0);
+  __syncthreads();
+  int buf = 0;
+  for (int ks = kbeg; ks < kend; ++ks) {
+    const bool more = ks + 1 < kend;
+    if (more) load_tile(ks + 1);          // global loads in flight under the MFMAs
+    compute_tile(buf);
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---- epilogue: D[i][j], j = lane&31 (output channel), i = (e&3) + 8*(e>>2) + 4*(lane>>5) (pixel) ----
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      if (m >= g.M) continue;
+      size_t opix;
+      if (g.out_identity) {
+        opix = (size_t)m;
+      } else {
+        int n, oy, ox;
+        decode_m(g, m, n, oy, ox);
+        opix = (size_t)out_pixel(g, n, oy, ox);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WTN + j * 32 + lr;
+        if (n >= ldc) continue;
+        float v = acc[i][j][e];
+        if (ws != nullptr) {
+          if (n < wrows) atomicAdd(ws + opix * ldc + n, v);
+        } else {
+          if (n < wrows) {
+            if (bias != nullptr) v += bias[n];
+            v = apply_act(v, act);
+          } else {
+            v = 0.f;
+          }
+          Elem<T>::store(out + opix * ldc + n, v);
+        }
+      }
+    }
+  }
+}
+
+// split-K finalize: out = act(ws + bias) over the whole (pixels, ldc) output, padded channels forced to 0
+template <typename T>
+__global__ void splitk_finalize_kernel(const float* __restrict__ ws, const float* __restrict__ bias, T* __restrict__ out,
+                                       size_t total, int ldc, int co, int act) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const int c = (int)(i % (size_t)ldc);
+    float v = 0.f;
+    if (c < co) {
+      v = ws[i];
+      if (bias != nullptr) v += bias[c];
+      v = apply_act(v, act);
+    }
+    Elem<T>::store(out + i, v);
+  }
+}
+
+// LDS swizzle for the pixel-major wgrad tiles read with ds_read_b64_tr_b16: a 32-lane half reads 4 consecutive
+// rows x 64 bytes; spread the 4 rows over the four 64-byte quarters of the 256-byte bank row.
+template <int ROWB> DEI2I_D int tr_swz(int row) {
+  if constexpr (ROWB % 256 == 0) return (row & 3) << 6;
+  else return ((row >> 1) & 1) << 6;    // 128-byte rows: rows r and r+2 alias, flip the 64-byte half
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad:  dw[co][k] += sum_m dy[m][co] * gather(src)[m][k]         (fp32 atomics into a zeroed buffer)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256) void wgrad_kernel(const GatherDesc g, const T* __restrict__ src,
+                                                    const T* __restrict__ dy, const int co_rows, const int ldy,
+                                                    float* __restrict__ dw, const int tiles_k,
+                                                    const int chunks_per_split) {
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr bool IS_BF16 = sizeof(T) == 2;
+  constexpr int BR = 128 / (int)sizeof(T);           // pixels per reduction chunk (64 bf16 / 32 f32)
+  constexpr int VPR_A = BM / VEC, VPR_B = BN / VEC;  // 16-byte vectors per LDS row
+  constexpr int RPP_A = 256 / VPR_A, RPP_B = 256 / VPR_B;   // rows covered per pass
+  constexpr int NA = BR / RPP_A, NB = BR / RPP_B;    // vectors per thread per chunk
+  constexpr int ROWB_A = BM * (int)sizeof(T), ROWB_B = BN * (int)sizeof(T);
+  constexpr int WTM = BM / 2, WTN = BN / 2;          // 2x2 waves
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  static_assert(NA >= 1 && NB >= 1, "tile too wide for 256 threads");
+  static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 block");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int A_BYTES = BR * ROWB_A, B_BYTES = BR * ROWB_B;
+  constexpr int TILE_BYTES = A_BYTES + B_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nwg = gridDim.x;
+  const int bid = xcd_remap(blockIdx.x, nwg);
+  const int tile_k = bid % tiles_k, tile_c = bid / tiles_k;
+  const int c0 = tile_c * BM, k0 = tile_k * BN;
+
+  const int nchunks = (g.M + BR - 1) / BR;
+  const int cbeg = blockIdx.z * chunks_per_split;
+  const int cend = min(nchunks, cbeg + chunks_per_split);
+  if (cbeg >= cend) return;
+
+  // A (dy) loader: fixed channel vector, rows strided
+  const int va = tid % VPR_A, ra0 = tid / VPR_A;
+  const int a_c = c0 + va * VEC;
+  const bool a_cok = a_c < ldy;
+  // B (gathered patches) loader: fixed k vector -> fixed (tap, ci)
+  const int vb = tid % VPR_B, rb0 = tid / VPR_B;
+  const int b_k = k0 + vb * VEC;
+  const bool b_kok = b_k < g.K;
+  int b_tap, b_ci;
+  decode_k(g, b_kok ? b_k : 0, b_tap, b_ci);
+  const int b_ty = (int)fd_div((uint32_t)b_tap, g.fd_tw);
+  const int b_dy = b_ty * g.ys, b_dx = (b_tap - b_ty * g.tw) * g.xs;
+
+  u32x4 areg[NA], breg[NB];
+  auto load_chunk = [&](int chunk) {
+    const int mb = chunk * BR;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int m = mb + ra0 + RPP_A * i;
+      areg[i] = (a_cok && m < g.M) ? ld16(dy + (size_t)m * ldy + a_c) : zero16();
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int m = mb + rb0 + RPP_B * i;
+      u32x4 v = zero16();
+      if (b_kok && m < g.M) {
+        int n, oy, ox;
+        decode_m(g, m, n, oy, ox);
+        const int y = bound_coord(oy * g.sh + g.by0 + b_dy, g.Hl, g.pad_mode);
+        const int x = bound_coord(ox * g.sw + g.bx0 + b_dx, g.Wl, g.pad_mode);
+        if ((y | x) >= 0) {
+          const int pix = (n * g.Hs + (y >> g.up)) * g.Ws + (x >> g.up);
+          v = ld16(src + (size_t)pix * g.Cs + b_ci);
+        }
+      }
+      breg[i] = v;
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    unsigned char* ab = smem + buf * TILE_BYTES;
+    unsigned char* bb = ab + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int row = ra0 + RPP_A * i;
+      int off = va * 16;
+      if (IS_BF16) off ^= tr_swz<ROWB_A>(row);
+      *reinterpret_cast<u32x4*>(ab + row * ROWB_A + off) = areg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int row = rb0 + RPP_B * i;
+      int off = vb * 16;
+      if (IS_BF16) off ^= tr_swz<ROWB_B>(row);
+      *reinterpret_cast<u32x4*>(bb + row * ROWB_B + off) = breg[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int lr = lane & 31, lh = lane >> 5;
+  // transposed-read lane roles (ds_read_b64_tr_b16): 16-lane group grp, lane i = 4q+p supplies row q, cols 4p..4p+3
+  const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_cohalf = (lane >> 4) & 1;
+
+  auto compute_chunk = [&](int buf) {
+    const unsigned char* ab = smem + buf * TILE_BYTES;
+    const unsigned char* bb = ab + A_BYTES;
+    if constexpr (IS_BF16) {
+#pragma unroll
+      for (int kk = 0; kk < BR / 16; ++kk) {
+        u32x4 af[TM], bf[TN];
+        const int row_lo = kk * 16 + 8 * lh + tr_q;     // rows row_lo (k 0..3) and row_lo+4 (k 4..7)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int colb = (wm * WTM + i * 32 + 16 * tr_cohalf + 4 * tr_p) * 2;
+          const int o0 = row_lo * ROWB_A + (colb ^ tr_swz<ROWB_A>(row_lo));
+          const int o1 = (row_lo + 4) * ROWB_A + (colb ^ tr_swz<ROWB_A>(row_lo + 4));
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ab + o0));
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ab + o1));
+          u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+          af[i].x = l2.x; af[i].y = l2.y; af[i].z = h2.x; af[i].w = h2.y;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int colb = (wn * WTN + j * 32 + 16 * tr_cohalf + 4 * tr_p) * 2;
+          const int o0 = row_lo * ROWB_B + (colb ^ tr_swz<ROWB_B>(row_lo));
+          const int o1 = (row_lo + 4) * ROWB_B + (colb ^ tr_swz<ROWB_B>(row_lo + 4));
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(bb + o0));
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(bb + o1));
+          u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+          bf[j].x = l2.x; bf[j].y = l2.y; bf[j].z = h2.x; bf[j].w = h2.y;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]),
+                                                                 __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll 4
+      for (int kk = 0; kk < BR / 2; ++kk) {
+        float af[TM], bf[TN];
+        const int row = kk * 2 + lh;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          af[i] = *reinterpret_cast<const float*>(ab + row * ROWB_A + (wm * WTM + i * 32 + lr) * 4);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bf[j] = *reinterpret_cast<const float*>(bb + row * ROWB_B + (wn * WTN + j * 32 + lr) * 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
+  load_chunk(cbeg);
+  store_chunk(0);
+  __syncthreads();
+  int buf = 0;
+  for (int c = cbeg; c < cend; ++c) {
+    const bool more = c + 1 < cend;
+    if (more) load_chunk(c + 1);
+    compute_chunk(buf);
+    if (more) store_chunk(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // D[i = co][j = k column]; lanes run along k (contiguous in dw) -> 128-byte atomic segments
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int co = c0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      if (co >= co_rows) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int k = k0 + wn * WTN + j * 32 + lr;
+        if (k < g.K) atomicAdd(dw + (size_t)co * g.K + k, acc[i][j][e]);
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static int g_num_cu = 256;
+
+template <typename T, int BM, int BN, int WM, int WN>
+static hipError_t launch_gg(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias,
+                            void* out, float* ws, int ldc, int act, int splits, hipStream_t st) {
+  constexpr int BKE = 128 / (int)sizeof(T);
+  const int tiles_m = (g.M + BM - 1) / BM;
+  const int tiles_n = (ldc + BN - 1) / BN;
+  const int nk = (g.K + BKE - 1) / BKE;
+  const int kps = (nk + splits - 1) / splits;
+  const int zs = (nk + kps - 1) / kps;
+  dim3 grid(tiles_m * tiles_n, 1, zs);
+  const size_t lds = 2 * (BM + BN) * 128;
+  auto kern = gather_gemm_kernel<T, BM, BN, WM, WN>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  prof_begin(PROF_GATHER_GEMM, 2.0 * (double)g.M * (double)g.K * (double)wrows, st);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, (const T*)src, (const T*)wgt, wrows, bias, (T*)out,
+                     zs > 1 ? ws : (float*)nullptr, ldc, act, tiles_n, kps);
+  prof_end(PROF_GATHER_GEMM, st);
+  return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t gather_gemm_t(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias,
+                                void* out, float* ws, size_t ws_bytes, int ldc, int act, hipStream_t st) {
+  if (g.M <= 0) return hipSuccess;
+  constexpr int BKE = 128 / (int)sizeof(T);
+  // tile choice by GEMM-N
+  int BN = ldc > 64 ? 128 : (ldc > 32 ? 64 : 32);
+  const int BM = 128;
+  const int tiles = ((g.M + BM - 1) / BM) * ((ldc + BN - 1) / BN);
+  const int nk = (g.K + BKE - 1) / BKE;
+  // split-K when the grid cannot fill the chip: aim for >= 2 workgroups per CU, keep >= 4 k-steps per split
+  int splits = 1;
+  const size_t out_elems = (size_t)g.N * g.OH * g.OW * ldc;
+  if (tiles < g_num_cu && nk >= 8 && ws != nullptr && ws_bytes >= out_elems * sizeof(float)) {
+    splits = (2 * g_num_cu + tiles - 1) / tiles;
+    if (splits > nk / 4) splits = nk / 4;
+    if (splits < 1) splits = 1;
+  }
+  if (splits > 1) {
+    hipError_t e = hipMemsetAsync(ws, 0, out_elems * sizeof(float), st);
+    if (e != hipSuccess) return e;
+  }
+  hipError_t e;
+  if (BN == 128) e = launch_gg<T, 128, 128, 2, 2>(g, src, wgt, wrows, bias, out, ws, ldc, act, splits, st);
+  else if (BN == 64) e = launch_gg<T, 128, 64, 2, 2>(g, src, wgt, wrows, bias, out, ws, ldc, act, splits, st);
+  else e = launch_gg<T, 128, 32, 4, 1>(g, src, wgt, wrows, bias, out, ws, ldc, act, splits, st);
+  if (e != hipSuccess) return e;
+  if (splits > 1) {
+    const int threads = 256;
+    size_t blocks = (out_elems + threads - 1) / threads;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_finalize_kernel<T>, dim3((unsigned)blocks), dim3(threads), 0, st, (const float*)ws, bias,
+                       (T*)out, out_elems, ldc, wrows, act);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
+hipError_t gather_gemm(int dtype, const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias,
+                       void* out, float* ws, size_t ws_bytes, int ldc, int act, hipStream_t st) {
+  if (dtype == DT_BF16) return gather_gemm_t<bf16_t>(g, src, wgt, wrows, bias, out, ws, ws_bytes, ldc, act, st);
+  return gather_gemm_t<float>(g, src, wgt, wrows, bias, out, ws, ws_bytes, ldc, act, st);
+}
+
+template <typename T, int BM, int BN>
+static hipError_t launch_wg(const GatherDesc& g, const void* src, const void* dy, int co_rows, int ldy, float* dw,
+                            hipStream_t st) {
+  constexpr int BR = 128 / (int)sizeof(T);
+  const int tiles_c = (co_rows + BM - 1) / BM;
+  const int tiles_k = (g.K + BN - 1) / BN;
+  const int nchunks = (g.M + BR - 1) / BR;
+  const int tiles = tiles_c * tiles_k;
+  int splits = (4 * g_num_cu + tiles - 1) / tiles;
+  if (splits > nchunks / 2) splits = nchunks / 2;
+  if (splits < 1) splits = 1;
+  const int cps = (nchunks + splits - 1) / splits;
+  const int zs = (nchunks + cps - 1) / cps;
+  const size_t lds = 2 * (size_t)BR * (BM + BN) * sizeof(T);
+  auto kern = wgrad_kernel<T, BM, BN>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  prof_begin(PROF_WGRAD, 2.0 * (double)g.M * (double)g.K * (double)co_rows, st);
+  hipLaunchKernelGGL(kern, dim3(tiles, 1, zs), dim3(256), lds, st, g, (const T*)src, (const T*)dy, co_rows, ldy, dw,
+                     tiles_k, cps);
+  prof_end(PROF_WGRAD, st);
+  return hipGetLastError();
+}
+
+hipError_t wgrad_gemm(int dtype, const GatherDesc& g, const void* src, const void* dy, int co_rows, int ldy, float* dw,
+                      hipStream_t st) {
+  if (g.M <= 0) return hipSuccess;
+  if (dtype == DT_BF16) return launch_wg<bf16_t, 128, 128>(g, src, dy, co_rows, ldy, dw, st);
+  return launch_wg<float, 128, 128>(g, src, dy, co_rows, ldy, dw, st);
+}
+
+void set_num_cu(int n) { g_num_cu = n > 0 ? n : 256; }
+
+}  // namespace dei2i

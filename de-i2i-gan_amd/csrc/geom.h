@@ -1,0 +1,196 @@
+// Gather geometry shared by the implicit-GEMM conv kernels (forward, dgrad, wgrad) and by the CPU
+// geometry check in tests/hostcheck.  One descriptor describes "output pixel m, tap t -> source pixel":
+//
+//   m -> (n, oy, ox)                       over an Ho x Wo output grid, M = N*Ho*Wo
+//   t -> (ty, tx) on a th x tw tap grid
+//   y = oy*sh + by0 + ty*ys ; x likewise   logical source coordinate (post-upsample extent Hl x Wl)
+//   boundary: reflect (index -1 -> 1, no repeat) or zero (out of range contributes 0)
+//   nearest upsample: physical row = y >> up
+//   output pixel lands at (n, oy*oys + oy0, ox*oxs + ox0) of an (N, OH, OW, ldc) tensor
+//
+// forward conv : sh = stride, by0 = -pad, ys = +1                      (reference: nn.Conv2d call sites,
+//                architecture.py:51-56,95-100,228-233; normalization.py:17-22)
+// dgrad        : source = dY, ys = -1 (the tap sign flip IS the kernel flip), zero boundary on dY's extent,
+//                one launch per output parity class for stride 2 (oys = 2, oy0 = parity)
+// wgrad        : the forward descriptor; the reduction runs over m.
+#pragma once
+#include "common.h"
+
+namespace dei2i {
+
+struct GatherDesc {
+  int N, Hs, Ws, Cs;      // physical source tensor (NHWC), Cs = channel count padded to the vector width
+  int Hl, Wl, up;         // logical extent (Hs << up), upsample shift
+  int Ho, Wo, M;          // output grid, M = N*Ho*Wo
+  int sh, sw, by0, bx0;   // y = oy*sh + by0 + ty*ys
+  int th, tw, ys, xs;     // tap grid and per-tap step
+  int pad_mode;           // PAD_ZERO / PAD_REFLECT
+  int K;                  // th*tw*Cs
+  int OH, OW, oys, oxs, oy0, ox0;   // output placement
+  int out_identity;       // 1 when the output pixel index == m
+  FastDiv fd_cs, fd_tw, fd_wo, fd_howo;
+};
+
+inline void finish_desc(GatherDesc& g) {
+  g.Hl = g.Hs << g.up;
+  g.Wl = g.Ws << g.up;
+  g.M = g.N * g.Ho * g.Wo;
+  g.K = g.th * g.tw * g.Cs;
+  g.fd_cs = make_fastdiv((uint32_t)g.Cs);
+  g.fd_tw = make_fastdiv((uint32_t)g.tw);
+  g.fd_wo = make_fastdiv((uint32_t)g.Wo);
+  g.fd_howo = make_fastdiv((uint32_t)(g.Ho * g.Wo));
+  g.out_identity = (g.OH == g.Ho && g.OW == g.Wo && g.oys == 1 && g.oxs == 1 && g.oy0 == 0 && g.ox0 == 0) ? 1 : 0;
+}
+
+DEI2I_HD void decode_m(const GatherDesc& g, int m, int& n, int& oy, int& ox) {
+  uint32_t um = (uint32_t)m;
+  uint32_t un = fd_div(um, g.fd_howo);
+  uint32_t rem = um - un * (uint32_t)(g.Ho * g.Wo);
+  uint32_t uy = fd_div(rem, g.fd_wo);
+  n = (int)un;
+  oy = (int)uy;
+  ox = (int)(rem - uy * (uint32_t)g.Wo);
+}
+
+DEI2I_HD void decode_k(const GatherDesc& g, int k, int& tap, int& ci) {
+  uint32_t t = fd_div((uint32_t)k, g.fd_cs);
+  tap = (int)t;
+  ci = k - (int)t * g.Cs;
+}
+
+// 1-D boundary handling; returns -1 when the coordinate contributes zero.
+DEI2I_HD int bound_coord(int v, int extent, int pad_mode) {
+  if (pad_mode == PAD_REFLECT) {
+    v = v < 0 ? -v : v;
+    v = v >= extent ? 2 * extent - 2 - v : v;
+    return v;
+  }
+  return (v < 0 || v >= extent) ? -1 : v;
+}
+
+// source pixel index (n*Hs + y)*Ws + x, or -1 for a zero contribution
+DEI2I_HD int src_pixel(const GatherDesc& g, int n, int oy, int ox, int tap) {
+  int ty = (int)fd_div((uint32_t)tap, g.fd_tw);
+  int tx = tap - ty * g.tw;
+  int y = bound_coord(oy * g.sh + g.by0 + ty * g.ys, g.Hl, g.pad_mode);
+  int x = bound_coord(ox * g.sw + g.bx0 + tx * g.xs, g.Wl, g.pad_mode);
+  if ((y | x) < 0) return -1;
+  return (n * g.Hs + (y >> g.up)) * g.Ws + (x >> g.up);
+}
+
+DEI2I_HD int out_pixel(const GatherDesc& g, int n, int oy, int ox) {
+  return (n * g.OH + oy * g.oys + g.oy0) * g.OW + ox * g.oxs + g.ox0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Descriptor builders (host).  conv parameters follow nn.Conv2d; `Cs` is the padded channel count
+// of whatever tensor is gathered.
+// ---------------------------------------------------------------------------------------------
+struct ConvShape {
+  int N, H, W;        // physical input (before the fused nearest upsample)
+  int Cin, Cout;      // logical channel counts
+  int kh, kw, stride, pad, pad_mode, up;
+};
+
+inline int conv_out_dim(int in_logical, int k, int stride, int pad) { return (in_logical + 2 * pad - k) / stride + 1; }
+
+inline GatherDesc make_fwd_desc(const ConvShape& c, int Cs) {
+  GatherDesc g{};
+  g.N = c.N; g.Hs = c.H; g.Ws = c.W; g.Cs = Cs; g.up = c.up;
+  g.Ho = conv_out_dim(c.H << c.up, c.kh, c.stride, c.pad);
+  g.Wo = conv_out_dim(c.W << c.up, c.kw, c.stride, c.pad);
+  g.sh = g.sw = c.stride; g.by0 = g.bx0 = -c.pad;
+  g.th = c.kh; g.tw = c.kw; g.ys = g.xs = 1;
+  g.pad_mode = c.pad_mode;
+  g.OH = g.Ho; g.OW = g.Wo; g.oys = g.oxs = 1; g.oy0 = g.ox0 = 0;
+  finish_desc(g);
+  return g;
+}
+
+// Gradient w.r.t. the conv's (logical, upsampled) input.
+//  reflect : the output is the gradient of the PADDED logical input, (N, Hl+2p, Wl+2p, Cin) -- fold_pad folds
+//            the halo (and the 2x2 upsample cells) back afterwards;
+//  zero    : the output is the gradient of the logical input itself (the halo's gradient is dropped).
+// One descriptor per output parity class (ay, ax) in [0,stride)^2; class (ay,ax) uses taps ky = ay + stride*j.
+inline int dgrad_num_classes(const ConvShape& c) { return c.stride * c.stride; }
+inline int dgrad_taps(int k, int stride, int a) { return a < k ? (k - a + stride - 1) / stride : 0; }
+inline int dgrad_out_h(const ConvShape& c) { return (c.H << c.up) + (c.pad_mode == PAD_REFLECT ? 2 * c.pad : 0); }
+inline int dgrad_out_w(const ConvShape& c) { return (c.W << c.up) + (c.pad_mode == PAD_REFLECT ? 2 * c.pad : 0); }
+
+inline GatherDesc make_dgrad_desc(const ConvShape& c, int CoutS, int ay, int ax) {
+  GatherDesc g{};
+  const int Ho = conv_out_dim(c.H << c.up, c.kh, c.stride, c.pad);
+  const int Wo = conv_out_dim(c.W << c.up, c.kw, c.stride, c.pad);
+  const int OHt = dgrad_out_h(c), OWt = dgrad_out_w(c);
+  // coordinate in the padded frame: hp = (h_out_tensor) + off, off = 0 (reflect) or pad (zero mode)
+  const int off = (c.pad_mode == PAD_REFLECT) ? 0 : c.pad;
+  // class a covers padded coords hp == a (mod stride): hp = stride*u + a ; tensor row = hp - off
+  // first u such that stride*u + a - off >= 0
+  const int s = c.stride;
+  auto first_u = [&](int a) { int v = off - a; return v <= 0 ? 0 : (v + s - 1) / s; };
+  auto count_u = [&](int a, int extent) {   // rows r = s*u + a - off in [0, extent)
+    int u0 = first_u(a);
+    int r0 = s * u0 + a - off;
+    return r0 >= extent ? 0 : (extent - 1 - r0) / s + 1;
+  };
+  const int uy0 = first_u(ay), ux0 = first_u(ax);
+  g.N = c.N; g.Hs = Ho; g.Ws = Wo; g.Cs = CoutS; g.up = 0;
+  g.Ho = count_u(ay, OHt); g.Wo = count_u(ax, OWt);
+  // source row ho = (hp - ky)/s = u - j with hp = s*u + a, ky = a + s*j ; u = oy + u0
+  g.sh = g.sw = 1; g.by0 = uy0; g.bx0 = ux0;
+  g.th = dgrad_taps(c.kh, s, ay); g.tw = dgrad_taps(c.kw, s, ax); g.ys = g.xs = -1;
+  g.pad_mode = PAD_ZERO;
+  g.OH = OHt; g.OW = OWt; g.oys = g.oxs = s;
+  g.oy0 = s * uy0 + ay - off; g.ox0 = s * ux0 + ax - off;
+  if (g.Ho <= 0 || g.Wo <= 0 || g.th <= 0 || g.tw <= 0) { g.Ho = g.Wo = 0; g.th = g.tw = 1; }
+  if (g.Ho == 0) { g.Ho = 0; }
+  // finish_desc needs non-zero divisors
+  int Ho_keep = g.Ho, Wo_keep = g.Wo;
+  if (g.Ho == 0) g.Ho = 1;
+  if (g.Wo == 0) g.Wo = 1;
+  finish_desc(g);
+  if (Ho_keep == 0 || Wo_keep == 0) g.M = 0;
+  return g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Index maps shared by the device kernels and the CPU geometry check
+// ---------------------------------------------------------------------------------------------
+// packed forward weight element i of [Cout][kh*kw][CinS] -> OIHW source index, or -1 for channel padding
+DEI2I_HD long long packed_fwd_src(long long i, int Cin, int CinS, int taps) {
+  const int ci = (int)(i % CinS);
+  const long long r = i / CinS;
+  const int t = (int)(r % taps);
+  const long long co = r / taps;
+  return ci < Cin ? (co * Cin + ci) * taps + t : -1;
+}
+
+// packed dgrad weight element i of class (ay,ax): [Cin][th*tw][CoutS], entry = w[co][ci][ay+s*jy][ax+s*jx]
+DEI2I_HD long long packed_dgrad_src(long long i, int Cout, int Cin, int CoutS, int kh, int kw, int s, int ay, int ax,
+                                    int th, int tw) {
+  const int co = (int)(i % CoutS);
+  const long long r = i / CoutS;
+  const int t = (int)(r % (th * tw));
+  const long long ci = r / (th * tw);
+  const int jy = t / tw, jx = t - jy * tw;
+  return co < Cout ? (((long long)co * Cin + ci) * kh + (ay + s * jy)) * kw + (ax + s * jx) : -1;
+}
+
+// rows (or columns) of the dgrad output frame that fold onto physical row hs: every logical row of the 2^up cell,
+// plus its reflected halo images.  Writes at most 6 entries, returns the count.
+DEI2I_HD int fold_sources(int hs, int up, int Hl, int pad, int reflect, int* out) {
+  const int off = reflect ? pad : 0;
+  int n = 0;
+  for (int a = 0; a < (1 << up); ++a) {
+    const int hl = (hs << up) + a;
+    out[n++] = hl + off;
+    if (reflect) {
+      if (hl >= 1 && hl <= pad) out[n++] = pad - hl;
+      if (hl >= Hl - 1 - pad && hl <= Hl - 2) out[n++] = 2 * (Hl - 1) - hl + pad;
+    }
+  }
+  return n;
+}
+
+}  // namespace dei2i

@@ -1,0 +1,31 @@
+// Internal declarations shared by the .hip translation units of libdei2i_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "common.h"
+#include "geom.h"
+
+namespace dei2i {
+
+enum ProfFamily : int { PROF_GATHER_GEMM = 0, PROF_WGRAD = 1, PROF_FAMILIES = 2 };
+void prof_begin(int family, double flops, hipStream_t st);
+void prof_end(int family, hipStream_t st);
+
+void set_num_cu(int n);
+int num_cu();
+
+hipError_t gather_gemm(int dtype, const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias,
+                       void* out, float* ws, size_t ws_bytes, int ldc, int act, hipStream_t st);
+hipError_t wgrad_gemm(int dtype, const GatherDesc& g, const void* src, const void* dy, int co_rows, int ldy, float* dw,
+                      hipStream_t st);
+
+inline unsigned grid_for(size_t work_items, int threads, unsigned cap = 256u * 8u) {
+  size_t b = (work_items + threads - 1) / threads;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (unsigned)b;
+}
+
+}  // namespace dei2i

@@ -1,0 +1,630 @@
+// Reduction kernels: per-channel moments (BatchNorm / InstanceNorm statistics), the two-pass backward of
+// BatchNorm and SPADE(InstanceNorm), bias-gradient column sums, and the scalar losses (BCE-with-logits, L1).
+//
+// Common shape: an NHWC tensor is viewed as (rows, C); a 256-thread workgroup owns a contiguous row range,
+// thread t owns the 16-byte channel vector (t % cv) and walks rows (t / cv), (t / cv) + 256/cv, ...  Per-thread
+// fp32 partials are combined across the row-threads through LDS; the (small) cross-workgroup combine runs in
+// fp64 in a finalize kernel, so the statistics do not depend on atomics ordering.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "../../include/dei2i_hip.h"
+#include "launch.h"
+
+namespace dei2i {
+
+static inline int vec_of(int dtype) { return dtype == DT_BF16 ? 8 : 4; }
+
+// Combine per-thread partials: vals[NV][VEC] of the threads sharing a channel vector; result valid where prow == 0.
+template <int NV, int VEC>
+DEI2I_D void block_combine(float (&vals)[NV][VEC], int cv, int rpp, float* smem) {
+  const int tid = threadIdx.x;
+  const int vcol = tid % cv, prow = tid / cv;
+  const bool active = prow < rpp;
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) smem[((size_t)(q * VEC + e) * rpp + prow) * cv + vcol] = vals[q][e];
+  }
+  __syncthreads();
+  if (active && prow == 0) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float s = 0.f;
+        for (int r = 0; r < rpp; ++r) s += smem[((size_t)(q * VEC + e) * rpp + r) * cv + vcol];
+        vals[q][e] = s;
+      }
+  }
+}
+
+// ---- moments: partial[(n*chunks + chunk)*2*C + {0,C} + c] = sum x, sum x^2 over the chunk's rows ----
+template <typename T>
+__global__ __launch_bounds__(256) void moments_partial_kernel(const T* __restrict__ x, float* __restrict__ partial, int HW,
+                                                              int C, int chunks) {
+  constexpr int VEC = Elem<T>::VEC;
+  extern __shared__ float smem[];
+  const int cv = C / VEC, rpp = 256 / cv;
+  const int tid = threadIdx.x, vcol = tid % cv, prow = tid / cv;
+  const int chunk = blockIdx.x, n = blockIdx.y;
+  const int rows_per_chunk = (HW + chunks - 1) / chunks;
+  const int rbeg = chunk * rows_per_chunk, rend = min(HW, rbeg + rows_per_chunk);
+  float v[2][VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) v[0][e] = v[1][e] = 0.f;
+  if (prow < rpp) {
+    for (int r = rbeg + prow; r < rend; r += rpp) {
+      float f[VEC];
+      Elem<T>::unpack(*reinterpret_cast<const u32x4*>(x + ((size_t)n * HW + r) * C + (size_t)vcol * VEC), f);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { v[0][e] += f[e]; v[1][e] = fmaf(f[e], f[e], v[1][e]); }
+    }
+  }
+  block_combine<2, VEC>(v, cv, rpp, smem);
+  if (prow == 0 && prow < rpp) {
+    float* dst = partial + ((size_t)n * chunks + chunk) * 2 * C + (size_t)vcol * VEC;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { dst[e] = v[0][e]; dst[C + e] = v[1][e]; }
+  }
+}
+
+__global__ void bn_finalize_train_kernel(const float* __restrict__ partial, int N, int chunks, int C, double count,
+                                         const float* __restrict__ weight, const float* __restrict__ bias,
+                                         float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
+                                         float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ a,
+                                         float* __restrict__ b) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, ss = 0.0;
+  for (int i = 0; i < N * chunks; ++i) {
+    s += (double)partial[(size_t)i * 2 * C + c];
+    ss += (double)partial[(size_t)i * 2 * C + C + c];
+  }
+  const double mu = s / count;
+  double var = ss / count - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const float rs = (float)(1.0 / sqrt(var + (double)eps));
+  mean[c] = (float)mu;
+  rstd[c] = rs;
+  const float av = weight[c] * rs;
+  a[c] = av;
+  b[c] = bias[c] - (float)mu * av;
+  if (rmean != nullptr) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mu;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ void bn_finalize_eval_kernel(int C, const float* __restrict__ weight, const float* __restrict__ bias,
+                                        const float* __restrict__ rmean, const float* __restrict__ rvar, float eps,
+                                        float* __restrict__ a, float* __restrict__ b) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float av = weight[c] / sqrtf(rvar[c] + eps);
+  a[c] = av;
+  b[c] = bias[c] - rmean[c] * av;
+}
+
+__global__ void in_finalize_kernel(const float* __restrict__ partial, int N, int chunks, int C, double count, float eps,
+                                   float* __restrict__ mean, float* __restrict__ rstd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * C) return;
+  const int n = i / C, c = i % C;
+  double s = 0.0, ss = 0.0;
+  for (int k = 0; k < chunks; ++k) {
+    s += (double)partial[((size_t)n * chunks + k) * 2 * C + c];
+    ss += (double)partial[((size_t)n * chunks + k) * 2 * C + C + c];
+  }
+  const double mu = s / count;
+  double var = ss / count - mu * mu;
+  if (var < 0.0) var = 0.0;
+  mean[i] = (float)mu;
+  rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// ---- BatchNorm backward ----
+// partial[(chunk*2 + {0,1})*C + c] = sum g, sum g*xhat ; g = dz*act'(a*y+b), xhat = (y-mean)*rstd
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict__ dz, const T* __restrict__ y,
+                                                             const float* __restrict__ a, const float* __restrict__ b,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             int act, float* __restrict__ partial, size_t pixels, int C,
+                                                             int chunks) {
+  constexpr int VEC = Elem<T>::VEC;
+  extern __shared__ float smem[];
+  const int cv = C / VEC, rpp = 256 / cv;
+  const int tid = threadIdx.x, vcol = tid % cv, prow = tid / cv;
+  const int chunk = blockIdx.x;
+  const size_t rows_per_chunk = (pixels + chunks - 1) / chunks;
+  const size_t rbeg = (size_t)chunk * rows_per_chunk;
+  const size_t rend = rbeg + rows_per_chunk < pixels ? rbeg + rows_per_chunk : pixels;
+  float v[2][VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) v[0][e] = v[1][e] = 0.f;
+  if (prow < rpp) {
+    float av[VEC], bv[VEC], mv[VEC], rv[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int c = vcol * VEC + e;
+      av[e] = a[c]; bv[e] = b[c]; mv[e] = mean[c]; rv[e] = rstd[c];
+    }
+    for (size_t r = rbeg + prow; r < rend; r += rpp) {
+      float d[VEC], yy[VEC];
+      Elem<T>::unpack(*reinterpret_cast<const u32x4*>(dz + r * C + (size_t)vcol * VEC), d);
+      Elem<T>::unpack(*reinterpret_cast<const u32x4*>(y + r * C + (size_t)vcol * VEC), yy);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float z = fmaf(av[e], yy[e], bv[e]);
+        const float g = d[e] * act_grad_from_out(z, act);
+        v[0][e] += g;
+        v[1][e] = fmaf(g, (yy[e] - mv[e]) * rv[e], v[1][e]);
+      }
+    }
+  }
+  block_combine<2, VEC>(v, cv, rpp, smem);
+  if (prow == 0 && prow < rpp) {
+    float* dst = partial + (size_t)chunk * 2 * C + (size_t)vcol * VEC;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { dst[e] = v[0][e]; dst[C + e] = v[1][e]; }
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int C, float* __restrict__ dweight,
+                                       float* __restrict__ dbias) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < chunks; ++k) {
+    s1 += (double)partial[(size_t)k * 2 * C + c];
+    s2 += (double)partial[(size_t)k * 2 * C + C + c];
+  }
+  dbias[c] = (float)s1;
+  dweight[c] = (float)s2;
+}
+
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ y, const float* __restrict__ a,
+                                    const float* __restrict__ b, const float* __restrict__ mean,
+                                    const float* __restrict__ rstd, int act, int train, const float* __restrict__ dweight,
+                                    const float* __restrict__ dbias, float inv_count, T* __restrict__ dy, size_t nvec,
+                                    int cv) {
+  constexpr int VEC = Elem<T>::VEC;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) * VEC;
+    float d[VEC], yy[VEC];
+    Elem<T>::unpack(*reinterpret_cast<const u32x4*>(dz + i * VEC), d);
+    Elem<T>::unpack(*reinterpret_cast<const u32x4*>(y + i * VEC), yy);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float av = a[c + e];
+      const float z = fmaf(av, yy[e], b[c + e]);
+      float g = d[e] * act_grad_from_out(z, act);
+      if (train) {
+        const float xh = (yy[e] - mean[c + e]) * rstd[c + e];
+        g = g - dbias[c + e] * inv_count - xh * dweight[c + e] * inv_count;
+      }
+      d[e] = av * g;
+    }
+    *reinterpret_cast<u32x4*>(dy + i * VEC) = Elem<T>::pack(d);
+  }
+}
+
+DEI2I_D int border_class(int i, int extent) { return i < 2 ? i : (i >= extent - 2 ? 4 - (extent - 1 - i) : 2); }
+
+// ---- SPADE backward, pass 1 ----
+// partial[((n*chunks + chunk)*4 + q)*C + c], q: 0 sum dxhat, 1 sum dxhat*xhat, 2 sum dgamma (interior class), 3 sum dbeta (interior)
+template <typename T>
+__global__ __launch_bounds__(256) void spade_bwd_partial_kernel(const T* __restrict__ dz, const T* __restrict__ z,
+                                                                const T* __restrict__ x, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, const T* __restrict__ gb,
+                                                                int gb_mode, T* __restrict__ dgb_dense,
+                                                                float* __restrict__ dgb_cls, T* __restrict__ dxhat,
+                                                                float* __restrict__ partial, int H, int W, int C, int up,
+                                                                int chunks) {
+  constexpr int VEC = Elem<T>::VEC;
+  extern __shared__ float smem[];
+  const int cv = C / VEC, rpp = 256 / cv;
+  const int tid = threadIdx.x, vcol = tid % cv, prow = tid / cv;
+  const int chunk = blockIdx.x, n = blockIdx.y;
+  const int HW = H * W, Hs = H >> up, Ws = W >> up;
+  const int rows_per_chunk = (HW + chunks - 1) / chunks;
+  const int rbeg = chunk * rows_per_chunk, rend = min(HW, rbeg + rows_per_chunk);
+  float v[4][VEC];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[q][e] = 0.f;
+  if (prow < rpp) {
+    const int c = vcol * VEC;
+    float mv[VEC], rv[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { mv[e] = mean[n * C + c + e]; rv[e] = rstd[n * C + c + e]; }
+    for (int r = rbeg + prow; r < rend; r += rpp) {
+      const int h = r / W, w = r - h * W;
+      const size_t opix = (size_t)n * HW + r;
+      float d[VEC], zz[VEC], xv[VEC], gm[VEC];
+      Elem<T>::unpack(*reinterpret_cast<const u32x4*>(dz + opix * C + c), d);
+      Elem<T>::unpack(*reinterpret_cast<const u32x4*>(z + opix * C + c), zz);
+      Elem<T>::unpack(*reinterpret_cast<const u32x4*>(x + (((size_t)n * Hs + (h >> up)) * Ws + (w >> up)) * C + c), xv);
+      size_t gpix;
+      int cy = 2, cx = 2;
+      if (gb_mode == 0) {
+        gpix = opix;
+      } else {
+        cy = border_class(h, H); cx = border_class(w, W);
+        gpix = ((size_t)n * 5 + cy) * 5 + cx;
+      }
+      Elem<T>::unpack(*reinterpret_cast<const u32x4*>(gb + gpix * 2 * C + c), gm);
+      float dg[VEC], db[VEC], dxh[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float g = zz[e] > 0.f ? d[e] : 0.f;
+        const float xh = (xv[e] - mv[e]) * rv[e];
+        dg[e] = g * xh;
+        db[e] = g;
+        dxh[e] = g * (1.f + gm[e]);
+        v[0][e] += dxh[e];
+        v[1][e] = fmaf(dxh[e], xh, v[1][e]);
+      }
+      *reinterpret_cast<u32x4*>(dxhat + opix * C + c) = Elem<T>::pack(dxh);
+      if (gb_mode == 0) {
+        *reinterpret_cast<u32x4*>(dgb_dense + opix * 2 * C + c) = Elem<T>::pack(dg);
+        *reinterpret_cast<u32x4*>(dgb_dense + opix * 2 * C + C + c) = Elem<T>::pack(db);
+      } else if (cy == 2 && cx == 2) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { v[2][e] += dg[e]; v[3][e] += db[e]; }
+      } else {      // border classes: O(perimeter) pixels, direct atomics
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          atomicAdd(dgb_cls + gpix * 2 * C + c + e, dg[e]);
+          atomicAdd(dgb_cls + gpix * 2 * C + C + c + e, db[e]);
+        }
+      }
+    }
+  }
+  block_combine<4, VEC>(v, cv, rpp, smem);
+  if (prow == 0 && prow < rpp) {
+    float* dst = partial + ((size_t)n * chunks + chunk) * 4 * C + (size_t)vcol * VEC;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) dst[(size_t)q * C + e] = v[q][e];
+  }
+}
+
+// coef[(n*2 + {0,1})*C + c] = s1/M, s2/M ; interior-class gamma/beta sums added into dgb_cls[n,2,2,:]
+__global__ void spade_bwd_finalize_kernel(const float* __restrict__ partial, int N, int chunks, int C, double count,
+                                          float* __restrict__ coef, float* __restrict__ dgb_cls) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * C) return;
+  const int n = i / C, c = i % C;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int k = 0; k < chunks; ++k)
+    for (int q = 0; q < 4; ++q) s[q] += (double)partial[(((size_t)n * chunks + k) * 4 + q) * C + c];
+  coef[((size_t)n * 2 + 0) * C + c] = (float)(s[0] / count);
+  coef[((size_t)n * 2 + 1) * C + c] = (float)(s[1] / count);
+  if (dgb_cls != nullptr) {
+    const size_t gpix = ((size_t)n * 5 + 2) * 5 + 2;
+    dgb_cls[gpix * 2 * C + c] += (float)s[2];
+    dgb_cls[gpix * 2 * C + C + c] += (float)s[3];
+  }
+}
+
+// dx (source resolution) = rstd * ( sum_cell dxhat - cnt*c1 - cnt*xhat*c2 ) (+ addend)
+template <typename T>
+__global__ void spade_bwd_apply_kernel(const T* __restrict__ dxhat, const T* __restrict__ x, const float* __restrict__ mean,
+                                       const float* __restrict__ rstd, const float* __restrict__ coef,
+                                       const T* __restrict__ addend, T* __restrict__ dx, int N, int H, int W, int C, int up) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cv = C / VEC;
+  const int Hs = H >> up, Ws = W >> up;
+  const size_t total = (size_t)N * Hs * Ws * cv;
+  const float cnt = (float)(1 << (2 * up));
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) * VEC;
+    size_t r = i / cv;
+    const int ws = (int)(r % Ws); r /= Ws;
+    const int hs = (int)(r % Hs);
+    const int n = (int)(r / Hs);
+    float acc[VEC], xv[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    for (int a = 0; a < (1 << up); ++a)
+      for (int b = 0; b < (1 << up); ++b) {
+        float t[VEC];
+        Elem<T>::unpack(*reinterpret_cast<const u32x4*>(
+                            dxhat + (((size_t)n * H + ((hs << up) + a)) * W + ((ws << up) + b)) * C + c), t);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += t[e];
+      }
+    Elem<T>::unpack(*reinterpret_cast<const u32x4*>(x + i * VEC), xv);
+    float ad[VEC];
+    if (addend != nullptr) Elem<T>::unpack(*reinterpret_cast<const u32x4*>(addend + i * VEC), ad);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float rs = rstd[n * C + c + e];
+      const float xh = (xv[e] - mean[n * C + c + e]) * rs;
+      float v = rs * (acc[e] - cnt * coef[((size_t)n * 2) * C + c + e] - cnt * xh * coef[((size_t)n * 2 + 1) * C + c + e]);
+      if (addend != nullptr) v += ad[e];
+      acc[e] = v;
+    }
+    *reinterpret_cast<u32x4*>(dx + i * VEC) = Elem<T>::pack(acc);
+  }
+}
+
+// ---- column sums (bias gradient) ----
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, float* __restrict__ out, size_t rows, int C) {
+  constexpr int VEC = Elem<T>::VEC;
+  extern __shared__ float smem[];
+  const int cv = C / VEC, rpp = 256 / cv;
+  const int tid = threadIdx.x, vcol = tid % cv, prow = tid / cv;
+  const size_t rows_per_block = (rows + gridDim.x - 1) / gridDim.x;
+  const size_t rbeg = (size_t)blockIdx.x * rows_per_block;
+  const size_t rend = rbeg + rows_per_block < rows ? rbeg + rows_per_block : rows;
+  float v[1][VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) v[0][e] = 0.f;
+  if (prow < rpp) {
+    for (size_t r = rbeg + prow; r < rend; r += rpp) {
+      float f[VEC];
+      Elem<T>::unpack(*reinterpret_cast<const u32x4*>(g + r * C + (size_t)vcol * VEC), f);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[0][e] += f[e];
+    }
+  }
+  block_combine<1, VEC>(v, cv, rpp, smem);
+  if (prow == 0 && prow < rpp) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) atomicAdd(out + vcol * VEC + e, v[0][e]);
+  }
+}
+
+// ---- scalar losses ----
+DEI2I_D float block_sum_256(float v, float* smem) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) smem[wave] = v;
+  __syncthreads();
+  return smem[0] + smem[1] + smem[2] + smem[3];
+}
+
+__global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ x, const float* __restrict__ t, float tconst,
+                                                      size_t n, float inv_n, float* __restrict__ out) {
+  __shared__ float smem[4];
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float xv = x[i], tv = t != nullptr ? t[i] : tconst;
+    acc += fmaxf(xv, 0.f) - xv * tv + log1pf(expf(-fabsf(xv)));
+  }
+  const float s = block_sum_256(acc, smem);
+  if (threadIdx.x == 0) atomicAdd(out, s * inv_n);
+}
+
+__global__ void bce_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t, float tconst, size_t n, float inv_n,
+                               const float* __restrict__ gout, float* __restrict__ dx) {
+  const float go = gout[0] * inv_n;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float xv = x[i], tv = t != nullptr ? t[i] : tconst;
+    dx[i] = (1.f / (1.f + expf(-xv)) - tv) * go;
+  }
+}
+
+__global__ __launch_bounds__(256) void l1_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n,
+                                                     float inv_n, float* __restrict__ out) {
+  __shared__ float smem[4];
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    acc += fabsf(a[i] - (b != nullptr ? b[i] : 0.f));
+  const float s = block_sum_256(acc, smem);
+  if (threadIdx.x == 0) atomicAdd(out, s * inv_n);
+}
+
+__global__ void l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n, float inv_n,
+                              const float* __restrict__ gout, float* __restrict__ da, float* __restrict__ db) {
+  const float go = gout[0] * inv_n;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float d = a[i] - (b != nullptr ? b[i] : 0.f);
+    const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    if (da != nullptr) da[i] = sgn * go;
+    if (db != nullptr) db[i] = -sgn * go;
+  }
+}
+
+}  // namespace dei2i
+
+using namespace dei2i;
+
+static inline bool cv_ok(int dtype, int C) {
+  const int vec = dtype == DT_BF16 ? 8 : 4;
+  return C > 0 && C % vec == 0 && C / vec <= 256;
+}
+static inline size_t combine_lds(int dtype, int nv) { return (size_t)nv * (dtype == DT_BF16 ? 8 : 4) * 256 * sizeof(float); }
+
+extern "C" {
+
+int dei2i_moments_chunks(int HW) {
+  int c = HW / 512;
+  if (c < 1) c = 1;
+  if (c > 128) c = 128;
+  return c;
+}
+
+int dei2i_moments_partial(int dtype, int N, int HW, int C, const void* x, float* partial, dei2i_stream s) {
+  if (N <= 0 || HW <= 0 || !cv_ok(dtype, C) || !x || !partial) return DEI2I_ERR_BAD_ARG;
+  const int chunks = dei2i_moments_chunks(HW);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(moments_partial_kernel<bf16_t>, dim3(chunks, N), dim3(256), combine_lds(dtype, 2), (hipStream_t)s,
+                       (const bf16_t*)x, partial, HW, C, chunks);
+  else
+    hipLaunchKernelGGL(moments_partial_kernel<float>, dim3(chunks, N), dim3(256), combine_lds(dtype, 2), (hipStream_t)s,
+                       (const float*)x, partial, HW, C, chunks);
+  return (int)hipGetLastError();
+}
+
+int dei2i_bn_finalize_train(int N, int HW, int C, const float* partial, const float* weight, const float* bias,
+                            float* running_mean, float* running_var, float momentum, float eps, float* mean, float* rstd,
+                            float* a, float* b, dei2i_stream s) {
+  if (N <= 0 || HW <= 0 || C <= 0 || !partial || !weight || !bias || !mean || !rstd || !a || !b) return DEI2I_ERR_BAD_ARG;
+  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)s, partial, N,
+                     dei2i_moments_chunks(HW), C, (double)N * (double)HW, weight, bias, running_mean, running_var, momentum,
+                     eps, mean, rstd, a, b);
+  return (int)hipGetLastError();
+}
+
+int dei2i_bn_finalize_eval(int C, const float* weight, const float* bias, const float* running_mean, const float* running_var,
+                           float eps, float* a, float* b, dei2i_stream s) {
+  if (C <= 0 || !weight || !bias || !running_mean || !running_var || !a || !b) return DEI2I_ERR_BAD_ARG;
+  hipLaunchKernelGGL(bn_finalize_eval_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)s, C, weight, bias, running_mean,
+                     running_var, eps, a, b);
+  return (int)hipGetLastError();
+}
+
+int dei2i_in_finalize(int N, int HW, int C, const float* partial, float eps, float* mean, float* rstd, dei2i_stream s) {
+  if (N <= 0 || HW <= 0 || C <= 0 || !partial || !mean || !rstd) return DEI2I_ERR_BAD_ARG;
+  hipLaunchKernelGGL(in_finalize_kernel, dim3((N * C + 63) / 64), dim3(64), 0, (hipStream_t)s, partial, N,
+                     dei2i_moments_chunks(HW), C, (double)HW, eps, mean, rstd);
+  return (int)hipGetLastError();
+}
+
+int dei2i_colsum(int dtype, size_t rows, int C, const void* g, float* out, dei2i_stream s) {
+  if (rows == 0 || !cv_ok(dtype, C) || !g || !out) return DEI2I_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)s;
+  hipError_t e = hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st);
+  if (e != hipSuccess) return (int)e;
+  size_t blocks = rows / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 1024) blocks = 1024;
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), combine_lds(dtype, 1), st, (const bf16_t*)g, out, rows, C);
+  else
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3((unsigned)blocks), dim3(256), combine_lds(dtype, 1), st, (const float*)g, out, rows, C);
+  return (int)hipGetLastError();
+}
+
+int dei2i_bn_bwd_chunks(size_t pixels) {
+  size_t c = pixels / 512;
+  if (c < 1) c = 1;
+  if (c > 512) c = 512;
+  return (int)c;
+}
+
+int dei2i_bn_bwd_partial(int dtype, size_t pixels, int C, const void* dz, const void* y, const float* a, const float* b,
+                         const float* mean, const float* rstd, int act, float* partial, dei2i_stream s) {
+  if (pixels == 0 || !cv_ok(dtype, C) || !dz || !y || !a || !b || !mean || !rstd || !partial) return DEI2I_ERR_BAD_ARG;
+  const int chunks = dei2i_bn_bwd_chunks(pixels);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(bn_bwd_partial_kernel<bf16_t>, dim3(chunks), dim3(256), combine_lds(dtype, 2), (hipStream_t)s,
+                       (const bf16_t*)dz, (const bf16_t*)y, a, b, mean, rstd, act, partial, pixels, C, chunks);
+  else
+    hipLaunchKernelGGL(bn_bwd_partial_kernel<float>, dim3(chunks), dim3(256), combine_lds(dtype, 2), (hipStream_t)s,
+                       (const float*)dz, (const float*)y, a, b, mean, rstd, act, partial, pixels, C, chunks);
+  return (int)hipGetLastError();
+}
+
+int dei2i_bn_bwd_apply(int dtype, size_t pixels, int C, const void* dz, const void* y, const float* a, const float* b,
+                       const float* mean, const float* rstd, int act, int train, const float* partial, int chunks,
+                       float* dweight, float* dbias, void* dy, dei2i_stream s) {
+  const int vec = dtype == DT_BF16 ? 8 : 4;
+  if (pixels == 0 || !cv_ok(dtype, C) || !dz || !y || !a || !b || !mean || !rstd || !partial || !dweight || !dbias || !dy)
+    return DEI2I_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)s;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial, chunks, C, dweight, dbias);
+  const size_t nvec = pixels * (size_t)(C / vec);
+  const unsigned grid = grid_for(nvec, 256, 256u * 16u);
+  const float inv = 1.f / (float)pixels;
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)y, a, b, mean,
+                       rstd, act, train, (const float*)dweight, (const float*)dbias, inv, (bf16_t*)dy, nvec, C / vec);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dz, (const float*)y, a, b, mean,
+                       rstd, act, train, (const float*)dweight, (const float*)dbias, inv, (float*)dy, nvec, C / vec);
+  return (int)hipGetLastError();
+}
+
+int dei2i_spade_bwd_partial(int dtype, int N, int H, int W, int C, int up, const void* dz, const void* z, const void* x,
+                            const float* mean, const float* rstd, const void* gb, int gb_mode, void* dgb, void* dxhat,
+                            float* partial, dei2i_stream s) {
+  if (N <= 0 || H <= 0 || W <= 0 || !cv_ok(dtype, C) || up < 0 || up > 1 || !dz || !z || !x || !mean || !rstd || !gb || !dgb ||
+      !dxhat || !partial)
+    return DEI2I_ERR_BAD_ARG;
+  if (gb_mode == 1 && (H < 4 || W < 4)) return DEI2I_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)s;
+  const int chunks = dei2i_moments_chunks(H * W);
+  if (gb_mode == 1) {
+    hipError_t e = hipMemsetAsync(dgb, 0, (size_t)N * 25 * 2 * C * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(spade_bwd_partial_kernel<bf16_t>, dim3(chunks, N), dim3(256), combine_lds(dtype, 4), st,
+                       (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)x, mean, rstd, (const bf16_t*)gb, gb_mode,
+                       gb_mode == 0 ? (bf16_t*)dgb : (bf16_t*)nullptr, gb_mode == 1 ? (float*)dgb : (float*)nullptr,
+                       (bf16_t*)dxhat, partial, H, W, C, up, chunks);
+  else
+    hipLaunchKernelGGL(spade_bwd_partial_kernel<float>, dim3(chunks, N), dim3(256), combine_lds(dtype, 4), st,
+                       (const float*)dz, (const float*)z, (const float*)x, mean, rstd, (const float*)gb, gb_mode,
+                       gb_mode == 0 ? (float*)dgb : (float*)nullptr, gb_mode == 1 ? (float*)dgb : (float*)nullptr,
+                       (float*)dxhat, partial, H, W, C, up, chunks);
+  return (int)hipGetLastError();
+}
+
+int dei2i_spade_bwd_apply(int dtype, int N, int H, int W, int C, int up, const void* dxhat, const void* x, const float* mean,
+                          const float* rstd, const float* partial, int chunks, float* dgb_cls, float* coef,
+                          const void* addend, void* dx, dei2i_stream s) {
+  const int vec = dtype == DT_BF16 ? 8 : 4;
+  if (N <= 0 || H <= 0 || W <= 0 || !cv_ok(dtype, C) || up < 0 || up > 1 || !dxhat || !x || !mean || !rstd || !partial ||
+      !coef || !dx)
+    return DEI2I_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)s;
+  hipLaunchKernelGGL(spade_bwd_finalize_kernel, dim3((N * C + 63) / 64), dim3(64), 0, st, partial, N, chunks, C,
+                     (double)H * (double)W, coef, dgb_cls);
+  const size_t total = (size_t)N * (H >> up) * (W >> up) * (C / vec);
+  const unsigned grid = grid_for(total, 256, 256u * 16u);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(spade_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dxhat, (const bf16_t*)x, mean,
+                       rstd, (const float*)coef, (const bf16_t*)addend, (bf16_t*)dx, N, H, W, C, up);
+  else
+    hipLaunchKernelGGL(spade_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dxhat, (const float*)x, mean,
+                       rstd, (const float*)coef, (const float*)addend, (float*)dx, N, H, W, C, up);
+  return (int)hipGetLastError();
+}
+
+int dei2i_bce_logits_fwd(size_t n, const float* x, const float* target, float tconst, float* out, dei2i_stream s) {
+  if (n == 0 || !x || !out) return DEI2I_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)s;
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(float), st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(bce_fwd_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, st, x, target, tconst, n, 1.f / (float)n, out);
+  return (int)hipGetLastError();
+}
+
+int dei2i_bce_logits_bwd(size_t n, const float* x, const float* target, float tconst, const float* gout, float* dx,
+                         dei2i_stream s) {
+  if (n == 0 || !x || !gout || !dx) return DEI2I_ERR_BAD_ARG;
+  hipLaunchKernelGGL(bce_bwd_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, (hipStream_t)s, x, target, tconst, n,
+                     1.f / (float)n, gout, dx);
+  return (int)hipGetLastError();
+}
+
+int dei2i_l1_fwd(size_t n, const float* a, const float* b, float* out, dei2i_stream s) {
+  if (n == 0 || !a || !out) return DEI2I_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)s;
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(float), st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(l1_fwd_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, st, a, b, n, 1.f / (float)n, out);
+  return (int)hipGetLastError();
+}
+
+int dei2i_l1_bwd(size_t n, const float* a, const float* b, const float* gout, float* da, float* db, dei2i_stream s) {
+  if (n == 0 || !a || !gout) return DEI2I_ERR_BAD_ARG;
+  hipLaunchKernelGGL(l1_bwd_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, (hipStream_t)s, a, b, n, 1.f / (float)n, gout,
+                     da, db);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+// Library bookkeeping: device query, error strings, in-library HIP-event timing of one kernel family.
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include <vector>
+
+#include "../../include/dei2i_hip.h"
+#include "launch.h"
+
+namespace dei2i {
+
+static int g_cus = 256;
+void set_num_cu_rt(int n) { g_cus = n > 0 ? n : 256; }
+int num_cu() { return g_cus; }
+
+struct ProfState {
+  bool on = false;
+  std::vector<hipEvent_t> starts, stops;
+  size_t used = 0;
+  double flops = 0.0;
+};
+static ProfState g_prof[PROF_FAMILIES];
+
+void prof_begin(int family, double flops, hipStream_t st) {
+  ProfState& p = g_prof[family];
+  if (!p.on) return;
+  if (p.used == p.starts.size()) {
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    p.starts.push_back(a);
+    p.stops.push_back(b);
+  }
+  p.flops += flops;
+  hipEventRecord(p.starts[p.used], st);
+}
+
+void prof_end(int family, hipStream_t st) {
+  ProfState& p = g_prof[family];
+  if (!p.on) return;
+  hipEventRecord(p.stops[p.used], st);
+  p.used++;
+}
+
+}  // namespace dei2i
+
+using namespace dei2i;
+
+extern "C" {
+
+int dei2i_version(void) { return 100; }
+
+int dei2i_init(int device) {
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) return (int)e;
+  set_num_cu_rt(prop.multiProcessorCount);
+  set_num_cu(prop.multiProcessorCount);
+  return 0;
+}
+
+const char* dei2i_error_string(int code) {
+  if (code == DEI2I_ERR_BAD_ARG) return "dei2i: bad argument";
+  if (code == DEI2I_ERR_WORKSPACE) return "dei2i: workspace too small";
+  if (code >= 0) return hipGetErrorString((hipError_t)code);
+  return "dei2i: unknown error";
+}
+
+int dei2i_prof_enable(int family, int on) {
+  if (family < 0 || family >= PROF_FAMILIES) return DEI2I_ERR_BAD_ARG;
+  ProfState& p = g_prof[family];
+  p.on = on != 0;
+  p.used = 0;
+  p.flops = 0.0;
+  return 0;
+}
+
+int dei2i_prof_collect(int family, int64_t* launches, double* total_ms, double* total_flops) {
+  if (family < 0 || family >= PROF_FAMILIES) return DEI2I_ERR_BAD_ARG;
+  ProfState& p = g_prof[family];
+  double ms = 0.0;
+  for (size_t i = 0; i < p.used; ++i) {
+    hipError_t e = hipEventSynchronize(p.stops[i]);
+    if (e != hipSuccess) return (int)e;
+    float t = 0.f;
+    e = hipEventElapsedTime(&t, p.starts[i], p.stops[i]);
+    if (e != hipSuccess) return (int)e;
+    ms += t;
+  }
+  if (launches) *launches = (int64_t)p.used;
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = p.flops;
+  p.used = 0;
+  p.flops = 0.0;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,179 @@
+/*
+ * dei2i_hip.h -- C ABI of libdei2i_hip.so, the MI355X (gfx950) kernel library under the de-i2i-gan_amd
+ * Python host code.
+ *
+ * The reference (jason2714/de-i2i-gan) has no FFI of its own: its hot path is Python calling ATen ops
+ * implicitly.  Each entry point below therefore replaces the ATen op(s) issued at the cited reference
+ * call sites (paths relative to /root/reference/defectGAN).  All functions:
+ *   - take raw device pointers + plain ints, launch on the caller's hipStream_t, allocate nothing,
+ *   - return 0 on success or a hipError_t / negative dei2i error code (the Python side raises RuntimeError),
+ *   - activations are NHWC with the channel stride padded to a 16-byte vector (8 bf16 / 4 f32); `dtype`
+ *     0 = bf16 storage + bf16 MFMA (fp32 accumulate), 1 = f32 storage + exact f32 MFMA (parity mode).
+ */
+#ifndef DEI2I_HIP_H
+#define DEI2I_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dei2i_stream;   /* hipStream_t */
+
+#define DEI2I_BF16 0
+#define DEI2I_F32 1
+#define DEI2I_ACT_NONE 0
+#define DEI2I_ACT_RELU 1
+#define DEI2I_ACT_LRELU 2      /* LeakyReLU(0.2), architecture.py:15 */
+#define DEI2I_PAD_ZERO 0       /* also 'valid' when pad == 0 */
+#define DEI2I_PAD_REFLECT 1
+
+#define DEI2I_ERR_BAD_ARG (-2)
+#define DEI2I_ERR_WORKSPACE (-3)
+
+/* nn.Conv2d geometry (architecture.py:51-56,95-100,228-233,320-337; normalization.py:17-22;
+ * discriminator.py:60-90).  `up` = 1 fuses the preceding nn.Upsample(scale_factor=2) (architecture.py:203). */
+typedef struct dei2i_conv {
+  int dtype;
+  int N, H, W;          /* physical input extent (before the fused upsample) */
+  int Cin, Cout;        /* logical channels */
+  int CinS, CoutS;      /* channel strides of the x / y tensors (padded to the vector width) */
+  int kh, kw, stride, pad, pad_mode, up;
+} dei2i_conv;
+
+/* ---- library / device ---- */
+int dei2i_version(void);
+int dei2i_init(int device);                         /* queries the CU count; optional */
+const char* dei2i_error_string(int code);
+
+/* ---- packed weight layouts (replaces nothing in the reference: layout prep for the kernels) ---- */
+size_t dei2i_packed_fwd_elems(const dei2i_conv* c);      /* Cout * kh*kw * CinS */
+size_t dei2i_packed_dgrad_elems(const dei2i_conv* c);    /* sum over stride^2 parity classes of Cin * taps * CoutS */
+int dei2i_pack_weight_fwd(const dei2i_conv* c, const float* w_oihw, void* packed, dei2i_stream s);
+int dei2i_pack_weight_dgrad(const dei2i_conv* c, const float* w_oihw, void* packed, dei2i_stream s);
+/* packed fp32 wgrad [Cout][kh*kw][CinS] -> OIHW fp32 (beta = 0: overwrite, 1: accumulate) */
+int dei2i_unpack_wgrad(const dei2i_conv* c, const float* dw_packed, float* dw_oihw, float beta, dei2i_stream s);
+
+/* ---- convolution (ATen convolution / convolution_backward) ---- */
+void dei2i_conv2d_out_shape(const dei2i_conv* c, int* Ho, int* Wo);
+/* dgrad output extent: reflect -> padded logical input (H<<up)+2*pad; zero -> logical input */
+void dei2i_conv2d_dgrad_shape(const dei2i_conv* c, int* OH, int* OW);
+size_t dei2i_conv2d_workspace_bytes(const dei2i_conv* c);   /* fp32 split-K workspace upper bound (fwd and dgrad) */
+int dei2i_conv2d_fwd(const dei2i_conv* c, const void* x, const void* w_packed, const float* bias, int act, void* y,
+                     float* ws, size_t ws_bytes, dei2i_stream s);
+int dei2i_conv2d_dgrad(const dei2i_conv* c, const void* dy, const void* wd_packed, void* dx_ext, float* ws,
+                       size_t ws_bytes, dei2i_stream s);
+/* dw_packed (fp32, dei2i_packed_fwd_elems) is zeroed by the call, then accumulated with fp32 atomics */
+int dei2i_conv2d_wgrad(const dei2i_conv* c, const void* x, const void* dy, float* dw_packed, dei2i_stream s);
+/* reflection_pad2d_backward + upsample_nearest2d_backward: fold the dgrad output (N,OH,OW,C) back onto the
+ * physical input (N,H,W,C); optional addend (residual-branch gradient) is summed in the same pass. */
+int dei2i_fold_pad(int dtype, int N, int H, int W, int C, int pad, int pad_mode, int up, const void* dx_ext,
+                   const void* addend, void* dx, dei2i_stream s);
+
+/* ---- layout at the module boundary (NCHW fp32 <-> NHWC compute dtype) ---- */
+int dei2i_nchw_to_nhwc(int dtype, int N, int C, int H, int W, int Cs, const float* src, void* dst, dei2i_stream s);
+int dei2i_nhwc_to_nchw(int dtype, int N, int C, int H, int W, int Cs, const void* src, float* dst, dei2i_stream s);
+/* same as nchw_to_nhwc with F.interpolate(mode='nearest') from (hs,ws) to (H,W) fused (SPADE label map,
+ * normalization.py:29) */
+int dei2i_nchw_to_nhwc_resize(int dtype, int N, int C, int hs, int ws, int H, int W, int Cs, const float* src, void* dst,
+                              dei2i_stream s);
+/* fp32 -> compute dtype cast of a flat buffer */
+int dei2i_cast_from_f32(int dtype, size_t n, const float* src, void* dst, dei2i_stream s);
+
+/* ---- per-channel moments (native_batch_norm statistics; generator.py:71,113,124; normalization.py:14) ----
+ * partial: (N, chunks, 2, C) fp32 sums / sums of squares.  chunks = dei2i_moments_chunks(HW). */
+int dei2i_moments_chunks(int HW);
+int dei2i_moments_partial(int dtype, int N, int HW, int C, const void* x, float* partial, dei2i_stream s);
+/* BatchNorm2d train: batch stats over (N,HW) -> scale/shift a[c], b[c]; mean/rstd saved for backward; running
+ * stats updated (momentum 0.1, unbiased var).  All vectors fp32[C]. */
+int dei2i_bn_finalize_train(int N, int HW, int C, const float* partial, const float* weight, const float* bias,
+                            float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                            float* rstd, float* a, float* b, dei2i_stream s);
+int dei2i_bn_finalize_eval(int C, const float* weight, const float* bias, const float* running_mean,
+                           const float* running_var, float eps, float* a, float* b, dei2i_stream s);
+/* InstanceNorm2d(affine=False): per (n,c) mean / rstd, fp32 [N][C] */
+int dei2i_in_finalize(int N, int HW, int C, const float* partial, float eps, float* mean, float* rstd, dei2i_stream s);
+
+/* ---- fused normalisation + activation, forward ---- */
+/* out = act(a[c]*x + b[c]) (+ res)   -- BatchNorm apply + LeakyReLU (+ ResBlock identity), architecture.py:116-118,174-176 */
+int dei2i_affine_act_fwd(int dtype, size_t pixels, int C, const void* x, const float* a, const float* b, const void* res,
+                         int act, void* out, dei2i_stream s);
+/* SPADE + ReLU (normalization.py:24-37, architecture.py:241-245,343-350):
+ *   out[n,h,w,c] = relu( (x[n,h>>up,w>>up,c] - mean[n,c]) * rstd[n,c] * (1 + gamma) + beta ) (+ nothing)
+ * gb is (N, Hg, Wg, 2*C): gamma = [..., :C], beta = [..., C:].  gb_mode 0: Hg x Wg == output extent;
+ * gb_mode 1: Hg = Wg = 5 "border class" table (labels constant over space; class = min(i,2) / 4-(H-1-i)). */
+int dei2i_spade_act_fwd(int dtype, int N, int H, int W, int C, int up, const void* x, const float* mean,
+                        const float* rstd, const void* gb, int gb_mode, void* out, dei2i_stream s);
+
+/* ---- backward of the above ---- */
+/* g = dz * act'(z) (LeakyReLU / ReLU expressed through the saved output z) */
+int dei2i_act_bwd(int dtype, size_t n, const void* dz, const void* z, int act, void* g, dei2i_stream s);
+/* column sums: out[c] = sum over rows of g[row][c]   (conv bias gradient) */
+int dei2i_colsum(int dtype, size_t rows, int C, const void* g, float* out, dei2i_stream s);
+/* BatchNorm backward (train): z = act(a*y+b); g = dz*act'(z); needs sum(g), sum(g*xhat) per channel.
+ * bn_bwd_partial writes (chunks, 2, C) partial sums over `pixels` rows; bn_bwd_apply finishes:
+ *   dy = a * (g - sum_g/M - xhat * sum_gx/M),  dweight = sum_gx, dbias = sum_g.   train = 0 -> dy = a*g. */
+int dei2i_bn_bwd_chunks(size_t pixels);
+int dei2i_bn_bwd_partial(int dtype, size_t pixels, int C, const void* dz, const void* y, const float* a, const float* b,
+                         const float* mean, const float* rstd, int act, float* partial, dei2i_stream s);
+int dei2i_bn_bwd_apply(int dtype, size_t pixels, int C, const void* dz, const void* y, const float* a, const float* b,
+                       const float* mean, const float* rstd, int act, int train, const float* partial, int chunks,
+                       float* dweight, float* dbias, void* dy, dei2i_stream s);
+/* SPADE backward, pass 1: g = dz*[z>0]; dgamma = g*xhat, dbeta = g -> dgb (dense T tensor, or fp32 (N,5,5,2C)
+ * in class mode; zeroed by the call); dxhat = g*(1+gamma) written to `dxhat`; per-(n,c) partial sums of dxhat,
+ * dxhat*xhat and the interior-class dgamma/dbeta -> partial (N, chunks, 4, C).
+ * chunks = dei2i_moments_chunks(H*W of the OUTPUT). */
+int dei2i_spade_bwd_partial(int dtype, int N, int H, int W, int C, int up, const void* dz, const void* z, const void* x,
+                            const float* mean, const float* rstd, const void* gb, int gb_mode, void* dgb,
+                            void* dxhat, float* partial, dei2i_stream s);
+/* pass 2 (finalize + apply).  coef: fp32 scratch (N,2,C).  dgb_cls: the class-mode fp32 (N,5,5,2C) buffer of pass 1
+ * (interior-class sums are added here) or NULL in dense mode.
+ * dx[n,hs,ws,c] = rstd * ( sum_cell dxhat - cnt*(s1/M) - xhat*cnt*(s2/M) ) (+ addend) at source resolution */
+int dei2i_spade_bwd_apply(int dtype, int N, int H, int W, int C, int up, const void* dxhat, const void* x,
+                          const float* mean, const float* rstd, const float* partial, int chunks, float* dgb_cls,
+                          float* coef, const void* addend, void* dx, dei2i_stream s);
+
+/* ---- generator heads + compose (generator.py:266-275) ----
+ * raw: (N,H,W,Cs>=4) = [fg_pre(3), prob_pre(1)]; x_in, out: NCHW fp32 (N,3,H,W); prob: NCHW fp32 (N,1,H,W)
+ *   out = x*(1-p) + tanh(fg_pre)*p,  p = sigmoid(prob_pre) */
+int dei2i_compose_fwd(int dtype, int N, int H, int W, int Cs, const void* raw, const float* x_in, float* out, float* prob,
+                      dei2i_stream s);
+int dei2i_compose_bwd(int dtype, int N, int H, int W, int Cs, const void* raw, const float* x_in, const float* d_out,
+                      const float* d_prob, void* d_raw, float* d_x, dei2i_stream s);
+/* NaN guard (generator.py:266-267): flag = any(isnan(x)); then, only if flag: nan->0, +-inf->+-max. No host sync. */
+int dei2i_nan_guard(int dtype, size_t n, void* x, int* flag, dei2i_stream s);
+
+/* ---- losses (models/base_model.py:68-80), fp32 tensors ---- */
+/* mean( max(x,0) - x*t + log1p(exp(-|x|)) ); target == NULL -> constant `tconst`.  out[0] = loss (overwritten). */
+int dei2i_bce_logits_fwd(size_t n, const float* x, const float* target, float tconst, float* out, dei2i_stream s);
+int dei2i_bce_logits_bwd(size_t n, const float* x, const float* target, float tconst, const float* gout, float* dx,
+                         dei2i_stream s);
+/* mean |a - b| ; b == NULL -> 0.  backward: da = sign(a-b)*gout/n, db = -da (either may be NULL) */
+int dei2i_l1_fwd(size_t n, const float* a, const float* b, float* out, dei2i_stream s);
+int dei2i_l1_bwd(size_t n, const float* a, const float* b, const float* gout, float* da, float* db, dei2i_stream s);
+
+/* ---- fused multi-tensor Adam (torch.optim.Adam semantics; trainers/base_trainer.py:75-89) ----
+ * table: device array of `count` records {p, g, m, v (fp32*), n (int64)}; one launch updates all. */
+typedef struct dei2i_adam_rec {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  int64_t n;
+} dei2i_adam_rec;
+int dei2i_adam_step(const dei2i_adam_rec* table_dev, int count, int64_t max_n, float lr, float beta1, float beta2,
+                    float eps, float bias_c1, float bias_c2_sqrt, float grad_scale, dei2i_stream s);
+
+/* ---- in-library kernel timing (bench.py roofline leg): HIP events around every launch of one kernel family ---- */
+#define DEI2I_PROF_GATHER_GEMM 0
+#define DEI2I_PROF_WGRAD 1
+int dei2i_prof_enable(int family, int on);
+/* synchronises the recorded events; returns launches, total ms and total algorithmic FLOPs since enable */
+int dei2i_prof_collect(int family, int64_t* launches, double* total_ms, double* total_flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEI2I_HIP_H */
