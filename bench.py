@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- paired 256x256 images/sec of the defectGAN G+D train step on N MI355X GPUs of one node.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A "step" = DefectGanTrainer.step(): one discriminator update + one generator update (num_critics = 1) on one
+synthetic batch that is already resident in HBM.  value = pairs/s over ALL ranks (weak scaling: 16 pairs per GPU).
+One JSON line is printed by rank 0.  Extra objects:
+  roofline     -- the dominant kernel family (implicit-GEMM gather conv: forward + dgrad), algorithmic FLOPs / HIP-event
+                  time of its launches inside the timed region, against the dense bf16 MFMA peak
+  cpu_baseline -- the CPU oracle restatement of the same step timed on this box's host cores (rank 0, N = 1 only)
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}      # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--image-size", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=16, help="pairs per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def make_opt(args, device):
+    """The reference's option attribute names with its defaults (options/defectgan_options.py:22-48,93-109)."""
+    import tempfile
+    from pathlib import Path
+    from types import SimpleNamespace
+    import torch
+    s = args.image_size
+    return SimpleNamespace(
+        model="defectgan", num_res=6, cycle_gan=False, label_nc=6, skip_conn=False, ngf=64, ndf=64, input_nc=3,
+        use_spectral=False, num_scales=3 if s >= 512 else 2, style_norm_block_type="spade", hidden_nc=128,
+        style_distill=False, embed_nc=768, add_noise=False, num_layers=5 if s >= 128 else 4, image_size=s,
+        batch_size=args.batch, device=torch.device(device), is_train=True, clf_loss_type="bce", continue_training=False,
+        load_model_name=None, init_type="normal", init_variance=0.02, phase="train", ckpt_dir=Path(tempfile.mkdtemp()),
+        name="bench", iters_per_epoch=1000, num_epochs=-1, num_iters=10 ** 6, lr=[2e-4], optimizer="adam", scheduler="step",
+        lr_decay=5e-3, loss_weight=[2, 5, 5, 5, 1], num_critics=1, diff_aug="", sean_alpha=None, use_running_stats=False,
+        save_latest_freq=10 ** 9, compute_dtype=args.dtype, defer_loss_sync=True)
+
+
+def synthetic_batch(n, size, seed, label_nc=6):
+    """bg, df ~ U(-1,1) fp32, multi-hot labels with labels[i, 1 + i % 5] = 1."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    bg = torch.rand(n, 3, size, size, generator=g) * 2 - 1
+    df = torch.rand(n, 3, size, size, generator=g) * 2 - 1
+    labels = torch.zeros(n, label_nc)
+    for i in range(n):
+        labels[i, 1 + i % (label_nc - 1)] = 1
+    return bg, labels, df
+
+
+def cpu_baseline():
+    """Oracle (CPU restatement, fp32, torch CPU ops) timed on this host: C1 = 64x64 batch 4 (3 timed steps) and one
+    256x256 batch-1 step; reported in pairs/s at 256x256.  Checker code used here only as the reported baseline."""
+    import torch
+    from oracle import defectgan_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    out = {}
+    for tag, size, n, layers, timed in (("c1_64px_b4", 64, 4, 4, 3), ("256px_b1", 256, 1, 5, 1)):
+        cfg = O.Cfg(image_size=size, num_layers=layers)
+        SG, SD = O.make_state(O.generator_state_shapes(cfg)), O.make_state(O.discriminator_state_shapes(cfg))
+        stG, stD = O.AdamState(), O.AdamState()
+        bg, lab, df = O.synthetic_batch(n, size)
+        if timed > 1:
+            O.step(SG, SD, stG, stD, bg, lab, df, cfg)          # warm-up
+        t0 = time.perf_counter()
+        for _ in range(timed):
+            O.step(SG, SD, stG, stD, bg, lab, df, cfg)
+        out[tag] = n * timed / (time.perf_counter() - t0)
+    return {"value": out["256px_b1"], "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": "oracle D+G step: 1 step at 256x256 batch 1 (value); 3 steps at 64x64 batch 4 = %.3f pairs/s" % out["c1_64px_b4"]}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    device = f"cuda:{local}"
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device(device))
+
+    from de_i2i_gan_amd import _lib
+    from de_i2i_gan_amd.parallel import attach_ddp
+    from de_i2i_gan_amd.trainers.defectgan_trainer import DefectGanTrainer
+
+    opt = make_opt(args, device)
+    torch.manual_seed(123)                           # reference default (utils/util.py:21); same weights on every rank
+    tr = DefectGanTrainer(opt)
+    if world > 1:
+        attach_ddp(tr)
+    bg, lab, df = synthetic_batch(args.batch, args.image_size, seed=7 + rank)
+    bg, lab, df = bg.to(device), lab.to(device), df.to(device)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.step(bg, lab, df)
+    lib = _lib.load()
+    sync()
+    if not args.no_roofline:
+        lib.dei2i_prof_enable(_lib.PROF_GATHER_GEMM, 1)
+        lib.dei2i_prof_enable(_lib.PROF_WGRAD, 1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.step(bg, lab, df)
+    sync()
+    elapsed = time.perf_counter() - t0
+    fam = {}
+    if not args.no_roofline:
+        for name, fid in (("gather_gemm", _lib.PROF_GATHER_GEMM), ("wgrad", _lib.PROF_WGRAD)):
+            n, ms, fl = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+            _lib.check(lib.dei2i_prof_collect(fid, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)), "prof_collect")
+            fam[name] = (n.value, ms.value, fl.value)
+            lib.dei2i_prof_enable(fid, 0)
+    tr.flush_losses()
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    pairs = args.batch * world * args.steps
+    ms_per_step = 1e3 * elapsed / args.steps
+    line = {
+        "metric": "paired 256x256 images/sec (G+D train step)", "value": pairs / elapsed, "unit": "pairs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"defectGAN D+G train step, {args.image_size}x{args.image_size} paired RGB, "
+                               f"batch {args.batch}/GPU, ngf=ndf=64 num_res=6 num_layers={opt.num_layers} SPADE, Adam(0.5,0.999)",
+                   "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                   "spade_path": "collapsed (5x5 border-class gamma/beta for 1x1 label maps)"},
+        "losses_last_step": {k: round(v[-1], 5) for kind in tr.losses.values() for k, v in kind.items() if v},
+    }
+    if fam:
+        n, ms, fl = fam["gather_gemm"]
+        wn, wms, wfl = fam["wgrad"]
+        peak = PEAK_TFLOPS[args.dtype]
+        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        line["roofline"] = {"bound": "mfma", "kernel": "gather_gemm_kernel (implicit-GEMM conv fwd + dgrad)",
+                            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                            "launches_per_step": n / args.steps, "avg_launch_ms": ms / max(n, 1),
+                            "flops_per_launch": fl / max(n, 1)}
+        conv_flops_step = (fl + wfl) / args.steps
+        line["mfma"] = {"executed_conv_tflop_per_step": conv_flops_step / 1e12,
+                        "step_mfma_util": conv_flops_step / (ms_per_step * 1e-3) / (peak * 1e12),
+                        "wgrad_tflops": wfl / (wms * 1e-3) / 1e12 if wms > 0 else 0.0,
+                        "conv_kernel_time_frac_of_step": (ms + wms) / args.steps / ms_per_step}
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,101 @@
+"""ctypes binding of libdei2i_hip.so (C ABI: include/dei2i_hip.h).  Fails loudly when the library is missing."""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdei2i_hip.so")
+
+BF16, F32 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+PAD_ZERO, PAD_REFLECT = 0, 1
+PROF_GATHER_GEMM, PROF_WGRAD = 0, 1
+
+
+class ConvDesc(Structure):
+    """struct dei2i_conv"""
+    _fields_ = [("dtype", c_int), ("N", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int), ("Cout", c_int),
+                ("CinS", c_int), ("CoutS", c_int), ("kh", c_int), ("kw", c_int), ("stride", c_int), ("pad", c_int),
+                ("pad_mode", c_int), ("up", c_int)]
+
+
+class AdamRec(Structure):
+    """struct dei2i_adam_rec"""
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_int64)]
+
+
+_P = c_void_p
+_CD = POINTER(ConvDesc)
+
+# name -> (restype, argtypes); every symbol include/dei2i_hip.h declares
+SIGNATURES = {
+    "dei2i_version": (c_int, []),
+    "dei2i_init": (c_int, [c_int]),
+    "dei2i_error_string": (c_char_p, [c_int]),
+    "dei2i_packed_fwd_elems": (c_size_t, [_CD]),
+    "dei2i_packed_dgrad_elems": (c_size_t, [_CD]),
+    "dei2i_pack_weight_fwd": (c_int, [_CD, _P, _P, _P]),
+    "dei2i_pack_weight_dgrad": (c_int, [_CD, _P, _P, _P]),
+    "dei2i_unpack_wgrad": (c_int, [_CD, _P, _P, c_float, _P]),
+    "dei2i_conv2d_out_shape": (None, [_CD, POINTER(c_int), POINTER(c_int)]),
+    "dei2i_conv2d_dgrad_shape": (None, [_CD, POINTER(c_int), POINTER(c_int)]),
+    "dei2i_conv2d_workspace_bytes": (c_size_t, [_CD]),
+    "dei2i_conv2d_fwd": (c_int, [_CD, _P, _P, _P, c_int, _P, _P, c_size_t, _P]),
+    "dei2i_conv2d_dgrad": (c_int, [_CD, _P, _P, _P, _P, c_size_t, _P]),
+    "dei2i_conv2d_wgrad": (c_int, [_CD, _P, _P, _P, _P]),
+    "dei2i_fold_pad": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "dei2i_nchw_to_nhwc": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "dei2i_nhwc_to_nchw": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "dei2i_nchw_to_nhwc_resize": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "dei2i_cast_from_f32": (c_int, [c_int, c_size_t, _P, _P, _P]),
+    "dei2i_moments_chunks": (c_int, [c_int]),
+    "dei2i_moments_partial": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "dei2i_bn_finalize_train": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P]),
+    "dei2i_bn_finalize_eval": (c_int, [c_int, _P, _P, _P, _P, c_float, _P, _P, _P]),
+    "dei2i_in_finalize": (c_int, [c_int, c_int, c_int, _P, c_float, _P, _P, _P]),
+    "dei2i_affine_act_fwd": (c_int, [c_int, c_size_t, c_int, _P, _P, _P, _P, c_int, _P, _P]),
+    "dei2i_spade_act_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P]),
+    "dei2i_act_bwd": (c_int, [c_int, c_size_t, _P, _P, c_int, _P, _P]),
+    "dei2i_colsum": (c_int, [c_int, c_size_t, c_int, _P, _P, _P]),
+    "dei2i_bn_bwd_chunks": (c_int, [c_size_t]),
+    "dei2i_bn_bwd_partial": (c_int, [c_int, c_size_t, c_int, _P, _P, _P, _P, _P, _P, c_int, _P, _P]),
+    "dei2i_bn_bwd_apply": (c_int, [c_int, c_size_t, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_int, _P, _P, _P, _P]),
+    "dei2i_spade_bwd_partial": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
+    "dei2i_spade_bwd_apply": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P]),
+    "dei2i_compose_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "dei2i_compose_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "dei2i_nan_guard": (c_int, [c_int, c_size_t, _P, _P, _P]),
+    "dei2i_bce_logits_fwd": (c_int, [c_size_t, _P, _P, c_float, _P, _P]),
+    "dei2i_bce_logits_bwd": (c_int, [c_size_t, _P, _P, c_float, _P, _P, _P]),
+    "dei2i_l1_fwd": (c_int, [c_size_t, _P, _P, _P, _P]),
+    "dei2i_l1_bwd": (c_int, [c_size_t, _P, _P, _P, _P, _P, _P]),
+    "dei2i_adam_step": (c_int, [_P, c_int, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, c_float, _P]),
+    "dei2i_prof_enable": (c_int, [c_int, c_int]),
+    "dei2i_prof_collect": (c_int, [c_int, POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle.  No fallback: a missing library is an error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"libdei2i_hip.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU / PyTorch fallback for the de-i2i-gan_amd ops.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here == header/library drift
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().dei2i_error_string(int(rc))
+        raise RuntimeError(f"dei2i {what} failed: code {rc} ({msg.decode() if msg else '?'})")

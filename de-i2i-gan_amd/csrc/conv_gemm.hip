@@ -476,7 +476,7 @@ static hipError_t launch_gg(const GatherDesc& g, const void* src, const void* wg
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  prof_begin(PROF_GATHER_GEMM, 2.0 * (double)g.M * (double)g.K * (double)wrows, st);
+  prof_begin(PROF_GATHER_GEMM, 2.0 * (double)g.M * (double)(g.th * g.tw) * (double)g.Clog * (double)wrows, st);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, (const T*)src, (const T*)wgt, wrows, bias, (T*)out,
                      zs > 1 ? ws : (float*)nullptr, ldc, act, tiles_n, kps);
   prof_end(PROF_GATHER_GEMM, st);
@@ -548,7 +548,7 @@ static hipError_t launch_wg(const GatherDesc& g, const void* src, const void* dy
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  prof_begin(PROF_WGRAD, 2.0 * (double)g.M * (double)g.K * (double)co_rows, st);
+  prof_begin(PROF_WGRAD, 2.0 * (double)g.M * (double)(g.th * g.tw) * (double)g.Clog * (double)co_rows, st);
   hipLaunchKernelGGL(kern, dim3(tiles, 1, zs), dim3(256), lds, st, g, (const T*)src, (const T*)dy, co_rows, ldy, dw,
                      tiles_k, cps);
   prof_end(PROF_WGRAD, st);

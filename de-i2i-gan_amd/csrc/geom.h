@@ -20,6 +20,7 @@ namespace dei2i {
 
 struct GatherDesc {
   int N, Hs, Ws, Cs;      // physical source tensor (NHWC), Cs = channel count padded to the vector width
+  int Clog;               // logical (unpadded) source channels -- FLOP accounting only
   int Hl, Wl, up;         // logical extent (Hs << up), upsample shift
   int Ho, Wo, M;          // output grid, M = N*Ho*Wo
   int sh, sw, by0, bx0;   // y = oy*sh + by0 + ty*ys
@@ -97,6 +98,7 @@ inline int conv_out_dim(int in_logical, int k, int stride, int pad) { return (in
 
 inline GatherDesc make_fwd_desc(const ConvShape& c, int Cs) {
   GatherDesc g{};
+  g.Clog = c.Cin;
   g.N = c.N; g.Hs = c.H; g.Ws = c.W; g.Cs = Cs; g.up = c.up;
   g.Ho = conv_out_dim(c.H << c.up, c.kh, c.stride, c.pad);
   g.Wo = conv_out_dim(c.W << c.up, c.kw, c.stride, c.pad);
@@ -135,7 +137,7 @@ inline GatherDesc make_dgrad_desc(const ConvShape& c, int CoutS, int ay, int ax)
     return r0 >= extent ? 0 : (extent - 1 - r0) / s + 1;
   };
   const int uy0 = first_u(ay), ux0 = first_u(ax);
-  g.N = c.N; g.Hs = Ho; g.Ws = Wo; g.Cs = CoutS; g.up = 0;
+  g.N = c.N; g.Hs = Ho; g.Ws = Wo; g.Cs = CoutS; g.up = 0; g.Clog = c.Cout;
   g.Ho = count_u(ay, OHt); g.Wo = count_u(ax, OWt);
   // source row ho = (hp - ky)/s = u - j with hp = s*u + a, ky = a + s*j ; u = oy + u0
   g.sh = g.sw = 1; g.by0 = uy0; g.bx0 = ux0;

@@ -1,0 +1,278 @@
+"""Building blocks with the reference's constructor signatures, module nesting and state_dict keys
+(models/networks/architecture.py, models/networks/normalization.py), executing on the HIP kernels.
+
+Blocks take and return NHWC activations of the compute dtype (see ``ops``); the NCHW fp32 boundary lives in the
+Generator / Discriminator.  Parameters stay fp32 in the reference's OIHW / per-channel shapes.
+"""
+import logging
+import math
+
+import torch
+from torch import nn
+
+from .. import ops
+
+
+def _pair_first(v):
+    return v[0] if isinstance(v, (tuple, list)) else v
+
+
+class Conv2d(nn.Module):
+    """Parameter container + launcher for one nn.Conv2d of the reference (weight OIHW fp32, optional bias).
+    The class name contains 'Conv' so BaseNetwork.init_weights dispatches on it like on nn.Conv2d."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, padding_mode="zeros", bias=True):
+        super().__init__()
+        k = _pair_first(kernel_size)
+        if isinstance(kernel_size, (tuple, list)) and kernel_size[0] != kernel_size[1]:
+            raise NotImplementedError("non-square kernels are not used by the reference hot path")
+        s = _pair_first(stride)
+        if padding == "same":
+            if k % 2 == 0:
+                raise ValueError("padding='same' needs an odd kernel")
+            pad = (k - 1) // 2
+        elif padding == "valid":
+            pad = 0
+        else:
+            pad = int(_pair_first(padding))
+        if padding_mode not in ("zeros", "reflect"):
+            raise NotImplementedError(f"padding_mode [{padding_mode}] is not implemented")
+        self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding = in_channels, out_channels, k, s, pad
+        self.padding_mode = padding_mode
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, k, k))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self._packed = ops.PackedWeights()
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            bound = 1 / math.sqrt(self.in_channels * self.kernel_size * self.kernel_size)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def geom(self, up=False):
+        return ops.ConvGeom(self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding,
+                            self.padding_mode == "reflect" and self.padding > 0, up)
+
+    def forward(self, x, act="none", up=False):
+        return ops.conv2d(x, self.weight, self.bias, self._packed, self.geom(up), act)
+
+    def extra_repr(self):
+        return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, "
+                f"padding={self.padding}, padding_mode={self.padding_mode}, bias={self.bias is not None}")
+
+
+class BatchNorm2d(nn.Module):
+    """nn.BatchNorm2d(eps=1e-5, momentum=0.1, affine, track_running_stats) parameter/buffer container."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def reset_parameters(self):
+        nn.init.ones_(self.weight)
+        nn.init.zeros_(self.bias)
+
+    def forward(self, y, act="none", res=None):
+        if self.training:
+            self.num_batches_tracked += 1
+        return ops.batchnorm_act(y, self.weight, self.bias, self.running_mean, self.running_var, self.training, act, res,
+                                 self.momentum, self.eps)
+
+    def extra_repr(self):
+        return f"{self.num_features}, eps={self.eps}, momentum={self.momentum}"
+
+
+class Act(nn.Module):
+    """Placeholder occupying the activation slot of the reference's nn.Sequential (keeps child indices and
+    printing aligned); the activation itself is fused into the producing kernel."""
+
+    def __init__(self, name):
+        super().__init__()
+        self.name = name
+
+    def extra_repr(self):
+        return str(self.name)
+
+
+def get_act_layer(act_str):
+    """architecture.py:12-26"""
+    if act_str in ("leaky_relu", "relu", "sigmoid", "tanh"):
+        return Act(act_str)
+    if act_str is None:
+        logging.info("create conv block without activation layer")
+        return Act(None)
+    raise NameError(f"activation layer named {act_str} not defined")
+
+
+def _is_batchnorm(norm_layer):
+    return norm_layer is BatchNorm2d or norm_layer is nn.BatchNorm2d
+
+
+def _reject(use_spectral=False, add_noise=False):
+    if use_spectral:
+        raise NotImplementedError("use_spectral is not implemented yet (SURVEY.md section 8f rank 2)")
+    if add_noise:
+        raise NotImplementedError("add_noise is not implemented yet (SURVEY.md section 8f rank 2)")
+
+
+class ConvBlock(nn.Module):
+    """conv -> [BatchNorm2d] -> [act]  (architecture.py:79-118)"""
+
+    def __init__(self, f_in, f_out, kernel_size=(3, 3), stride=(1, 1), padding=0, padding_mode="zeros", bias=False,
+                 norm_layer=None, act_layer=None, use_spectral=False):
+        super().__init__()
+        _reject(use_spectral)
+        blocks = [Conv2d(f_in, f_out, kernel_size, stride, padding, padding_mode, bias)]
+        self._has_norm = norm_layer is not None
+        if self._has_norm:
+            if not _is_batchnorm(norm_layer):
+                raise NotImplementedError("ConvBlock: only BatchNorm2d is used by the reference hot path")
+            blocks.append(BatchNorm2d(f_out))
+        if act_layer not in (None, "leaky_relu", "relu"):
+            raise NotImplementedError(f"ConvBlock activation [{act_layer}] is not fused")
+        self._act = act_layer or "none"
+        blocks.append(get_act_layer(act_layer))
+        self.conv_block = nn.Sequential(*blocks)
+
+    def forward(self, x, seg=None, res=None):
+        if self._has_norm:
+            y = self.conv_block[0](x)
+            return self.conv_block[1](y, self._act, res)
+        assert res is None
+        return self.conv_block[0](x, self._act)
+
+
+class DeConvBlock(nn.Module):
+    """[upsample] -> conv -> act (architecture.py:29-76).  In the reference hot path only the two generator heads
+    use it (up_scale=False, no norm, tanh / sigmoid); their convs are fused into one launch by the generator, so this
+    module is a parameter container with the reference's key layout."""
+
+    def __init__(self, f_in, f_out, kernel_size=(3, 3), stride=(1, 1), padding=0, padding_mode="zeros", bias=False,
+                 up_scale=True, norm_layer=None, act_layer=None, use_spectral=False, add_noise=False):
+        super().__init__()
+        _reject(use_spectral, add_noise)
+        if up_scale or norm_layer is not None:
+            raise NotImplementedError("DeConvBlock with up_scale / norm is not on the reference hot path")
+        self.de_conv_block = nn.Sequential(Conv2d(f_in, f_out, kernel_size, stride, padding, padding_mode, bias),
+                                           get_act_layer(act_layer))
+
+    @property
+    def conv(self):
+        return self.de_conv_block[0]
+
+
+class ResBlock(nn.Module):
+    """x + BN(conv(LReLU(BN(conv(x)))))  (architecture.py:121-176, down_scale=False)"""
+
+    def __init__(self, f_in, f_out, kernel_size=(3, 3), stride=(1, 1), padding=0, padding_mode="zeros", bias=False,
+                 norm_layer=BatchNorm2d, act_layer="relu", use_spectral=False, down_scale=False):
+        super().__init__()
+        if down_scale:
+            raise NotImplementedError("ResBlock(down_scale=True) is not on the reference hot path")
+        self.down_scale = False
+        self.res_block = nn.Sequential(
+            ConvBlock(f_in, f_in, kernel_size, stride, padding, padding_mode, bias, norm_layer, act_layer, use_spectral),
+            ConvBlock(f_in, f_out, kernel_size, stride, padding, padding_mode, bias, norm_layer, None, use_spectral))
+
+    def forward(self, x, seg=None):
+        h = self.res_block[0](x)
+        return self.res_block[1](h, res=x)           # identity add fused into the BatchNorm-apply kernel
+
+
+class SPADE(nn.Module):
+    """normalization.py:10-37.  ``forward`` returns relu(IN(x)*(1+gamma)+beta) -- every reference call site
+    applies ReLU right after (architecture.py:244,346-347), so it is fused; a preceding nearest x2 upsample of x
+    (architecture.py:203,241) is fused as well.
+
+    gamma/beta come from two zero-padded 3x3 convs on the nearest-resized label map.  When the label map is 1x1
+    (training, defectgan_model.py:385-392) gamma/beta take only 5x5 distinct values per (n,c) (position relative to
+    the 2-pixel border), so the convs run on a 5x5 'border class' image and the modulate kernel indexes the table."""
+
+    def __init__(self, label_nc, norm_nc, hidden_nc=128, kernel_size=(3, 3), padding="same", norm_layer=None):
+        super().__init__()
+        self.norm_nc, self.hidden_nc, self.label_nc = norm_nc, hidden_nc, label_nc
+        self.param_free_norm = Act("instance_norm(affine=False)")
+        self.mlp_shared = nn.Sequential(Conv2d(label_nc, hidden_nc, kernel_size, padding=padding), Act("relu"))
+        self.mlp_gamma = Conv2d(hidden_nc, norm_nc, kernel_size, padding=padding)
+        self.mlp_beta = Conv2d(hidden_nc, norm_nc, kernel_size, padding=padding)
+        self._packed_gb = ops.PackedWeights()
+
+    def forward(self, x, segmap, up=False):
+        prec = ops.precision_of(x)
+        n, hs, ws, c = x.shape
+        h, w = (2 * hs, 2 * ws) if up else (hs, ws)
+        class_mode = segmap.shape[2] == 1 and segmap.shape[3] == 1 and h >= 4 and w >= 4
+        seg = ops.to_nhwc(segmap, prec, size=(5, 5) if class_mode else (h, w))
+        actv = self.mlp_shared[0](seg, "relu")
+        w_gb = torch.cat([self.mlp_gamma.weight, self.mlp_beta.weight], 0)
+        b_gb = torch.cat([self.mlp_gamma.bias, self.mlp_beta.bias], 0)
+        geom = ops.ConvGeom(self.hidden_nc, 2 * self.norm_nc, self.mlp_gamma.kernel_size, 1, self.mlp_gamma.padding, False, False)
+        gb = ops.conv2d(actv, w_gb, b_gb, self._packed_gb, geom, "none", sources=(self.mlp_gamma.weight, self.mlp_beta.weight))
+        return ops.spade_relu(x, gb, up, 1 if class_mode else 0)
+
+
+def _style_norm(style_norm_block_type, label_nc, f, hidden_nc):
+    if style_norm_block_type != "spade":
+        raise NotImplementedError(f"style_norm_block_type [{style_norm_block_type}] is not implemented yet "
+                                  "(SURVEY.md section 8f rank 3: SEAN / AdaIN)")
+    return SPADE(label_nc, f, hidden_nc=hidden_nc)
+
+
+class NormConvBlock(nn.Module):
+    """up -> SPADE -> ReLU -> conv  (architecture.py:179-254, order at :241-245)"""
+
+    def __init__(self, style_norm_block_type, hidden_nc, label_nc, f_in, f_out, style_distill=False, embed_nc=None,
+                 kernel_size=(3, 3), stride=(1, 1), padding=0, padding_mode="zeros", bias=False, up_scale=False,
+                 norm_layer=None, act_layer="relu", use_spectral=False, add_noise=False):
+        super().__init__()
+        _reject(use_spectral, add_noise)
+        if act_layer != "relu":
+            raise NotImplementedError("NormConvBlock: the reference uses ReLU here")
+        self.up_scale = up_scale
+        self.up = Act("nearest x2" if up_scale else None)
+        self.noise = Act(None)
+        self.style_norm_block_type = style_norm_block_type
+        self.norm = _style_norm(style_norm_block_type, label_nc, f_in, hidden_nc)
+        self.conv = Conv2d(f_in, f_out, kernel_size, stride, padding, padding_mode, bias)
+        self.act = get_act_layer(act_layer)
+
+    def forward(self, x, labels, style_feat=None):
+        return self.conv(self.norm(x, labels, up=self.up_scale))
+
+
+class NormResBlock(nn.Module):
+    """x + conv_1(ReLU(SPADE_1(conv_0(ReLU(SPADE_0(x))))))  (architecture.py:260-371).  norm_s / conv_s exist as
+    parameters (state_dict compatibility) but are never executed when up_scale=False (:352-357)."""
+
+    def __init__(self, style_norm_block_type, hidden_nc, label_nc, f_in, f_out, style_distill=False, embed_nc=None,
+                 kernel_size=(3, 3), stride=(1, 1), padding=0, padding_mode="zeros", bias=False, up_scale=False,
+                 norm_layer=None, act_layer="relu", use_spectral=False, add_noise=False):
+        super().__init__()
+        _reject(use_spectral, add_noise)
+        if up_scale:
+            raise NotImplementedError("NormResBlock(up_scale=True) is not on the reference hot path")
+        if act_layer != "relu":
+            raise NotImplementedError("NormResBlock: the reference uses ReLU here")
+        self.up_scale = False
+        self.up = Act("nearest x2")
+        self.noise_0, self.noise_1 = Act(None), Act(None)
+        f_mid = min(f_in, f_out)
+        self.style_norm_block_type = style_norm_block_type
+        self.norm_0 = _style_norm(style_norm_block_type, label_nc, f_in, hidden_nc)
+        self.norm_1 = _style_norm(style_norm_block_type, label_nc, f_mid, hidden_nc)
+        self.norm_s = _style_norm(style_norm_block_type, label_nc, f_in, hidden_nc)
+        self.act = get_act_layer(act_layer)
+        self.conv_0 = Conv2d(f_in, f_mid, kernel_size, stride, padding, padding_mode, bias)
+        self.conv_1 = Conv2d(f_mid, f_out, kernel_size, stride, padding, padding_mode, bias)
+        self.conv_s = Conv2d(f_in, f_out, kernel_size, stride, padding, padding_mode, bias)
+
+    def forward(self, x, labels, style_feat=None):
+        h = self.conv_0(self.norm_0(x, labels))
+        h = self.conv_1(self.norm_1(h, labels))
+        return ops.add(h, x)

@@ -1,0 +1,89 @@
+"""DefectGanGenerator with the reference's constructor/forward signature and state_dict keys
+(models/networks/generator.py:52-275), running on the HIP kernels."""
+import math
+
+import torch
+from torch import nn
+
+from .. import ops
+from .architecture import BatchNorm2d, ConvBlock, DeConvBlock, NormConvBlock, NormResBlock, ResBlock
+from .base_network import BaseNetwork
+
+
+class DefectGanGenerator(BaseNetwork):
+    def __init__(self, opt):
+        super().__init__()
+        assert (opt.num_res & 1) == 0, "num_res must be even"
+        self.opt = opt
+        self.cycle_gan = opt.cycle_gan
+        self.label_nc = opt.label_nc
+        self.skip_conn = opt.skip_conn
+        if opt.skip_conn:
+            raise NotImplementedError("skip_conn: the reference's UnetBlock path does not run as written "
+                                      "(architecture.py:451,504-513)")
+        if opt.cycle_gan:
+            raise NotImplementedError("cycle_gan output mode is not implemented yet")
+        self.prec = ops.get_precision(getattr(opt, "compute_dtype", "bf16"))
+
+        crt_dim = opt.ngf
+        self.stem = ConvBlock(opt.input_nc, crt_dim, kernel_size=(7, 7), padding="same", padding_mode="reflect",
+                              norm_layer=BatchNorm2d, act_layer="leaky_relu", use_spectral=opt.use_spectral)
+        conv_blk, de_conv_blk, enc_res_blk, dec_res_blk = [], [], [], []
+        for _ in range(opt.num_scales):
+            conv_blk.append(ConvBlock(crt_dim, crt_dim * 2, kernel_size=(4, 4), stride=(2, 2), padding=1,
+                                      padding_mode="reflect", norm_layer=BatchNorm2d, act_layer="leaky_relu",
+                                      use_spectral=opt.use_spectral))
+            crt_dim *= 2
+        for _ in range(opt.num_res // 2):
+            enc_res_blk.append(ResBlock(crt_dim, crt_dim, kernel_size=(3, 3), stride=(1, 1), padding="same",
+                                        padding_mode="reflect", norm_layer=BatchNorm2d, act_layer="leaky_relu",
+                                        use_spectral=opt.use_spectral))
+        for _ in range(opt.num_res // 2, opt.num_res):
+            dec_res_blk.append(NormResBlock(opt.style_norm_block_type, opt.hidden_nc, opt.label_nc, crt_dim, crt_dim,
+                                            style_distill=opt.style_distill, embed_nc=opt.embed_nc, kernel_size=(3, 3),
+                                            stride=(1, 1), padding="same", padding_mode="reflect", up_scale=False,
+                                            act_layer="relu", use_spectral=opt.use_spectral, add_noise=opt.add_noise))
+        for _ in range(opt.num_scales):
+            de_conv_blk.append(NormConvBlock(opt.style_norm_block_type, opt.hidden_nc, opt.label_nc, crt_dim, crt_dim // 2,
+                                             style_distill=opt.style_distill, embed_nc=opt.embed_nc, kernel_size=(3, 3),
+                                             stride=(1, 1), padding="same", padding_mode="reflect", up_scale=True,
+                                             act_layer="relu", use_spectral=opt.use_spectral, add_noise=opt.add_noise))
+            crt_dim //= 2
+        self.enc_blk = nn.Sequential(*conv_blk)
+        self.enc_res_blk = nn.Sequential(*enc_res_blk)
+        self.dec_res_blk = nn.Sequential(*dec_res_blk)
+        self.dec_blk = nn.Sequential(*de_conv_blk)
+        self.foreground_head = DeConvBlock(crt_dim, 3, kernel_size=(3, 3), padding="same", padding_mode="reflect",
+                                           up_scale=False, norm_layer=None, act_layer="tanh")
+        self.distribution_head = DeConvBlock(crt_dim, 1, kernel_size=(3, 3), padding="same", padding_mode="reflect",
+                                             up_scale=False, norm_layer=None, act_layer="sigmoid")
+        self._head_dim = crt_dim
+        self._packed_heads = ops.PackedWeights()
+
+    def forward(self, x, labels, style_feat=None):
+        assert isinstance(x, torch.Tensor), "x must be Original Images: Torch.Tensor"
+        if labels.dim() == 2:
+            labels = labels.reshape(labels.size(0), labels.size(1), 1, 1)
+        feat = self.stem(ops.to_nhwc(x, self.prec))
+        for enc_blk in self.enc_blk:
+            feat = enc_blk(feat, labels)
+        for enc_res_blk in self.enc_res_blk:
+            feat = enc_res_blk(feat, labels)
+        for dec_res_blk in self.dec_res_blk:
+            feat = dec_res_blk(feat, labels, style_feat)
+        for dec_blk in self.dec_blk:
+            feat = dec_blk(feat, labels, style_feat)
+        # generator.py:266-267 -- nan_to_num only when a NaN is present; device-side flag, no host sync
+        with torch.no_grad():
+            ops.nan_guard_(feat)
+        # both heads as one 4-output conv (3 tanh channels + 1 sigmoid channel), then the compose kernel
+        fg_w, pr_w = self.foreground_head.conv.weight, self.distribution_head.conv.weight
+        w4 = torch.cat([fg_w, pr_w], 0)
+        geom = ops.ConvGeom(self._head_dim, 4, 3, 1, 1, True, False)
+        raw = ops.conv2d(feat, w4, None, self._packed_heads, geom, "none", sources=(fg_w, pr_w))
+        output, spatial_prob = ops.compose(raw, x)
+        return output, spatial_prob
+
+    def update_per_epoch(self, epoch):
+        super().update_per_epoch(epoch)
+        _ = (1 + math.cos(math.pi * epoch / self.opt.num_epochs)) / 2      # SEAN alpha schedule; SPADE has no use for it

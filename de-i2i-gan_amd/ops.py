@@ -1,0 +1,557 @@
+"""Autograd bindings of the HIP kernels (libdei2i_hip.so).  One ``torch.autograd.Function`` per fused op.
+
+Internal activations are NHWC tensors of the compute dtype (bf16, or f32 in parity mode) whose last dimension is the
+channel count padded to a 16-byte vector.  NCHW fp32 appears only at the module boundary (inputs, outputs,
+parameters, gradients, state_dict), as in the reference.  Every op requires a GPU tensor; there is no fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import byref, c_int, c_void_p
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+ACT = {"none": L.ACT_NONE, None: L.ACT_NONE, "relu": L.ACT_RELU, "leaky_relu": L.ACT_LRELU}
+
+
+@dataclass(frozen=True)
+class Precision:
+    name: str
+    code: int
+    dtype: torch.dtype
+    vec: int
+
+    def pad(self, c: int) -> int:
+        return (c + self.vec - 1) // self.vec * self.vec
+
+
+BF16 = Precision("bf16", L.BF16, torch.bfloat16, 8)
+F32 = Precision("f32", L.F32, torch.float32, 4)
+
+
+def get_precision(name) -> Precision:
+    if isinstance(name, Precision):
+        return name
+    if name in (None, "bf16", "bfloat16"):
+        return BF16
+    if name in ("f32", "fp32", "float32"):
+        return F32
+    raise ValueError(f"compute dtype [{name}] is not supported (bf16 | f32)")
+
+
+def precision_of(t: torch.Tensor) -> Precision:
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float32:
+        return F32
+    raise TypeError(f"unsupported activation dtype {t.dtype}")
+
+
+def _require_gpu(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"de-i2i-gan_amd.{what}: tensor is on {t.device}; the HIP kernels need a GPU tensor "
+                           "(there is no CPU fallback)")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_initialised = set()
+
+
+def _lib_for(t: torch.Tensor):
+    lib = L.load()
+    dev = t.device.index if t.device.index is not None else torch.cuda.current_device()
+    if dev not in _initialised:
+        L.check(lib.dei2i_init(dev), "init")
+        _initialised.add(dev)
+    return lib
+
+
+_workspaces = {}
+
+
+def _workspace(device, nbytes: int) -> torch.Tensor:
+    ws = _workspaces.get(device)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(max(nbytes // 4 + 1, 1 << 20), dtype=torch.float32, device=device)
+        _workspaces[device] = ws
+    return ws
+
+
+_const_vecs = {}
+
+
+def _const_vec(device, n: int, value: float) -> torch.Tensor:
+    key = (device, n, value)
+    v = _const_vecs.get(key)
+    if v is None:
+        v = torch.full((n,), value, dtype=torch.float32, device=device)
+        _const_vecs[key] = v
+    return v
+
+
+# --------------------------------------------------------------------------------------------------------------
+# convolution
+# --------------------------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class ConvGeom:
+    """nn.Conv2d geometry of one reference conv (architecture.py:51-56,95-100,228-233; normalization.py:17-22)."""
+    cin: int
+    cout: int
+    k: int
+    stride: int = 1
+    pad: int = 0
+    reflect: bool = False
+    up: bool = False      # nearest x2 upsample fused in front of the conv (architecture.py:203)
+
+
+def _desc(prec: Precision, g: ConvGeom, n: int, h: int, w: int, cins: int, couts: int) -> L.ConvDesc:
+    return L.ConvDesc(prec.code, n, h, w, g.cin, g.cout, cins, couts, g.k, g.k, g.stride, g.pad,
+                      L.PAD_REFLECT if g.reflect else L.PAD_ZERO, 1 if g.up else 0)
+
+
+class PackedWeights:
+    """Kernel-layout copies of one conv weight: forward [Cout][k*k][CinS] and dgrad (per stride-parity class
+    [Cin][taps][CoutS]).  Re-packed lazily when any source parameter changed (autograd version counter, or the
+    ``_dei2i_epoch`` stamp the fused Adam sets because it updates parameters through raw pointers)."""
+
+    def __init__(self):
+        self._key = None
+        self.fwd = None
+        self.dgrad = None
+
+    @staticmethod
+    def _stamp(t: torch.Tensor):
+        return (t.data_ptr(), t._version, getattr(t, "_dei2i_epoch", 0))
+
+    def get(self, weight: torch.Tensor, sources, prec: Precision, geom: ConvGeom, cins: int, couts: int, need_dgrad: bool):
+        key = (tuple(self._stamp(s) for s in sources), prec.code, cins, couts)
+        lib = _lib_for(weight)
+        if key != self._key:
+            self._key, self.fwd, self.dgrad = key, None, None
+        d = _desc(prec, geom, 1, max(geom.k, 4), max(geom.k, 4), cins, couts)
+        w = weight.detach()
+        if w.dtype != torch.float32 or not w.is_contiguous():
+            w = w.float().contiguous()
+        if self.fwd is None:
+            self.fwd = torch.empty(lib.dei2i_packed_fwd_elems(byref(d)), dtype=prec.dtype, device=weight.device)
+            L.check(lib.dei2i_pack_weight_fwd(byref(d), _p(w), _p(self.fwd), _stream()), "pack_weight_fwd")
+        if need_dgrad and self.dgrad is None:
+            self.dgrad = torch.empty(lib.dei2i_packed_dgrad_elems(byref(d)), dtype=prec.dtype, device=weight.device)
+            L.check(lib.dei2i_pack_weight_dgrad(byref(d), _p(w), _p(self.dgrad), _stream()), "pack_weight_dgrad")
+        return self.fwd, self.dgrad
+
+
+class _Conv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, cache: PackedWeights, sources, geom: ConvGeom, act: int):
+        _require_gpu(x, "conv2d")
+        prec = precision_of(x)
+        x = x.contiguous()
+        n, h, w, cins = x.shape
+        couts = prec.pad(geom.cout)
+        lib = _lib_for(x)
+        d = _desc(prec, geom, n, h, w, cins, couts)
+        wf, _ = cache.get(weight, sources, prec, geom, cins, couts, need_dgrad=False)
+        ho, wo = c_int(), c_int()
+        lib.dei2i_conv2d_out_shape(byref(d), byref(ho), byref(wo))
+        y = torch.empty((n, ho.value, wo.value, couts), dtype=prec.dtype, device=x.device)
+        ws_bytes = lib.dei2i_conv2d_workspace_bytes(byref(d))
+        ws = _workspace(x.device, ws_bytes)
+        b32 = None
+        if bias is not None:
+            b32 = bias.detach().float().contiguous()
+        L.check(lib.dei2i_conv2d_fwd(byref(d), _p(x), _p(wf), _p(b32), act, _p(y), _p(ws), ws.numel() * 4, _stream()),
+                "conv2d_fwd")
+        ctx.geom, ctx.act, ctx.cache, ctx.sources, ctx.prec = geom, act, cache, sources, prec
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight, y if act != L.ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        geom, prec, act = ctx.geom, ctx.prec, ctx.act
+        lib = _lib_for(x)
+        dy = dy.contiguous()
+        n, h, w, cins = x.shape
+        couts = dy.shape[-1]
+        d = _desc(prec, geom, n, h, w, cins, couts)
+        st = _stream()
+        if act != L.ACT_NONE:
+            g = torch.empty_like(dy)
+            L.check(lib.dei2i_act_bwd(prec.code, dy.numel(), _p(dy), _p(y), act, _p(g), st), "act_bwd")
+        else:
+            g = dy
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            _, wd = ctx.cache.get(weight, ctx.sources, prec, geom, cins, couts, need_dgrad=True)
+            oh, ow = c_int(), c_int()
+            lib.dei2i_conv2d_dgrad_shape(byref(d), byref(oh), byref(ow))
+            ext = torch.empty((n, oh.value, ow.value, cins), dtype=prec.dtype, device=x.device)
+            ws = _workspace(x.device, lib.dei2i_conv2d_workspace_bytes(byref(d)))
+            L.check(lib.dei2i_conv2d_dgrad(byref(d), _p(g), _p(wd), _p(ext), _p(ws), ws.numel() * 4, st), "conv2d_dgrad")
+            if (geom.reflect and geom.pad > 0) or geom.up:
+                dx = torch.empty_like(x)
+                L.check(lib.dei2i_fold_pad(prec.code, n, h, w, cins, geom.pad, d.pad_mode, d.up, _p(ext), None, _p(dx), st),
+                        "fold_pad")
+            else:
+                dx = ext
+        if ctx.needs_input_grad[1]:
+            dwp = torch.empty(lib.dei2i_packed_fwd_elems(byref(d)), dtype=torch.float32, device=x.device)
+            L.check(lib.dei2i_conv2d_wgrad(byref(d), _p(x), _p(g), _p(dwp), st), "conv2d_wgrad")
+            dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+            L.check(lib.dei2i_unpack_wgrad(byref(d), _p(dwp), _p(dw), 0.0, st), "unpack_wgrad")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            dbf = torch.empty(couts, dtype=torch.float32, device=x.device)
+            L.check(lib.dei2i_colsum(prec.code, g.numel() // couts, couts, _p(g), _p(dbf), st), "colsum")
+            db = dbf[:geom.cout].clone()
+        return dx, dw, db, None, None, None, None
+
+
+def conv2d(x, weight, bias, cache: PackedWeights, geom: ConvGeom, act="none", sources=None):
+    """y = act(conv(x) + bias) on an NHWC activation; ``weight`` is the reference's OIHW fp32 parameter."""
+    return _Conv2d.apply(x, weight, bias, cache, tuple(sources) if sources is not None else (weight,), geom, ACT[act])
+
+
+# --------------------------------------------------------------------------------------------------------------
+# layout at the module boundary
+# --------------------------------------------------------------------------------------------------------------
+class _ToNHWC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, prec: Precision, size):
+        _require_gpu(x, "to_nhwc")
+        x = x.detach().float().contiguous() if x.dtype != torch.float32 or not x.is_contiguous() else x
+        n, c, hs, ws = x.shape
+        h, w = (hs, ws) if size is None else size
+        cs = prec.pad(c)
+        out = torch.empty((n, h, w, cs), dtype=prec.dtype, device=x.device)
+        lib = _lib_for(x)
+        L.check(lib.dei2i_nchw_to_nhwc_resize(prec.code, n, c, hs, ws, h, w, cs, _p(x), _p(out), _stream()), "nchw_to_nhwc")
+        ctx.shape, ctx.prec, ctx.resized = (n, c, hs, ws), prec, (h, w) != (hs, ws)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.resized:
+            raise RuntimeError("to_nhwc with nearest resize is only differentiable w.r.t. nothing (label maps)")
+        n, c, h, w = ctx.shape
+        g = g.contiguous()
+        dx = torch.empty((n, c, h, w), dtype=torch.float32, device=g.device)
+        lib = _lib_for(g)
+        L.check(lib.dei2i_nhwc_to_nchw(ctx.prec.code, n, c, h, w, g.shape[-1], _p(g), _p(dx), _stream()), "nhwc_to_nchw")
+        return dx, None, None
+
+
+class _ToNCHW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, c: int):
+        _require_gpu(x, "to_nchw")
+        prec = precision_of(x)
+        x = x.contiguous()
+        n, h, w, cs = x.shape
+        out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+        lib = _lib_for(x)
+        L.check(lib.dei2i_nhwc_to_nchw(prec.code, n, c, h, w, cs, _p(x), _p(out), _stream()), "nhwc_to_nchw")
+        ctx.prec, ctx.cs = prec, cs
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().float()
+        n, c, h, w = g.shape
+        dx = torch.empty((n, h, w, ctx.cs), dtype=ctx.prec.dtype, device=g.device)
+        lib = _lib_for(g)
+        L.check(lib.dei2i_nchw_to_nhwc(ctx.prec.code, n, c, h, w, ctx.cs, _p(g), _p(dx), _stream()), "nchw_to_nhwc")
+        return dx, None
+
+
+def to_nhwc(x_nchw, prec: Precision, size=None):
+    """NCHW fp32 -> NHWC compute dtype (channels zero-padded); ``size`` fuses F.interpolate(mode='nearest')."""
+    return _ToNHWC.apply(x_nchw, prec, size)
+
+
+def to_nchw(x_nhwc, c: int):
+    return _ToNCHW.apply(x_nhwc, c)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# BatchNorm2d (+ LeakyReLU) (+ residual)
+# --------------------------------------------------------------------------------------------------------------
+class _BatchNormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, weight, bias, res, running_mean, running_var, training: bool, momentum: float, eps: float, act: int):
+        _require_gpu(y, "batchnorm_act")
+        prec = precision_of(y)
+        y = y.contiguous()
+        n, h, w, c = y.shape
+        lib = _lib_for(y)
+        st = _stream()
+        dev = y.device
+        a = torch.empty(c, dtype=torch.float32, device=dev)
+        b = torch.empty(c, dtype=torch.float32, device=dev)
+        w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        if training:
+            chunks = lib.dei2i_moments_chunks(h * w)
+            partial = torch.empty((n, chunks, 2, c), dtype=torch.float32, device=dev)
+            mean = torch.empty(c, dtype=torch.float32, device=dev)
+            rstd = torch.empty(c, dtype=torch.float32, device=dev)
+            L.check(lib.dei2i_moments_partial(prec.code, n, h * w, c, _p(y), _p(partial), st), "moments_partial")
+            L.check(lib.dei2i_bn_finalize_train(n, h * w, c, _p(partial), _p(w32), _p(b32), _p(running_mean), _p(running_var),
+                                                momentum, eps, _p(mean), _p(rstd), _p(a), _p(b), st), "bn_finalize_train")
+        else:
+            L.check(lib.dei2i_bn_finalize_eval(c, _p(w32), _p(b32), _p(running_mean), _p(running_var), eps, _p(a), _p(b), st),
+                    "bn_finalize_eval")
+            mean = running_mean.detach().clone()
+            rstd = torch.rsqrt(running_var.detach() + eps)
+        out = torch.empty_like(y)
+        if res is not None:
+            res = res.contiguous()
+        L.check(lib.dei2i_affine_act_fwd(prec.code, n * h * w, c, _p(y), _p(a), _p(b), _p(res), act, _p(out), st), "affine_act")
+        ctx.prec, ctx.act, ctx.training, ctx.has_res = prec, act, training, res is not None
+        ctx.save_for_backward(y, a, b, mean, rstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, a, b, mean, rstd = ctx.saved_tensors
+        prec = ctx.prec
+        lib = _lib_for(y)
+        st = _stream()
+        dout = dout.contiguous()
+        n, h, w, c = y.shape
+        pixels = n * h * w
+        chunks = lib.dei2i_bn_bwd_chunks(pixels)
+        partial = torch.empty((chunks, 2, c), dtype=torch.float32, device=y.device)
+        L.check(lib.dei2i_bn_bwd_partial(prec.code, pixels, c, _p(dout), _p(y), _p(a), _p(b), _p(mean), _p(rstd), ctx.act,
+                                         _p(partial), st), "bn_bwd_partial")
+        dweight = torch.empty(c, dtype=torch.float32, device=y.device)
+        dbias = torch.empty(c, dtype=torch.float32, device=y.device)
+        dy = torch.empty_like(y)
+        L.check(lib.dei2i_bn_bwd_apply(prec.code, pixels, c, _p(dout), _p(y), _p(a), _p(b), _p(mean), _p(rstd), ctx.act,
+                                       1 if ctx.training else 0, _p(partial), chunks, _p(dweight), _p(dbias), _p(dy), st),
+                "bn_bwd_apply")
+        return dy, dweight, dbias, (dout if ctx.has_res else None), None, None, None, None, None, None
+
+
+def batchnorm_act(y, weight, bias, running_mean, running_var, training, act="none", res=None, momentum=0.1, eps=1e-5):
+    return _BatchNormAct.apply(y, weight, bias, res, running_mean, running_var, bool(training), float(momentum), float(eps),
+                               ACT[act])
+
+
+def add(x, res):
+    """x + res on NHWC activations (NormResBlock identity branch, architecture.py:350)."""
+    c = x.shape[-1]
+    return _AffineAdd.apply(x, res, _const_vec(x.device, c, 1.0), _const_vec(x.device, c, 0.0))
+
+
+class _AffineAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, ones, zeros):
+        _require_gpu(x, "add")
+        prec = precision_of(x)
+        x, res = x.contiguous(), res.contiguous()
+        out = torch.empty_like(x)
+        lib = _lib_for(x)
+        L.check(lib.dei2i_affine_act_fwd(prec.code, x.numel() // x.shape[-1], x.shape[-1], _p(x), _p(ones), _p(zeros), _p(res),
+                                         L.ACT_NONE, _p(out), _stream()), "add")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g, None, None
+
+
+# --------------------------------------------------------------------------------------------------------------
+# SPADE (InstanceNorm * (1+gamma) + beta) + ReLU, optional fused nearest x2 upsample of x
+# --------------------------------------------------------------------------------------------------------------
+class _SpadeRelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gb, up: bool, gb_mode: int, eps: float):
+        _require_gpu(x, "spade_relu")
+        prec = precision_of(x)
+        x, gb = x.contiguous(), gb.contiguous()
+        n, hs, ws, c = x.shape
+        h, w = (hs * 2, ws * 2) if up else (hs, ws)
+        lib = _lib_for(x)
+        st = _stream()
+        dev = x.device
+        chunks = lib.dei2i_moments_chunks(hs * ws)
+        partial = torch.empty((n, chunks, 2, c), dtype=torch.float32, device=dev)
+        mean = torch.empty((n, c), dtype=torch.float32, device=dev)
+        rstd = torch.empty((n, c), dtype=torch.float32, device=dev)
+        # statistics of the upsampled tensor == statistics of the source tensor (every pixel replicated 4x)
+        L.check(lib.dei2i_moments_partial(prec.code, n, hs * ws, c, _p(x), _p(partial), st), "moments_partial")
+        L.check(lib.dei2i_in_finalize(n, hs * ws, c, _p(partial), eps, _p(mean), _p(rstd), st), "in_finalize")
+        out = torch.empty((n, h, w, c), dtype=prec.dtype, device=dev)
+        L.check(lib.dei2i_spade_act_fwd(prec.code, n, h, w, c, 1 if up else 0, _p(x), _p(mean), _p(rstd), _p(gb), gb_mode,
+                                        _p(out), st), "spade_act_fwd")
+        ctx.prec, ctx.up, ctx.gb_mode = prec, up, gb_mode
+        ctx.save_for_backward(x, gb, mean, rstd, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, gb, mean, rstd, out = ctx.saved_tensors
+        prec, up, gb_mode = ctx.prec, ctx.up, ctx.gb_mode
+        lib = _lib_for(x)
+        st = _stream()
+        dev = x.device
+        dout = dout.contiguous()
+        n, h, w, c = out.shape
+        chunks = lib.dei2i_moments_chunks(h * w)
+        partial = torch.empty((n, chunks, 4, c), dtype=torch.float32, device=dev)
+        dxhat = torch.empty_like(out)
+        if gb_mode == 0:
+            dgb = torch.empty_like(gb)
+        else:
+            dgb = torch.empty((n, 5, 5, 2 * c), dtype=torch.float32, device=dev)
+        L.check(lib.dei2i_spade_bwd_partial(prec.code, n, h, w, c, 1 if up else 0, _p(dout), _p(out), _p(x), _p(mean), _p(rstd),
+                                            _p(gb), gb_mode, _p(dgb), _p(dxhat), _p(partial), st), "spade_bwd_partial")
+        coef = torch.empty((n, 2, c), dtype=torch.float32, device=dev)
+        dx = torch.empty_like(x)
+        L.check(lib.dei2i_spade_bwd_apply(prec.code, n, h, w, c, 1 if up else 0, _p(dxhat), _p(x), _p(mean), _p(rstd), _p(partial),
+                                          chunks, _p(dgb) if gb_mode == 1 else None, _p(coef), None, _p(dx), st),
+                "spade_bwd_apply")
+        if gb_mode == 1 and prec.dtype != torch.float32:
+            dgb_t = torch.empty(dgb.shape, dtype=prec.dtype, device=dev)
+            L.check(lib.dei2i_cast_from_f32(prec.code, dgb.numel(), _p(dgb), _p(dgb_t), st), "cast")
+            dgb = dgb_t
+        return dx, dgb, None, None, None
+
+
+def spade_relu(x, gb, up: bool, gb_mode: int, eps: float = 1e-5):
+    return _SpadeRelu.apply(x, gb, bool(up), int(gb_mode), float(eps))
+
+
+# --------------------------------------------------------------------------------------------------------------
+# generator heads: tanh / sigmoid / compose  (generator.py:268-270), NaN guard (generator.py:266-267)
+# --------------------------------------------------------------------------------------------------------------
+class _Compose(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw, x_in):
+        _require_gpu(raw, "compose")
+        prec = precision_of(raw)
+        raw = raw.contiguous()
+        x32 = x_in.detach()
+        if x32.dtype != torch.float32 or not x32.is_contiguous():
+            x32 = x32.float().contiguous()
+        n, h, w, cs = raw.shape
+        out = torch.empty((n, 3, h, w), dtype=torch.float32, device=raw.device)
+        prob = torch.empty((n, 1, h, w), dtype=torch.float32, device=raw.device)
+        lib = _lib_for(raw)
+        L.check(lib.dei2i_compose_fwd(prec.code, n, h, w, cs, _p(raw), _p(x32), _p(out), _p(prob), _stream()), "compose_fwd")
+        ctx.prec = prec
+        ctx.save_for_backward(raw, x32)
+        return out, prob
+
+    @staticmethod
+    def backward(ctx, d_out, d_prob):
+        raw, x32 = ctx.saved_tensors
+        n, h, w, cs = raw.shape
+        lib = _lib_for(raw)
+        d_out = d_out.contiguous().float() if d_out is not None else None
+        d_prob = d_prob.contiguous().float() if d_prob is not None else None
+        d_raw = torch.empty_like(raw)
+        d_x = torch.empty_like(x32) if ctx.needs_input_grad[1] else None
+        if d_out is None and d_x is not None:
+            d_x.zero_()
+        L.check(lib.dei2i_compose_bwd(ctx.prec.code, n, h, w, cs, _p(raw), _p(x32), _p(d_out), _p(d_prob), _p(d_raw), _p(d_x),
+                                      _stream()), "compose_bwd")
+        return d_raw, d_x
+
+
+def compose(raw, x_in):
+    """(out, prob) = (x*(1-p) + tanh(raw[..., :3])*p, p = sigmoid(raw[..., 3])) as NCHW fp32."""
+    return _Compose.apply(raw, x_in)
+
+
+_nan_flags = {}
+
+
+def nan_guard_(x):
+    """In-place nan_to_num applied only if any NaN is present (reference semantics) -- no device->host sync."""
+    _require_gpu(x, "nan_guard")
+    prec = precision_of(x)
+    flag = _nan_flags.get(x.device)
+    if flag is None:
+        flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+        _nan_flags[x.device] = flag
+    lib = _lib_for(x)
+    L.check(lib.dei2i_nan_guard(prec.code, x.numel(), _p(x), _p(flag), _stream()), "nan_guard")
+    return x
+
+
+# --------------------------------------------------------------------------------------------------------------
+# losses (models/base_model.py:68-80)
+# --------------------------------------------------------------------------------------------------------------
+class _BceLogits(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, target, tconst: float):
+        _require_gpu(x, "bce_logits")
+        x = x.contiguous().float()
+        t = None if target is None else target.detach().contiguous().float().view(-1)
+        if t is not None and t.numel() != x.numel():
+            raise ValueError("bce_logits: target size mismatch")
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        lib = _lib_for(x)
+        L.check(lib.dei2i_bce_logits_fwd(x.numel(), _p(x), _p(t), tconst, _p(out), _stream()), "bce_fwd")
+        ctx.tconst = tconst
+        ctx.save_for_backward(x, t)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, t = ctx.saved_tensors
+        g = g.contiguous().float()
+        dx = torch.empty_like(x)
+        lib = _lib_for(x)
+        L.check(lib.dei2i_bce_logits_bwd(x.numel(), _p(x), _p(t), ctx.tconst, _p(g), _p(dx), _stream()), "bce_bwd")
+        return dx, None, None
+
+
+def bce_logits(x, target):
+    """binary_cross_entropy_with_logits(x, target), mean.  ``target`` is a tensor or a python float constant."""
+    if isinstance(target, (int, float)):
+        return _BceLogits.apply(x, None, float(target))
+    return _BceLogits.apply(x, target, 0.0)
+
+
+class _L1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        _require_gpu(a, "l1")
+        a = a.contiguous().float()
+        bb = None if b is None else b.contiguous().float()
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        lib = _lib_for(a)
+        L.check(lib.dei2i_l1_fwd(a.numel(), _p(a), _p(bb), _p(out), _stream()), "l1_fwd")
+        ctx.save_for_backward(a, bb)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, bb = ctx.saved_tensors
+        g = g.contiguous().float()
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(bb) if (bb is not None and ctx.needs_input_grad[1]) else None
+        if da is None and db is None:
+            return None, None
+        lib = _lib_for(a)
+        L.check(lib.dei2i_l1_bwd(a.numel(), _p(a), _p(bb), _p(g), _p(da), _p(db), _stream()), "l1_bwd")
+        return da, db
+
+
+def l1(a, b=None):
+    """l1_loss(a, b), mean; ``b=None`` means zeros (sd_con, defectgan_model.py:231-236)."""
+    return _L1.apply(a, b)

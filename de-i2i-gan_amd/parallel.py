@@ -1,0 +1,162 @@
+"""Data-parallel minibatch sharding: one process per GPU, gradient all-reduce over RCCL/xGMI overlapped with backward.
+
+The reference is single-device; this is the build's addition (section 8e).  Design for the
+MI355X node (8 GPUs, point-to-point xGMI, no switch):
+
+* Each rank runs the full D step and G step on its shard of the batch; the only exchange is SUM all-reduce of the
+  gradients that step produced.  The 1/world averaging is folded into the fused Adam kernel's ``grad_scale`` -- no
+  extra pass over the gradients.
+* Overlap: a ``post_accumulate_grad`` hook fires as soon as autograd has finished a parameter's gradient.  Large
+  gradients (>= ``direct_bytes``) are all-reduced in place immediately, small ones are coalesced into flat buckets of
+  ``bucket_bytes``.  Collectives are issued on a dedicated side stream that waits on an event recorded on the compute
+  stream, so RCCL traffic runs under the remaining backward kernels.  Backward reaches the discriminator's 134 MB
+  ``enc_blk.5`` weight gradient first, so the biggest message has the whole rest of backward to hide behind.
+* Every rank sees the same autograd graph, so hooks fire in the same order on every rank and the collective
+  sequence matches without negotiation.  Parameters that get no gradient in a step (the never-executed
+  ``norm_s`` / ``conv_s``; all of D during the G step) simply never enter a collective.
+* BatchNorm statistics stay local (per-shard), like torch DDP without SyncBN; ``broadcast_buffers`` copies rank 0's
+  running stats to every rank (torch DDP ``broadcast_buffers`` semantics) -- parity definition in SURVEY.md 8e.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    def __init__(self, process_group=None, bucket_bytes: int = 16 << 20, direct_bytes: int = 4 << 20, overlap: bool = True):
+        if not dist.is_initialized():
+            raise RuntimeError("GradReducer needs an initialised torch.distributed process group")
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group)
+        self.bucket_bytes, self.direct_bytes, self.overlap = bucket_bytes, direct_bytes, overlap
+        self._attached = set()
+        self._side: Dict[torch.device, torch.cuda.Stream] = {}
+        self._bucket: List[torch.Tensor] = []
+        self._bucket_nbytes = 0
+        self._inflight = []          # (work, flat, [grads]) to finish in reduce()
+        self.stats = {"collectives": 0, "bytes": 0}
+
+    # ---- wiring ------------------------------------------------------------------------------------------
+    def attach(self, net: torch.nn.Module) -> None:
+        """Register the gradient-ready hooks (once per network)."""
+        if id(net) in self._attached:
+            return
+        self._attached.add(id(net))
+        if not self.overlap:
+            return
+        for p in net.parameters():
+            p.register_post_accumulate_grad_hook(self._on_grad_ready)
+
+    def _comm_stream(self, device):
+        if device.type != "cuda":
+            return None
+        s = self._side.get(device)
+        if s is None:
+            s = torch.cuda.Stream(device=device)
+            self._side[device] = s
+        return s
+
+    # ---- hook path (during backward) ---------------------------------------------------------------------
+    def _on_grad_ready(self, p: torch.Tensor) -> None:
+        g = p.grad
+        if g is None or self.world == 1:
+            return
+        nbytes = g.numel() * g.element_size()
+        if nbytes >= self.direct_bytes:
+            self._launch([g], flat=None)
+        else:
+            self._bucket.append(g)
+            self._bucket_nbytes += nbytes
+            if self._bucket_nbytes >= self.bucket_bytes:
+                self._flush_bucket()
+
+    def _flush_bucket(self) -> None:
+        if self._bucket:
+            grads, self._bucket, self._bucket_nbytes = self._bucket, [], 0
+            self._launch(grads, flat=True)
+
+    def _launch(self, grads: List[torch.Tensor], flat) -> None:
+        dev = grads[0].device
+        side = self._comm_stream(dev)
+        if side is not None:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(dev))      # the gradient's producer kernels
+            side.wait_event(ready)
+            ctx = torch.cuda.stream(side)
+        else:
+            ctx = _NullCtx()
+        with ctx:
+            if flat:
+                buf = torch.cat([g.reshape(-1) for g in grads])
+                for g in grads:
+                    if side is not None:
+                        g.record_stream(side)
+            else:
+                buf = grads[0]
+                if side is not None:
+                    buf.record_stream(side)
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        self.stats["collectives"] += 1
+        self.stats["bytes"] += buf.numel() * buf.element_size()
+        self._inflight.append((work, buf if flat else None, grads))
+
+    # ---- after backward ----------------------------------------------------------------------------------
+    def reduce(self, net: torch.nn.Module) -> None:
+        """Finish the step's gradient exchange: after this returns (stream-ordered), every ``p.grad`` holds the SUM
+        over ranks.  Use ``FusedAdam.grad_scale = 1/world`` (set by ``attach_ddp``) for the average."""
+        if self.world == 1:
+            return
+        if id(net) not in self._attached or not self.overlap:
+            for p in net.parameters():                      # no-overlap path: same bucketing, issued now
+                if p.grad is not None:
+                    self._on_grad_ready(p)
+        self._flush_bucket()
+        for work, flat, grads in self._inflight:
+            dev = grads[0].device
+            side = self._comm_stream(dev)
+            ctx = torch.cuda.stream(side) if side is not None else _NullCtx()
+            with ctx:
+                work.wait()
+                if flat is not None:
+                    off = 0
+                    for g in grads:
+                        n = g.numel()
+                        g.copy_(flat[off:off + n].view_as(g))
+                        off += n
+        for dev, side in self._side.items():
+            torch.cuda.current_stream(dev).wait_stream(side)    # optimizer kernels run after the reduced grads land
+        self._inflight = []
+
+    def broadcast_buffers(self, net: torch.nn.Module, src: int = 0) -> None:
+        bufs = [b for b in net.buffers() if b.is_floating_point()]
+        if self.world == 1 or not bufs:
+            return
+        flat = torch.cat([b.reshape(-1) for b in bufs])
+        dist.broadcast(flat, src=src, group=self.pg)
+        off = 0
+        for b in bufs:
+            n = b.numel()
+            b.copy_(flat[off:off + n].view_as(b))
+            off += n
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def attach_ddp(trainer, process_group=None, **kw) -> GradReducer:
+    """Make a DefectGanTrainer data-parallel: gradients are summed across ranks after each backward and averaged
+    inside the fused Adam kernel; generator BatchNorm buffers follow rank 0."""
+    red = GradReducer(process_group, **kw)
+    for name, net in trainer.model.networks.items():
+        red.attach(net)
+        trainer.optimizers[name].grad_scale = 1.0 / red.world
+    trainer.reducer = red
+    return red

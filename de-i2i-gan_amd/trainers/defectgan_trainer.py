@@ -1,0 +1,91 @@
+"""DefectGanTrainer (trainers/defectgan_trainer.py:19-188): the two ``_train_*_once`` methods with the reference's
+signatures and side effects, plus ``step()`` = one D update then (every ``num_critics`` iterations) one G update.
+
+TensorBoard logging, image grids and FID/IS/LPIPS validation are host-side tooling outside the hot path
+ and are not part of this package."""
+from collections import defaultdict
+
+import torch
+
+from .base_trainer import BaseTrainer
+
+
+class DefectGanTrainer(BaseTrainer):
+    def __init__(self, opt):
+        super().__init__(opt)
+        assert len(opt.loss_weight) == 5, f"length of loss weights must be 5, not {len(opt.loss_weight)}"
+        self.loss_weights = {"clf_d": opt.loss_weight[0], "clf_g": opt.loss_weight[1], "rec": opt.loss_weight[2],
+                             "sd_cyc": opt.loss_weight[3], "sd_con": opt.loss_weight[4]}
+        self.loss_types = ["gan", "clf", "aux"]
+        self._init_losses()
+        if opt.phase == "val":
+            raise NotImplementedError("phase='val' builds FID/LPIPS metric networks (downloaded weights): out of scope")
+        # defer_loss_sync: keep the per-step losses on the device and convert them in one batch in flush_losses()
+        # instead of the reference's .item() per loss (7 host syncs per step, defectgan_trainer.py:164-168,179-180)
+        self.defer_loss_sync = bool(getattr(opt, "defer_loss_sync", False))
+        self._pending = []
+        self.reducer = None          # set by parallel.attach_ddp(): gradient all-reduce across ranks
+
+    def _init_lr(self, opt):
+        assert len(opt.lr) in (1, 2), f"length of lr must be 1 or 2, not {len(opt.lr)}"
+        self.lr = {"D": opt.lr[0], "G": opt.lr[1]} if len(opt.lr) == 2 else opt.lr[0]
+
+    def _init_losses(self):
+        self.losses = {loss_type: defaultdict(list) for loss_type in self.loss_types}
+
+    # ---- loss bookkeeping -------------------------------------------------------------------------------------
+    def _record(self, keys, tensors):
+        stacked = torch.stack([t.detach() for t in tensors])
+        if self.defer_loss_sync:
+            self._pending.append((keys, stacked))
+        else:
+            for (kind, name), v in zip(keys, stacked.tolist()):        # ONE device->host read for the group
+                self.losses[kind][name].append(v)
+
+    def flush_losses(self):
+        if self._pending:
+            flat = torch.cat([s for _, s in self._pending]).tolist()
+            i = 0
+            for keys, s in self._pending:
+                for kind, name in keys:
+                    self.losses[kind][name].append(flat[i])
+                    i += 1
+            self._pending = []
+
+    # ---- the step ---------------------------------------------------------------------------------------------
+    def _train_generator_once(self, bg_data, df_labels, df_data):
+        """defectgan_trainer.py:138-168"""
+        self.optimizers["G"].zero_grad()
+        gan_loss, clf_loss, rec_loss, sd_cyc_loss, sd_con_loss = self.model("generator", bg_data, df_labels, df_data)
+        g_loss = gan_loss + clf_loss * self.loss_weights["clf_g"] + rec_loss * self.loss_weights["rec"] + \
+            sd_cyc_loss * self.loss_weights["sd_cyc"] + sd_con_loss * self.loss_weights["sd_con"]
+        g_loss.backward()
+        if self.reducer is not None:
+            self.reducer.reduce(self.model.netG)
+        self.optimizers["G"].step()
+        if self.reducer is not None:
+            self.reducer.broadcast_buffers(self.model.netG)      # BatchNorm running stats follow rank 0
+        self._record([("gan", "G"), ("clf", "G"), ("aux", "rec"), ("aux", "cyc"), ("aux", "con")],
+                     [gan_loss, clf_loss, rec_loss, sd_cyc_loss, sd_con_loss])
+
+    def _train_discriminator_once(self, bg_data, df_labels, df_data):
+        """defectgan_trainer.py:170-180"""
+        self.optimizers["D"].zero_grad()
+        gan_loss, clf_loss = self.model("discriminator", bg_data, df_labels, df_data)
+        d_loss = gan_loss + clf_loss * self.loss_weights["clf_d"]
+        d_loss.backward()
+        if self.reducer is not None:
+            self.reducer.reduce(self.model.netD)
+        self.optimizers["D"].step()
+        self._record([("gan", "D"), ("clf", "D")], [gan_loss, clf_loss])
+
+    def step(self, bg_data, df_labels, df_data):
+        """One iteration of the reference's hot loop (defectgan_trainer.py:96-109)."""
+        self.iters += 1
+        self._train_discriminator_once(bg_data, df_labels, df_data)
+        if self.iters % self.opt.num_critics == 0:
+            self._train_generator_once(bg_data, df_labels, df_data)
+
+    def _update_per_epoch(self, epoch=None):
+        super()._update_per_epoch(epoch)
+        self.model.update_per_epoch(epoch)
