@@ -82,6 +82,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64.so.7; whichever copy is mapped first serves the whole process.  Import torch
+    # first so this library shares torch's HIP runtime (streams, device pointers) instead of /opt/rocm's copy.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"libdei2i_hip.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

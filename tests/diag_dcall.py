@@ -1,0 +1,62 @@
+"""Diagnostic: after a real D Adam step, gradient of individual D-loss terms w.r.t. the D input, HIP f32 vs oracle fp64."""
+import sys
+from pathlib import Path
+import torch
+sys.path.insert(0, str(Path(__file__).resolve().parents[1])); sys.path.insert(0, str(Path(__file__).resolve().parent))
+from helpers import formula_fill, make_opt
+from oracle import defectgan_oracle as O
+from de_i2i_gan_amd import ops
+DEV = "cuda:0"
+c = dict(image_size=32, batch=2, num_layers=3, ngf=8, ndf=8, hidden_nc=16)
+cfg = O.Cfg(image_size=32, ngf=8, ndf=8, num_layers=3, hidden_nc=16)
+bg, labels, df = O.synthetic_batch(2, 32)
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+from de_i2i_gan_amd.trainers.defectgan_trainer import DefectGanTrainer
+SG = {k: (v.double() if v.is_floating_point() else v) for k, v in O.make_state(O.generator_state_shapes(cfg)).items()}
+SD = {k: v.double() for k, v in O.make_state(O.discriminator_state_shapes(cfg)).items()}
+d_gan, d_clf, gD = O.train_discriminator_once(SG, SD, None, bg.double(), labels.double(), df.double(), cfg)
+O.adam_update(SD, gD, O.AdamState(), cfg)
+SD = {k: v.detach() for k, v in SD.items()}
+tr = DefectGanTrainer(make_opt(c, DEV, "f32"))
+G, D = tr.model.netG, tr.model.netD
+formula_fill(G); formula_fill(D)
+tr.optimizers["D"].zero_grad()
+g1, c1 = tr.model("discriminator", bg, labels, df)
+(g1 + 2 * c1).backward()
+tr.optimizers["D"].step()
+with torch.no_grad():
+    G.train()
+    xa = G(bg.to(DEV), labels.to(DEV))[0].cpu()
+    nm = torch.zeros_like(labels); nm[:, 0] = 1
+    xb = G(df.to(DEV), nm.to(DEV))[0].cpu()
+lab = labels
+for trial in range(1):
+    for nograd_w in (False, True):
+        if nograd_w:
+            for p in D.parameters(): p.requires_grad_(False)
+        xs = [xa, xb]
+        refs, mines = [], []
+        gx = [x.to(DEV).requires_grad_(True) for x in xs]
+        outs = [D(g) for g in gx]
+        for i, x in enumerate(xs):
+            xr = x.double().requires_grad_(True)
+            src, cls = O.discriminator_forward(SD, xr, cfg)
+            for term, (lo, lm) in enumerate(((O.bce_logits(src, torch.ones_like(src)), lambda o: ops.bce_logits(o[0], 1.0)),
+                                            (O.bce_logits(cls, lab.double()), lambda o: ops.bce_logits(o[1], lab.to(DEV))))):
+                (gr,) = torch.autograd.grad(lo, xr, retain_graph=True)
+                (gm,) = torch.autograd.grad(lm(outs[i]), gx[i], retain_graph=True)
+                print(f"trial {trial} w_nograd {nograd_w} call {i} term {'gan' if term == 0 else 'clf'}: fwd err {rel(outs[i][term], (src, cls)[term]):.1e} grad err {rel(gm, gr):.2e}")
+        for i, x in enumerate(xs):
+            for lname, lb in (("df", lab), ("nm", nm)):
+                xr = x.double().requires_grad_(True)
+                src, cls = O.discriminator_forward(SD, xr, cfg)
+                lo = 0.5 * O.bce_logits(src, torch.ones_like(src)) + 2.5 * O.bce_logits(cls, lb.double())
+                (gr,) = torch.autograd.grad(lo, xr)
+                xg_ = x.to(DEV).requires_grad_(True)
+                s_, c_ = D(xg_)
+                lm_ = 0.5 * ops.bce_logits(s_, 1.0) + 2.5 * ops.bce_logits(c_, lb.to(DEV))
+                (gm,) = torch.autograd.grad(lm_, xg_)
+                print(f"trial combined w_nograd {nograd_w} call {i} labels {lname}: grad err {rel(gm, gr):.2e}")
+        for p in D.parameters(): p.requires_grad_(True)

@@ -1,0 +1,100 @@
+"""Diagnostic: G-step intermediate gradients (w.r.t. each G call's outputs) HIP f32 vs oracle fp64 after a D update."""
+import sys
+from pathlib import Path
+import torch
+sys.path.insert(0, str(Path(__file__).resolve().parents[1])); sys.path.insert(0, str(Path(__file__).resolve().parent))
+from helpers import formula_fill, make_opt
+from oracle import defectgan_oracle as O
+DEV = "cuda:0"
+c = dict(image_size=32, batch=2, num_layers=3, ngf=8, ndf=8, hidden_nc=16)
+cfg = O.Cfg(image_size=32, ngf=8, ndf=8, num_layers=3, hidden_nc=16)
+bg, labels, df = O.synthetic_batch(2, 32)
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+from de_i2i_gan_amd.trainers.defectgan_trainer import DefectGanTrainer
+SG = {k: (v.double() if v.is_floating_point() else v) for k, v in O.make_state(O.generator_state_shapes(cfg)).items()}
+SD = {k: v.double() for k, v in O.make_state(O.discriminator_state_shapes(cfg)).items()}
+d_gan, d_clf, gD = O.train_discriminator_once(SG, SD, None, bg.double(), labels.double(), df.double(), cfg)
+O.adam_update(SD, gD, O.AdamState(), cfg)
+SD = {k: v.detach() for k, v in SD.items()}
+for k in O.param_keys(SG):
+    SG[k].requires_grad_(True)
+nm_l, df_l = O._labels(labels.double())
+inter = {}
+def keep(name, t):
+    t.retain_grad(); inter[name] = t; return t
+bgd, dfd = bg.double(), df.double()
+fd, dfp = O.generator_forward(SG, bgd, df_l, cfg, True); keep("fake_defects", fd); keep("df_prob", dfp)
+rn, rdfp = O.generator_forward(SG, fd, nm_l, cfg, True); keep("recover_normals", rn); keep("rec_df_prob", rdfp)
+fn, nmp = O.generator_forward(SG, dfd, nm_l, cfg, True); keep("fake_normals", fn); keep("nm_prob", nmp)
+rd, rnmp = O.generator_forward(SG, fn, df_l, cfg, True); keep("recover_defects", rd); keep("rec_nm_prob", rnmp)
+fd_src, fd_cls = O.discriminator_forward(SD, fd, cfg); fn_src, fn_cls = O.discriminator_forward(SD, fn, cfg)
+ones = torch.ones_like(fd_src)
+gan = torch.stack([O.bce_logits(fd_src, ones), O.bce_logits(fn_src, ones)]).mean()
+clf = torch.stack([O.bce_logits(fd_cls, df_l.view_as(fd_cls)), O.bce_logits(fn_cls, nm_l.view_as(fn_cls))]).mean()
+rec = torch.stack([O.l1(rd, dfd), O.l1(rn, bgd)]).mean()
+cyc = torch.stack([O.l1(dfp, rdfp), O.l1(nmp, rnmp)]).mean()
+z = torch.zeros_like(dfp)
+con = torch.stack([O.l1(dfp, z), O.l1(nmp, z), O.l1(rdfp, z), O.l1(rnmp, z)]).mean()
+ref_parts = {}
+for nm_, l_ in (("D", gan + 5 * clf), ("rec", 5 * rec), ("cyc", 5 * cyc), ("con", con)):
+    ref_parts[nm_] = torch.autograd.grad(l_, [fd, fn], retain_graph=True, allow_unused=True)
+(gan + 5 * clf + 5 * rec + 5 * cyc + con).backward()
+
+tr = DefectGanTrainer(make_opt(c, DEV, "f32"))
+G, D = tr.model.netG, tr.model.netD
+formula_fill(G); formula_fill(D)
+tr.optimizers["D"].zero_grad()
+g1, c1 = tr.model("discriminator", bg, labels, df)
+(g1 + 2 * c1).backward()
+tr.optimizers["D"].step()
+mine = {}
+MINE_T = {}
+names = iter(["fake_defects", "df_prob", "recover_normals", "rec_df_prob", "fake_normals", "nm_prob", "recover_defects", "rec_nm_prob"])
+orig_forward = G.forward
+def wrapped(x, labels_, style_feat=None):
+    out, prob = orig_forward(x, labels_, style_feat)
+    for t in (out, prob):
+        nm = next(names)
+        mine[nm + "_val"] = t.detach().clone()
+        MINE_T[nm] = t
+        t.register_hook(lambda g, nm=nm: mine.__setitem__(nm, g.detach().clone()) if g is not None else None)
+    return out, prob
+G.forward = wrapped
+tr.optimizers["G"].zero_grad()
+ls = tr.model("generator", bg, labels, df)
+keyed = {}
+def grab(nm):
+    # the tensors the hooks saw are the G outputs; find them through the hook registry by re-wrapping
+    return None
+mine_t = MINE_T
+for nm_, l_ in (("D", ls[0] + 5 * ls[1]), ("rec", 5 * ls[2]), ("cyc", 5 * ls[3]), ("con", ls[4])):
+    g_ = torch.autograd.grad(l_, [mine_t["fake_defects"], mine_t["fake_normals"]], retain_graph=True, allow_unused=True)
+    for i, who in enumerate(("fake_defects", "fake_normals")):
+        r_ = ref_parts[nm_][i]
+        if g_[i] is None or r_ is None:
+            print(f"part {nm_:4s} {who:14s} mine None={g_[i] is None} ref None={r_ is None}")
+        else:
+            print(f"part {nm_:4s} {who:14s} err {rel(g_[i], r_):.2e} |ref| {r_.norm().item():.3e}")
+# same D path evaluated OUTSIDE the G graph (mine vs mine)
+from de_i2i_gan_amd import ops as _ops
+G.forward = orig_forward
+for who, lab_ in (("fake_defects", labels), ("fake_normals", torch.tensor([[1., 0, 0, 0, 0, 0]] * 2))):
+    xin = mine[who + "_val"].clone().requires_grad_(True)
+    s_, c_ = D(xin)
+    l_ = 0.5 * _ops.bce_logits(s_, 1.0) + 2.5 * _ops.bce_logits(c_, lab_.to(DEV))
+    (g_out,) = torch.autograd.grad(l_, xin)
+    g_in = torch.autograd.grad(ls[0] + 5 * ls[1], mine_t[who], retain_graph=True)[0]
+    r_ = ref_parts["D"][0 if who == "fake_defects" else 1]
+    xr_ = mine[who + "_val"].double().cpu().requires_grad_(True)
+    so_, co_ = O.discriminator_forward(SD, xr_, cfg)
+    lo_ = 0.5 * O.bce_logits(so_, torch.ones_like(so_)) + 2.5 * O.bce_logits(co_, lab_.double())
+    (r2_,) = torch.autograd.grad(lo_, xr_)
+    print(f"{who}: oracle out-of-graph vs oracle in-graph {rel(r2_, r_):.2e}; mine vs oracle out-of-graph {rel(g_out, r2_):.2e}")
+    print(f"{who}: in-graph vs out-of-graph (mine/mine) {rel(g_in, g_out):.2e}; out-of-graph vs oracle {rel(g_out, r_):.2e}; in-graph vs oracle {rel(g_in, r_):.2e}")
+import sys as _s; _s.exit(0)
+for nm, t in inter.items():
+    print(f"{nm:18s} value err {rel(mine[nm + '_val'], t):.2e}   grad err {rel(mine[nm], t.grad):.2e}  |grad| {t.grad.norm().item():.3e}")

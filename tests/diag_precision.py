@@ -1,0 +1,99 @@
+"""Diagnostic (not a test): error statistics of the HIP path vs the oracle in fp64, per dtype, forward and backward."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+from helpers import formula_fill, make_opt  # noqa: E402
+from oracle import defectgan_oracle as O  # noqa: E402
+
+DEV = "cuda:0"
+UPDATE_D = False
+MODE = ""
+RESET_CACHES = False
+
+
+def stats(a, b):
+    a, b = a.detach().double().cpu().flatten(), torch.as_tensor(b).double().flatten()
+    d = (a - b).abs()
+    return dict(rms=float(d.pow(2).mean().sqrt() / b.pow(2).mean().sqrt()), max=float(d.max() / b.abs().max()),
+                p999=float(d.kthvalue(max(1, int(0.999 * d.numel()))).values / b.abs().max()),
+                cos=float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)))
+
+
+def run(c, pname, which="gstep"):
+    from de_i2i_gan_amd.trainers.defectgan_trainer import DefectGanTrainer
+    cfg = O.Cfg(image_size=c["image_size"], ngf=c["ngf"], ndf=c["ndf"], num_layers=c["num_layers"], hidden_nc=c["hidden_nc"])
+    bg, labels, df = O.synthetic_batch(c["batch"], c["image_size"])
+    # fp64 oracle
+    SG = {k: (v.double() if v.is_floating_point() else v) for k, v in O.make_state(O.generator_state_shapes(cfg)).items()}
+    SD = {k: v.double() for k, v in O.make_state(O.discriminator_state_shapes(cfg)).items()}
+    seg = labels.double().reshape(c["batch"], 6, 1, 1)
+    with torch.no_grad():
+        out_ref, prob_ref = O.generator_forward({k: v.clone() for k, v in SG.items()}, bg.double(), seg, cfg, training=False)
+    d_gan, d_clf, gD = O.train_discriminator_once(SG, SD, None, bg.double(), labels.double(), df.double(), cfg)
+    if UPDATE_D:
+        O.adam_update(SD, gD, O.AdamState(), cfg)
+        SD = {k: v.detach() for k, v in SD.items()}
+    losses_ref, gG = O.train_generator_once({k: v.clone() for k, v in SG.items()}, SD, None, bg.double(), labels.double(), df.double(), cfg)
+
+    tr = DefectGanTrainer(make_opt(c, DEV, pname))
+    G, D = tr.model.netG, tr.model.netD
+    formula_fill(G)
+    formula_fill(D)
+    with torch.no_grad():
+        G.eval()
+        out, prob = G(bg.to(DEV), labels.to(DEV))
+    print(f"[{pname}] forward out:", {k: f"{v:.2e}" for k, v in stats(out, out_ref).items()})
+    tr.optimizers["D"].zero_grad()
+    gan, clf = tr.model("discriminator", bg, labels, df)
+    (gan + 2 * clf).backward()
+    print(f"[{pname}] D losses", float(gan), float(d_gan), float(clf), float(d_clf))
+    for k, p in D.named_parameters():
+        print(f"   D {k:45s}", {kk: f"{v:.2e}" for kk, v in stats(p.grad, gD[k]).items()})
+    if MODE == "lr0":
+        for gph in tr.optimizers["D"].param_groups:
+            gph["lr"] = 0.0
+        tr.optimizers["D"].step()
+    if MODE == "poison":
+        junk = [torch.full((1 << 22,), float("nan"), device=DEV) for _ in range(64)]
+        small = [torch.full((n,), float("nan"), device=DEV) for n in (64, 256, 1024, 4096, 16384, 65536, 262144) for _ in range(32)]
+        del junk, small
+    if UPDATE_D:
+        tr.optimizers["D"].step()
+        for k, p in D.named_parameters():
+            print(f"   Dpost {k:45s}", {kk: f"{v:.2e}" for kk, v in stats(p, SD[k]).items()})
+    if RESET_CACHES:
+        from de_i2i_gan_amd import ops as _ops
+        for m in list(D.modules()) + list(G.modules()):
+            for a in ("_packed", "_packed_gb", "_packed_heads"):
+                if hasattr(m, a):
+                    setattr(m, a, _ops.PackedWeights())
+    tr.optimizers["G"].zero_grad()
+    ls = tr.model("generator", bg, labels, df)
+    (ls[0] + 5 * ls[1] + 5 * ls[2] + 5 * ls[3] + ls[4]).backward()
+    print(f"[{pname}] G losses", [f"{float(a):.8f}/{float(b):.8f}" for a, b in zip(ls, losses_ref)])
+    rows = []
+    for k, p in G.named_parameters():
+        if p.grad is None:
+            continue
+        s = stats(p.grad, gG[k])
+        rows.append((s["rms"], k, s))
+    rows.sort(reverse=True)
+    for r in rows[:12]:
+        print(f"   G {r[1]:50s}", {kk: f"{v:.2e}" for kk, v in r[2].items()})
+    print("   G median rms", np.median([r[0] for r in rows]))
+
+
+if __name__ == "__main__":
+    cfgs = {"tiny": dict(image_size=16, batch=1, num_layers=1, ngf=8, ndf=8, hidden_nc=8),
+            "t0": dict(image_size=32, batch=2, num_layers=3, ngf=8, ndf=8, hidden_nc=16),
+            "t1": dict(image_size=64, batch=4, num_layers=4, ngf=16, ndf=16, hidden_nc=32)}
+    for name in sys.argv[1:] or ["tiny", "t0"]:
+        for mode in ("", "lr0", "poison"):
+            MODE = mode
+            print("=====", name, "f32 mode", mode)
+            run(cfgs[name], "f32")
