@@ -191,30 +191,28 @@ int dei2i_conv2d_dgrad(const dei2i_conv* c, const void* dy, const void* wd_packe
                        dei2i_stream s) {
   if (!valid_conv(c) || !dy || !wd_packed || !dx_ext) return DEI2I_ERR_BAD_ARG;
   const ConvShape sh = to_shape(c);
-  const size_t esz = c->dtype == DT_BF16 ? 2 : 4;
   const int ncls = c->stride * c->stride;
-  size_t off = 0;
+  if (ncls > 4) return DEI2I_ERR_BAD_ARG;
+  GatherDesc descs[4];
+  long long woffs[4];
+  long long off = 0;
+  int n = 0;
   for (int ay = 0; ay < c->stride; ++ay)
     for (int ax = 0; ax < c->stride; ++ax) {
-      GatherDesc g = make_dgrad_desc(sh, c->CoutS, ay, ax);
-      const size_t welems = (size_t)c->Cin * g.th * g.tw * c->CoutS;
-      const void* wcls = (const char*)wd_packed + off * esz;
-      off += welems;
-      if (g.M <= 0) continue;
-      // split-K finalises the WHOLE output tensor, so it is only usable when one class covers it
-      hipError_t e = gather_gemm(c->dtype, g, dy, wcls, c->Cin, nullptr, dx_ext, ncls == 1 ? ws : nullptr,
-                                 ncls == 1 ? ws_bytes : 0, c->CinS, ACT_NONE, (hipStream_t)s);
-      if (e != hipSuccess) return (int)e;
+      descs[n] = make_dgrad_desc(sh, c->CoutS, ay, ax);
+      woffs[n] = off;
+      off += (long long)c->Cin * dgrad_taps(c->kh, c->stride, ay) * dgrad_taps(c->kw, c->stride, ax) * c->CoutS;
+      ++n;
     }
-  return 0;
+  // all parity classes in ONE launch (blockIdx.y); split-K accumulates every class into the shared fp32 workspace
+  return (int)gather_gemm_multi(c->dtype, descs, woffs, n, dy, wd_packed, c->Cin, nullptr, dx_ext, ws, ws_bytes, c->CinS,
+                                ACT_NONE, (hipStream_t)s);
 }
 
 int dei2i_conv2d_wgrad(const dei2i_conv* c, const void* x, const void* dy, float* dw_packed, dei2i_stream s) {
   if (!valid_conv(c) || !x || !dy || !dw_packed) return DEI2I_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)s;
   GatherDesc g = make_fwd_desc(to_shape(c), c->CinS);
-  hipError_t e = hipMemsetAsync(dw_packed, 0, dei2i_packed_fwd_elems(c) * sizeof(float), st);
-  if (e != hipSuccess) return (int)e;
   return (int)wgrad_gemm(c->dtype, g, x, dy, c->Cout, c->CoutS, dw_packed, st);
 }
 

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <algorithm>
 
 #include "common.h"
 #include "geom.h"
@@ -52,9 +53,15 @@ DEI2I_D int xcd_remap(int bid, int nwg) {
 // ------------------------------------------------------------------------------------------------
 // gather GEMM:  out[m][n] = act( sum_k  gather(src)[m][k] * wgt[n][k] + bias[n] )
 // ------------------------------------------------------------------------------------------------
+struct DescPack {
+  GatherDesc d[4];
+  long long woff[4];      // element offset of each class's packed weights
+  int n;
+};
+
 template <typename T, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherDesc g, const T* __restrict__ src,
-                                                          const T* __restrict__ wgt, const int wrows,
+__global__ __launch_bounds__(256) void gather_gemm_kernel(const DescPack pack, const T* __restrict__ src,
+                                                          const T* __restrict__ wgt_base, const int wrows,
                                                           const float* __restrict__ bias, T* __restrict__ out,
                                                           float* __restrict__ ws, const int ldc, const int act,
                                                           const int tiles_n, const int ksteps_per_split) {
@@ -74,11 +81,14 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherDesc g, co
   const int wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
 
+  const GatherDesc& g = pack.d[blockIdx.y];
+  const T* __restrict__ wgt = wgt_base + pack.woff[blockIdx.y];
   const int nwg = gridDim.x;
   const int bid = xcd_remap(blockIdx.x, nwg);
   const int tile_n = bid % tiles_n;
   const int tile_m = bid / tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
+  if (m0 >= g.M) return;
 
   const int nk_total = (g.K + BKE - 1) / BKE;
   const int kbeg = blockIdx.z * ksteps_per_split;
@@ -272,7 +282,7 @@ template <typename T, int BM, int BN>
 __global__ __launch_bounds__(256) void wgrad_kernel(const GatherDesc g, const T* __restrict__ src,
                                                     const T* __restrict__ dy, const int co_rows, const int ldy,
                                                     float* __restrict__ dw, const int tiles_k,
-                                                    const int chunks_per_split) {
+                                                    const int chunks_per_split, const int direct) {
   constexpr int VEC = Elem<T>::VEC;
   constexpr bool IS_BF16 = sizeof(T) == 2;
   constexpr int BR = 128 / (int)sizeof(T);           // pixels per reduction chunk (64 bf16 / 32 f32)
@@ -448,7 +458,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GatherDesc g, const T*
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int k = k0 + wn * WTN + j * 32 + lr;
-        if (k < g.K) atomicAdd(dw + (size_t)co * g.K + k, acc[i][j][e]);
+        if (k < g.K) {
+          if (direct) dw[(size_t)co * g.K + k] = acc[i][j][e];
+          else atomicAdd(dw + (size_t)co * g.K + k, acc[i][j][e]);
+        }
       }
     }
 }
@@ -459,15 +472,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GatherDesc g, const T*
 static int g_num_cu = 256;
 
 template <typename T, int BM, int BN, int WM, int WN>
-static hipError_t launch_gg(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias,
+static hipError_t launch_gg(const DescPack& pack, const void* src, const void* wgt, int wrows, const float* bias,
                             void* out, float* ws, int ldc, int act, int splits, hipStream_t st) {
   constexpr int BKE = 128 / (int)sizeof(T);
-  const int tiles_m = (g.M + BM - 1) / BM;
+  int tiles_m = 0, Kmax = 0;
+  double flops = 0.0;
+  for (int i = 0; i < pack.n; ++i) {
+    const GatherDesc& g = pack.d[i];
+    tiles_m = std::max(tiles_m, (g.M + BM - 1) / BM);
+    Kmax = std::max(Kmax, g.K);
+    flops += 2.0 * (double)g.M * (double)(g.th * g.tw) * (double)g.Clog * (double)wrows;
+  }
   const int tiles_n = (ldc + BN - 1) / BN;
-  const int nk = (g.K + BKE - 1) / BKE;
+  const int nk = (Kmax + BKE - 1) / BKE;
   const int kps = (nk + splits - 1) / splits;
   const int zs = (nk + kps - 1) / kps;
-  dim3 grid(tiles_m * tiles_n, 1, zs);
+  dim3 grid(tiles_m * tiles_n, pack.n, zs);
   const size_t lds = 2 * (BM + BN) * 128;
   auto kern = gather_gemm_kernel<T, BM, BN, WM, WN>;
   static bool attr_done = false;
@@ -476,26 +496,34 @@ static hipError_t launch_gg(const GatherDesc& g, const void* src, const void* wg
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  prof_begin(PROF_GATHER_GEMM, 2.0 * (double)g.M * (double)(g.th * g.tw) * (double)g.Clog * (double)wrows, st);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, (const T*)src, (const T*)wgt, wrows, bias, (T*)out,
+  prof_begin(PROF_GATHER_GEMM, flops, st);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, pack, (const T*)src, (const T*)wgt, wrows, bias, (T*)out,
                      zs > 1 ? ws : (float*)nullptr, ldc, act, tiles_n, kps);
   prof_end(PROF_GATHER_GEMM, st);
   return hipGetLastError();
 }
 
 template <typename T>
-static hipError_t gather_gemm_t(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias,
+static hipError_t gather_gemm_t(const DescPack& pack, const void* src, const void* wgt, int wrows, const float* bias,
                                 void* out, float* ws, size_t ws_bytes, int ldc, int act, hipStream_t st) {
-  if (g.M <= 0) return hipSuccess;
   constexpr int BKE = 128 / (int)sizeof(T);
   // tile choice by GEMM-N
   int BN = ldc > 64 ? 128 : (ldc > 32 ? 64 : 32);
   const int BM = 128;
-  const int tiles = ((g.M + BM - 1) / BM) * ((ldc + BN - 1) / BN);
-  const int nk = (g.K + BKE - 1) / BKE;
+  int tiles = 0, nk = 0;
+  bool any = false;
+  for (int i = 0; i < pack.n; ++i) {
+    const GatherDesc& g = pack.d[i];
+    if (g.M <= 0) continue;
+    any = true;
+    tiles += ((g.M + BM - 1) / BM) * ((ldc + BN - 1) / BN);
+    nk = std::max(nk, (g.K + BKE - 1) / BKE);
+  }
+  if (!any) return hipSuccess;
+  const GatherDesc& g0 = pack.d[0];
   // split-K when the grid cannot fill the chip: aim for >= 2 workgroups per CU, keep >= 4 k-steps per split
   int splits = 1;
-  const size_t out_elems = (size_t)g.N * g.OH * g.OW * ldc;
+  const size_t out_elems = (size_t)g0.N * g0.OH * g0.OW * ldc;
   if (tiles < g_num_cu && nk >= 8 && ws != nullptr && ws_bytes >= out_elems * sizeof(float)) {
     splits = (2 * g_num_cu + tiles - 1) / tiles;
     if (splits > nk / 4) splits = nk / 4;
@@ -506,9 +534,9 @@ static hipError_t gather_gemm_t(const GatherDesc& g, const void* src, const void
     if (e != hipSuccess) return e;
   }
   hipError_t e;
-  if (BN == 128) e = launch_gg<T, 128, 128, 2, 2>(g, src, wgt, wrows, bias, out, ws, ldc, act, splits, st);
-  else if (BN == 64) e = launch_gg<T, 128, 64, 2, 2>(g, src, wgt, wrows, bias, out, ws, ldc, act, splits, st);
-  else e = launch_gg<T, 128, 32, 4, 1>(g, src, wgt, wrows, bias, out, ws, ldc, act, splits, st);
+  if (BN == 128) e = launch_gg<T, 128, 128, 2, 2>(pack, src, wgt, wrows, bias, out, ws, ldc, act, splits, st);
+  else if (BN == 64) e = launch_gg<T, 128, 64, 2, 2>(pack, src, wgt, wrows, bias, out, ws, ldc, act, splits, st);
+  else e = launch_gg<T, 128, 32, 4, 1>(pack, src, wgt, wrows, bias, out, ws, ldc, act, splits, st);
   if (e != hipSuccess) return e;
   if (splits > 1) {
     const int threads = 256;
@@ -521,10 +549,28 @@ static hipError_t gather_gemm_t(const GatherDesc& g, const void* src, const void
   return e;
 }
 
+hipError_t gather_gemm_multi(int dtype, const GatherDesc* descs, const long long* woffs, int n, const void* src,
+                             const void* wgt, int wrows, const float* bias, void* out, float* ws, size_t ws_bytes, int ldc,
+                             int act, hipStream_t st) {
+  if (n < 1 || n > 4) return hipErrorInvalidValue;
+  DescPack pack;
+  pack.n = 0;
+  for (int i = 0; i < n; ++i) {
+    if (descs[i].M <= 0) continue;           // empty parity class
+    pack.d[pack.n] = descs[i];
+    pack.woff[pack.n] = woffs[i];
+    pack.n++;
+  }
+  if (pack.n == 0) return hipSuccess;
+  for (int i = pack.n; i < 4; ++i) { pack.d[i] = pack.d[0]; pack.woff[i] = 0; }
+  if (dtype == DT_BF16) return gather_gemm_t<bf16_t>(pack, src, wgt, wrows, bias, out, ws, ws_bytes, ldc, act, st);
+  return gather_gemm_t<float>(pack, src, wgt, wrows, bias, out, ws, ws_bytes, ldc, act, st);
+}
+
 hipError_t gather_gemm(int dtype, const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias,
                        void* out, float* ws, size_t ws_bytes, int ldc, int act, hipStream_t st) {
-  if (dtype == DT_BF16) return gather_gemm_t<bf16_t>(g, src, wgt, wrows, bias, out, ws, ws_bytes, ldc, act, st);
-  return gather_gemm_t<float>(g, src, wgt, wrows, bias, out, ws, ws_bytes, ldc, act, st);
+  const long long zero = 0;
+  return gather_gemm_multi(dtype, &g, &zero, 1, src, wgt, wrows, bias, out, ws, ws_bytes, ldc, act, st);
 }
 
 template <typename T, int BM, int BN>
@@ -548,9 +594,13 @@ static hipError_t launch_wg(const GatherDesc& g, const void* src, const void* dy
     if (e != hipSuccess) return e;
     attr_done = true;
   }
+  if (zs > 1) {        // accumulate with fp32 atomics into a zeroed buffer; a single split stores directly
+    hipError_t e = hipMemsetAsync(dw, 0, (size_t)co_rows * g.K * sizeof(float), st);
+    if (e != hipSuccess) return e;
+  }
   prof_begin(PROF_WGRAD, 2.0 * (double)g.M * (double)(g.th * g.tw) * (double)g.Clog * (double)co_rows, st);
   hipLaunchKernelGGL(kern, dim3(tiles, 1, zs), dim3(256), lds, st, g, (const T*)src, (const T*)dy, co_rows, ldy, dw,
-                     tiles_k, cps);
+                     tiles_k, cps, zs == 1 ? 1 : 0);
   prof_end(PROF_WGRAD, st);
   return hipGetLastError();
 }
@@ -558,8 +608,12 @@ static hipError_t launch_wg(const GatherDesc& g, const void* src, const void* dy
 hipError_t wgrad_gemm(int dtype, const GatherDesc& g, const void* src, const void* dy, int co_rows, int ldy, float* dw,
                       hipStream_t st) {
   if (g.M <= 0) return hipSuccess;
-  if (dtype == DT_BF16) return launch_wg<bf16_t, 128, 128>(g, src, dy, co_rows, ldy, dw, st);
-  return launch_wg<float, 128, 128>(g, src, dy, co_rows, ldy, dw, st);
+  if (dtype == DT_BF16) {
+    if (co_rows > 64) return launch_wg<bf16_t, 128, 128>(g, src, dy, co_rows, ldy, dw, st);
+    return launch_wg<bf16_t, 64, 128>(g, src, dy, co_rows, ldy, dw, st);
+  }
+  if (co_rows > 64) return launch_wg<float, 128, 128>(g, src, dy, co_rows, ldy, dw, st);
+  return launch_wg<float, 64, 128>(g, src, dy, co_rows, ldy, dw, st);
 }
 
 void set_num_cu(int n) { g_num_cu = n > 0 ? n : 256; }

@@ -48,18 +48,31 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict
 }
 
 // ---- out = act(a[c]*x + b[c]) (+ res) ----
-template <typename T>
+// When the launch's thread count is a multiple of cv, a thread's channel vector is the same in every grid-stride
+// iteration and its coefficients live in registers (INVARIANT); otherwise they are re-read per iteration.
+template <typename T, bool INVARIANT>
 __global__ void affine_act_kernel(const T* __restrict__ x, const float* __restrict__ a, const float* __restrict__ b,
                                   const T* __restrict__ res, T* __restrict__ out, size_t nvec, int cv, int act) {
   constexpr int VEC = Elem<T>::VEC;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+  float av[VEC], bv[VEC];
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (INVARIANT) {
     const int c = (int)(i % cv) * VEC;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { av[e] = a[c + e]; bv[e] = b[c + e]; }
+  }
+  for (; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+    if (!INVARIANT) {
+      const int c = (int)(i % cv) * VEC;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { av[e] = a[c + e]; bv[e] = b[c + e]; }
+    }
     float f[VEC], r[VEC];
     Elem<T>::unpack(*reinterpret_cast<const u32x4*>(x + i * VEC), f);
     if (res != nullptr) Elem<T>::unpack(*reinterpret_cast<const u32x4*>(res + i * VEC), r);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      float v = apply_act(fmaf(a[c + e], f[e], b[c + e]), act);
+      float v = apply_act(fmaf(av[e], f[e], bv[e]), act);
       if (res != nullptr) v += r[e];
       f[e] = v;
     }
@@ -210,12 +223,6 @@ __global__ void cast_from_f32_kernel(const float* __restrict__ src, T* __restric
 
 using namespace dei2i;
 
-#define DISPATCH(dtype, KERN, grid, block, st, ...)                                                   \
-  do {                                                                                               \
-    if ((dtype) == DT_BF16) hipLaunchKernelGGL(KERN<bf16_t>, dim3(grid), dim3(block), 0, st, __VA_ARGS__); \
-    else hipLaunchKernelGGL(KERN<float>, dim3(grid), dim3(block), 0, st, __VA_ARGS__);                 \
-  } while (0)
-
 static inline int vec_of(int dtype) { return dtype == DT_BF16 ? 8 : 4; }
 static const unsigned EW_CAP = 256u * 16u;
 
@@ -256,12 +263,17 @@ int dei2i_affine_act_fwd(int dtype, size_t pixels, int C, const void* x, const f
   const int vec = vec_of(dtype);
   if (pixels == 0 || C <= 0 || C % vec || !x || !a || !b || !out) return DEI2I_ERR_BAD_ARG;
   const size_t nvec = pixels * (size_t)(C / vec);
-  if (dtype == DT_BF16)
-    hipLaunchKernelGGL(affine_act_kernel<bf16_t>, dim3(grid_for(nvec, 256, EW_CAP)), dim3(256), 0, (hipStream_t)s,
-                       (const bf16_t*)x, a, b, (const bf16_t*)res, (bf16_t*)out, nvec, C / vec, act);
-  else
-    hipLaunchKernelGGL(affine_act_kernel<float>, dim3(grid_for(nvec, 256, EW_CAP)), dim3(256), 0, (hipStream_t)s,
-                       (const float*)x, a, b, (const float*)res, (float*)out, nvec, C / vec, act);
+  const int cv = C / vec;
+  const bool inv = (256 % cv) == 0;
+  const unsigned grid = grid_for(nvec, 256, EW_CAP);
+  hipStream_t st = (hipStream_t)s;
+  if (dtype == DT_BF16) {
+    if (inv) hipLaunchKernelGGL((affine_act_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, a, b, (const bf16_t*)res, (bf16_t*)out, nvec, cv, act);
+    else hipLaunchKernelGGL((affine_act_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, a, b, (const bf16_t*)res, (bf16_t*)out, nvec, cv, act);
+  } else {
+    if (inv) hipLaunchKernelGGL((affine_act_kernel<float, true>), dim3(grid), dim3(256), 0, st, (const float*)x, a, b, (const float*)res, (float*)out, nvec, cv, act);
+    else hipLaunchKernelGGL((affine_act_kernel<float, false>), dim3(grid), dim3(256), 0, st, (const float*)x, a, b, (const float*)res, (float*)out, nvec, cv, act);
+  }
   return (int)hipGetLastError();
 }
 

@@ -18,6 +18,9 @@ int num_cu();
 
 hipError_t gather_gemm(int dtype, const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias,
                        void* out, float* ws, size_t ws_bytes, int ldc, int act, hipStream_t st);
+hipError_t gather_gemm_multi(int dtype, const GatherDesc* descs, const long long* woffs, int n, const void* src,
+                             const void* wgt, int wrows, const float* bias, void* out, float* ws, size_t ws_bytes, int ldc,
+                             int act, hipStream_t st);
 hipError_t wgrad_gemm(int dtype, const GatherDesc& g, const void* src, const void* dy, int co_rows, int ldy, float* dw,
                       hipStream_t st);
 

@@ -71,18 +71,27 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const T* __restric
   }
 }
 
-__global__ void bn_finalize_train_kernel(const float* __restrict__ partial, int N, int chunks, int C, double count,
+DEI2I_D double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// one 64-lane wave per channel: lanes stride over the N*chunks partial records, fp64 combine
+__global__ __launch_bounds__(64) void bn_finalize_train_kernel(const float* __restrict__ partial, int N, int chunks, int C, double count,
                                          const float* __restrict__ weight, const float* __restrict__ bias,
                                          float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
                                          float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ a,
                                          float* __restrict__ b) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int c = blockIdx.x;
   double s = 0.0, ss = 0.0;
-  for (int i = 0; i < N * chunks; ++i) {
+  for (int i = threadIdx.x; i < N * chunks; i += 64) {
     s += (double)partial[(size_t)i * 2 * C + c];
     ss += (double)partial[(size_t)i * 2 * C + C + c];
   }
+  s = wave_sum_f64(s);
+  ss = wave_sum_f64(ss);
+  if (threadIdx.x != 0) return;
   const double mu = s / count;
   double var = ss / count - mu * mu;
   if (var < 0.0) var = 0.0;
@@ -173,41 +182,52 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int C, float* __restrict__ dweight,
-                                       float* __restrict__ dbias) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int C,
+                                                             float* __restrict__ dweight, float* __restrict__ dbias) {
+  const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < chunks; ++k) {
+  for (int k = threadIdx.x; k < chunks; k += 64) {
     s1 += (double)partial[(size_t)k * 2 * C + c];
     s2 += (double)partial[(size_t)k * 2 * C + C + c];
   }
-  dbias[c] = (float)s1;
-  dweight[c] = (float)s2;
+  s1 = wave_sum_f64(s1);
+  s2 = wave_sum_f64(s2);
+  if (threadIdx.x == 0) {
+    dbias[c] = (float)s1;
+    dweight[c] = (float)s2;
+  }
 }
 
-template <typename T>
+template <typename T, bool INVARIANT>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ y, const float* __restrict__ a,
                                     const float* __restrict__ b, const float* __restrict__ mean,
                                     const float* __restrict__ rstd, int act, int train, const float* __restrict__ dweight,
                                     const float* __restrict__ dbias, float inv_count, T* __restrict__ dy, size_t nvec,
                                     int cv) {
   constexpr int VEC = Elem<T>::VEC;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % cv) * VEC;
+  float av[VEC], bv[VEC], mv[VEC], rv[VEC], k1[VEC], k2[VEC];
+  auto load_coef = [&](int c) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      av[e] = a[c + e]; bv[e] = b[c + e]; mv[e] = mean[c + e]; rv[e] = rstd[c + e];
+      k1[e] = train ? dbias[c + e] * inv_count : 0.f;
+      k2[e] = train ? dweight[c + e] * inv_count : 0.f;
+    }
+  };
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (INVARIANT) load_coef((int)(i % cv) * VEC);
+  for (; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+    if (!INVARIANT) load_coef((int)(i % cv) * VEC);
     float d[VEC], yy[VEC];
     Elem<T>::unpack(*reinterpret_cast<const u32x4*>(dz + i * VEC), d);
     Elem<T>::unpack(*reinterpret_cast<const u32x4*>(y + i * VEC), yy);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      const float av = a[c + e];
-      const float z = fmaf(av, yy[e], b[c + e]);
+      const float z = fmaf(av[e], yy[e], bv[e]);
       float g = d[e] * act_grad_from_out(z, act);
-      if (train) {
-        const float xh = (yy[e] - mean[c + e]) * rstd[c + e];
-        g = g - dbias[c + e] * inv_count - xh * dweight[c + e] * inv_count;
-      }
-      d[e] = av * g;
+      const float xh = (yy[e] - mv[e]) * rv[e];
+      g = g - k1[e] - xh * k2[e];
+      d[e] = av[e] * g;
     }
     *reinterpret_cast<u32x4*>(dy + i * VEC) = Elem<T>::pack(d);
   }
@@ -471,7 +491,7 @@ int dei2i_bn_finalize_train(int N, int HW, int C, const float* partial, const fl
                             float* running_mean, float* running_var, float momentum, float eps, float* mean, float* rstd,
                             float* a, float* b, dei2i_stream s) {
   if (N <= 0 || HW <= 0 || C <= 0 || !partial || !weight || !bias || !mean || !rstd || !a || !b) return DEI2I_ERR_BAD_ARG;
-  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)s, partial, N,
+  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(C), dim3(64), 0, (hipStream_t)s, partial, N,
                      dei2i_moments_chunks(HW), C, (double)N * (double)HW, weight, bias, running_mean, running_var, momentum,
                      eps, mean, rstd, a, b);
   return (int)hipGetLastError();
@@ -534,16 +554,19 @@ int dei2i_bn_bwd_apply(int dtype, size_t pixels, int C, const void* dz, const vo
   if (pixels == 0 || !cv_ok(dtype, C) || !dz || !y || !a || !b || !mean || !rstd || !partial || !dweight || !dbias || !dy)
     return DEI2I_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)s;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial, chunks, C, dweight, dbias);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, partial, chunks, C, dweight, dbias);
   const size_t nvec = pixels * (size_t)(C / vec);
   const unsigned grid = grid_for(nvec, 256, 256u * 16u);
   const float inv = 1.f / (float)pixels;
-  if (dtype == DT_BF16)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)y, a, b, mean,
-                       rstd, act, train, (const float*)dweight, (const float*)dbias, inv, (bf16_t*)dy, nvec, C / vec);
-  else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dz, (const float*)y, a, b, mean,
-                       rstd, act, train, (const float*)dweight, (const float*)dbias, inv, (float*)dy, nvec, C / vec);
+  const int cv = C / vec;
+  const bool invc = (256 % cv) == 0;
+  if (dtype == DT_BF16) {
+    if (invc) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)y, a, b, mean, rstd, act, train, (const float*)dweight, (const float*)dbias, inv, (bf16_t*)dy, nvec, cv);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)y, a, b, mean, rstd, act, train, (const float*)dweight, (const float*)dbias, inv, (bf16_t*)dy, nvec, cv);
+  } else {
+    if (invc) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, true>), dim3(grid), dim3(256), 0, st, (const float*)dz, (const float*)y, a, b, mean, rstd, act, train, (const float*)dweight, (const float*)dbias, inv, (float*)dy, nvec, cv);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<float, false>), dim3(grid), dim3(256), 0, st, (const float*)dz, (const float*)y, a, b, mean, rstd, act, train, (const float*)dweight, (const float*)dbias, inv, (float*)dy, nvec, cv);
+  }
   return (int)hipGetLastError();
 }
 
@@ -597,8 +620,6 @@ int dei2i_spade_bwd_apply(int dtype, int N, int H, int W, int C, int up, const v
 int dei2i_bce_logits_fwd(size_t n, const float* x, const float* target, float tconst, float* out, dei2i_stream s) {
   if (n == 0 || !x || !out) return DEI2I_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)s;
-  hipError_t e = hipMemsetAsync(out, 0, sizeof(float), st);
-  if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(bce_fwd_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, st, x, target, tconst, n, 1.f / (float)n, out);
   return (int)hipGetLastError();
 }
@@ -614,8 +635,6 @@ int dei2i_bce_logits_bwd(size_t n, const float* x, const float* target, float tc
 int dei2i_l1_fwd(size_t n, const float* a, const float* b, float* out, dei2i_stream s) {
   if (n == 0 || !a || !out) return DEI2I_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)s;
-  hipError_t e = hipMemsetAsync(out, 0, sizeof(float), st);
-  if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(l1_fwd_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, st, a, b, n, 1.f / (float)n, out);
   return (int)hipGetLastError();
 }

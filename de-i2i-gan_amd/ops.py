@@ -495,6 +495,19 @@ def nan_guard_(x):
 # --------------------------------------------------------------------------------------------------------------
 # losses (models/base_model.py:68-80)
 # --------------------------------------------------------------------------------------------------------------
+_slabs = {}
+
+
+def _zero_scalar(device) -> torch.Tensor:
+    """0-dim fp32 zero carved from a pre-zeroed slab (one memset per 256 scalars instead of one per loss).  Slabs are
+    never recycled, so a loss tensor stays valid for as long as anything references it."""
+    slab, used = _slabs.get(device, (None, 0))
+    if slab is None or used >= slab.numel():
+        slab, used = torch.zeros(256, dtype=torch.float32, device=device), 0
+    _slabs[device] = (slab, used + 1)
+    return slab[used]
+
+
 class _BceLogits(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, target, tconst: float):
@@ -503,7 +516,7 @@ class _BceLogits(torch.autograd.Function):
         t = None if target is None else target.detach().contiguous().float().view(-1)
         if t is not None and t.numel() != x.numel():
             raise ValueError("bce_logits: target size mismatch")
-        out = torch.empty((), dtype=torch.float32, device=x.device)
+        out = _zero_scalar(x.device)
         lib = _lib_for(x)
         L.check(lib.dei2i_bce_logits_fwd(x.numel(), _p(x), _p(t), tconst, _p(out), _stream()), "bce_fwd")
         ctx.tconst = tconst
@@ -533,7 +546,7 @@ class _L1(torch.autograd.Function):
         _require_gpu(a, "l1")
         a = a.contiguous().float()
         bb = None if b is None else b.contiguous().float()
-        out = torch.empty((), dtype=torch.float32, device=a.device)
+        out = _zero_scalar(a.device)
         lib = _lib_for(a)
         L.check(lib.dei2i_l1_fwd(a.numel(), _p(a), _p(bb), _p(out), _stream()), "l1_fwd")
         ctx.save_for_backward(a, bb)

@@ -146,11 +146,12 @@ int dei2i_compose_bwd(int dtype, int N, int H, int W, int Cs, const void* raw, c
 int dei2i_nan_guard(int dtype, size_t n, void* x, int* flag, dei2i_stream s);
 
 /* ---- losses (models/base_model.py:68-80), fp32 tensors ---- */
-/* mean( max(x,0) - x*t + log1p(exp(-|x|)) ); target == NULL -> constant `tconst`.  out[0] = loss (overwritten). */
+/* mean( max(x,0) - x*t + log1p(exp(-|x|)) ); target == NULL -> constant `tconst`.  out[0] += loss: the caller hands
+ * in a zeroed scalar (the Python side carves them from one pre-zeroed slab: one memset per 256 losses). */
 int dei2i_bce_logits_fwd(size_t n, const float* x, const float* target, float tconst, float* out, dei2i_stream s);
 int dei2i_bce_logits_bwd(size_t n, const float* x, const float* target, float tconst, const float* gout, float* dx,
                          dei2i_stream s);
-/* mean |a - b| ; b == NULL -> 0.  backward: da = sign(a-b)*gout/n, db = -da (either may be NULL) */
+/* mean |a - b| ; b == NULL -> 0; out[0] += loss (zeroed by the caller).  backward: da = sign(a-b)*gout/n, db = -da (either may be NULL) */
 int dei2i_l1_fwd(size_t n, const float* a, const float* b, float* out, dei2i_stream s);
 int dei2i_l1_bwd(size_t n, const float* a, const float* b, const float* gout, float* da, float* db, dei2i_stream s);
 

@@ -159,7 +159,7 @@ def test_two_train_steps_match_reference_goldens(name, pname):
             assert maxrel(sdg[k], arr["bn::" + k]) < (5e-2 if pname == "f32" else 0.35), k
     for k in ("enc_blk.0.conv_block.0.weight", "src_clf.conv_block.0.weight"):
         d = (sd[k].cpu() - torch.from_numpy(arr["Dp::" + k])).abs()
-        assert d.max().item() <= 4 * cfg.lr + 1e-6          # sign-like early Adam steps: see test_oracle_goldens.py
+        assert d.max().item() <= 5 * cfg.lr          # sign-like early Adam steps (|update| <= ~1.1 lr each): see test_oracle_goldens.py
 
 
 def test_bf16_tracks_f32_with_reference_init():
