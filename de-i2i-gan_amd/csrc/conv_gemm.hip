@@ -53,12 +53,6 @@ DEI2I_D int xcd_remap(int bid, int nwg) {
 // ------------------------------------------------------------------------------------------------
 // gather GEMM:  out[m][n] = act( sum_k  gather(src)[m][k] * wgt[n][k] + bias[n] )
 // ------------------------------------------------------------------------------------------------
-struct DescPack {
-  GatherDesc d[4];
-  long long woff[4];      // element offset of each class's packed weights
-  int n;
-};
-
 template <typename T, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void gather_gemm_kernel(const DescPack pack, const T* __restrict__ src,
                                                           const T* __restrict__ wgt_base, const int wrows,
@@ -470,6 +464,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GatherDesc g, const T*
 // launchers
 // ------------------------------------------------------------------------------------------------
 static int g_num_cu = 256;
+static int g_use_v2 = 1;
+void set_use_v2(int on) { g_use_v2 = on; }
 
 template <typename T, int BM, int BN, int WM, int WN>
 static hipError_t launch_gg(const DescPack& pack, const void* src, const void* wgt, int wrows, const float* bias,
@@ -559,11 +555,18 @@ hipError_t gather_gemm_multi(int dtype, const GatherDesc* descs, const long long
     if (descs[i].M <= 0) continue;           // empty parity class
     pack.d[pack.n] = descs[i];
     pack.woff[pack.n] = woffs[i];
+    pack.fd_taps[pack.n] = make_fastdiv((uint32_t)(descs[i].th * descs[i].tw));
     pack.n++;
   }
   if (pack.n == 0) return hipSuccess;
-  for (int i = pack.n; i < 4; ++i) { pack.d[i] = pack.d[0]; pack.woff[i] = 0; }
-  if (dtype == DT_BF16) return gather_gemm_t<bf16_t>(pack, src, wgt, wrows, bias, out, ws, ws_bytes, ldc, act, st);
+  for (int i = pack.n; i < 4; ++i) { pack.d[i] = pack.d[0]; pack.woff[i] = 0; pack.fd_taps[i] = pack.fd_taps[0]; }
+  if (dtype == DT_BF16) {
+    if (g_use_v2) {
+      hipError_t e = gather_gemm_v2(pack, src, wgt, wrows, bias, out, ws, ws_bytes, ldc, act, g_num_cu, st);
+      if (e != hipErrorNotSupported) return e;
+    }
+    return gather_gemm_t<bf16_t>(pack, src, wgt, wrows, bias, out, ws, ws_bytes, ldc, act, st);
+  }
   return gather_gemm_t<float>(pack, src, wgt, wrows, bias, out, ws, ws_bytes, ldc, act, st);
 }
 

@@ -1,0 +1,289 @@
+// gather GEMM v2 (bf16 hot path): 256 x {128,64} output tiles, 8 wavefronts (512 threads), both operands streamed
+// straight into LDS with LDS-DMA (global_load_lds, 16 B per lane, no VGPR staging, no ds_write), a 3-stage LDS ring
+// with ONE raw s_barrier per k-step and counted vmcnt so two stages of loads stay in flight under the MFMAs.
+//
+// Why this shape on MI355X: a 128x128 tile needs (128+128)*128 B of operands per 2*128*128*64 FLOP = 64 FLOP/B, i.e.
+// ~150 GB/s per CU at the MFMA peak -- more than a CU can pull from L2, and the VGPR->LDS store path (ds_write_b128,
+// ~79 B/clk/CU) alone costs 80% of the MFMA time.  256x128 tiles raise the intensity to 85 FLOP/B and LDS-DMA takes
+// the store path out of the picture.
+//
+// Requirements (checked by the launcher; everything else runs on the v1 kernel): bf16, source channel stride a
+// multiple of 64 (every 64-element k-step then lies inside one tap: tap / channel offset are wave-uniform scalars).
+//
+// LDS image: [row][128 B] with the 16-byte chunk c of row r stored at slot c ^ ((r>>1)&7) (conflict-free
+// ds_read_b128 fragments).  LDS-DMA writes lane l of a wave-instruction at base + 16*l, i.e. row (l>>3), slot (l&7) of
+// an 8-row group, so each lane FETCHES chunk (l&7) ^ ((r>>1)&7) of its row: the swizzle lives on the source address.
+// Rows that contribute zeros (M / N edge, zero padding) fetch from a zero page.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <algorithm>
+
+#include "common.h"
+#include "geom.h"
+#include "launch.h"
+
+namespace dei2i {
+
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];   // zero-initialised device memory
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+DEI2I_D void glds16(const void* gptr, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gbl_void_t*)gptr, (lds_void_t*)lds_wave_base, 16, 0, 0);
+}
+
+DEI2I_D int xcd_remap2(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+template <int BN, int WM, int WN>
+__global__ __launch_bounds__(512) void gather_gemm_v2_kernel(const DescPack pack, const bf16_t* __restrict__ src,
+                                                             const bf16_t* __restrict__ wgt_base, const int wrows,
+                                                             const float* __restrict__ bias, bf16_t* __restrict__ out,
+                                                             float* __restrict__ ws, const int ldc, const int act,
+                                                             const int tiles_n, const int ksteps_per_split) {
+  constexpr int BM = 256, STAGES = 3;
+  constexpr int STAGE_BYTES = (BM + BN) * 128;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int LA = BM / 64, LB = BN / 64;         // LDS-DMA instructions per wave per stage
+  static_assert(WM * WN == 8, "8 waves per workgroup");
+  static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 block");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  const GatherDesc& g = pack.d[blockIdx.y];
+  const bf16_t* __restrict__ wgt = wgt_base + pack.woff[blockIdx.y];
+  const int bid = xcd_remap2(blockIdx.x, gridDim.x);
+  const int tile_n = bid % tiles_n, tile_m = bid / tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  if (m0 >= g.M) return;
+
+  const int nk_total = g.K >> 6;
+  const int kbeg = blockIdx.z * ksteps_per_split;
+  const int kend = min(nk_total, kbeg + ksteps_per_split);
+  if (kbeg >= kend) return;
+  const int nk = kend - kbeg;
+
+  // ---- per-lane load roles ----
+  const int lrow = lane >> 3, lslot = lane & 7;
+  int a_chunk[LA];
+#pragma unroll
+  for (int j = 0; j < LA; ++j) {
+    const int r = j * 64 + wave * 8 + lrow;
+    a_chunk[j] = (lslot ^ ((r >> 1) & 7)) * 8;      // element offset of the 16-byte chunk this lane fetches
+  }
+  const bf16_t* b_ptr[LB];
+#pragma unroll
+  for (int j = 0; j < LB; ++j) {
+    const int r = j * 64 + wave * 8 + lrow;
+    const int n = n0 + r;
+    const int chunk = (lslot ^ ((r >> 1) & 7)) * 8;
+    b_ptr[j] = n < wrows ? wgt + (size_t)n * g.K + chunk : nullptr;
+  }
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+
+  // Source-pixel offset table in LDS: tab[tap][row] = element offset of the row's source pixel for that tap (or -1
+  // for a zero contribution), built once per workgroup.  The steady-state k-step then costs a handful of VALU
+  // instructions per LDS-DMA: address generation (reflect / bounds / upsample math) is off the critical path.
+  int* tab = reinterpret_cast<int*>(smem + STAGES * STAGE_BYTES);
+  const int ntaps = g.th * g.tw;
+  {
+    const int r = tid & 255;
+    const int m = m0 + r;
+    int n = -1, by = 0, bx = 0;
+    if (m < g.M) {
+      int oy, ox;
+      decode_m(g, m, n, oy, ox);
+      by = oy * g.sh + g.by0;
+      bx = ox * g.sw + g.bx0;
+    }
+    for (int t = tid >> 8; t < ntaps; t += 2) {
+      const int ty = (int)fd_div((uint32_t)t, g.fd_tw);
+      const int tx = t - ty * g.tw;
+      const int y = bound_coord(by + ty * g.ys, g.Hl, g.pad_mode);
+      const int x = bound_coord(bx + tx * g.xs, g.Wl, g.pad_mode);
+      const int pix = (n * g.Hs + (y >> g.up)) * g.Ws + (x >> g.up);
+      tab[t * 256 + r] = ((y | x | n) < 0) ? -1 : pix * g.Cs;
+    }
+  }
+  __syncthreads();
+
+  const int cs = g.Cs;
+  const int steps_per_tap = cs >> 6;
+  int cur_tap = -1;
+  int a_off[LA];
+  // k-step order: tap outer, 64-channel chunk inner (matches the packed weight layout [Cout][tap][Cs])
+  auto issue = [&](int stage, int it) {
+    const int kstep = kbeg + it;
+    const int tap = kstep / steps_per_tap;                   // wave-uniform (scalar unit)
+    const int ci0 = (kstep - tap * steps_per_tap) << 6;
+    if (tap != cur_tap) {
+      cur_tap = tap;
+#pragma unroll
+      for (int j = 0; j < LA; ++j) a_off[j] = tab[tap * 256 + j * 64 + wave * 8 + lrow];
+    }
+    unsigned char* sbase = smem + stage * STAGE_BYTES;
+#pragma unroll
+    for (int j = 0; j < LA; ++j) {
+      const bf16_t* p = a_off[j] >= 0 ? src + ((size_t)(unsigned)a_off[j] + (unsigned)(a_chunk[j] + ci0)) : zero;
+      glds16(p, sbase + (j * 64 + wave * 8) * 128);
+    }
+    const int kb = kstep << 6;
+#pragma unroll
+    for (int j = 0; j < LB; ++j) {
+      const bf16_t* p = b_ptr[j] != nullptr ? b_ptr[j] + kb : zero;
+      glds16(p, sbase + BM * 128 + (j * 64 + wave * 8) * 128);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int lr = lane & 31, lh = lane >> 5;
+
+  auto compute = [&](int stage) {
+    const unsigned char* ab = smem + stage * STAGE_BYTES;
+    const unsigned char* bb = ab + BM * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 af[TM], bf[TN];
+      const int chunk = ks * 2 + lh;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * WTM + i * 32 + lr;
+        af[i] = *reinterpret_cast<const u32x4*>(ab + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wn * WTN + j * 32 + lr;
+        bf[j] = *reinterpret_cast<const u32x4*>(bb + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]),
+                                                               __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  };
+
+  // ---- 3-stage ring, one barrier per k-step ----
+  //   iteration it:  wait(stage it landed) ; barrier ; issue(stage it+2) ; compute(stage it)
+  // barrier(it) is passed only after every wave finished compute(it-1), so stage (it+2)%3 == (it-1)%3 is free to refill.
+  issue(0, 0);
+  if (nk > 1) issue(1, 1);
+  for (int it = 0; it < nk; ++it) {
+    if (it + 1 < nk) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LA + LB) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (it + 2 < nk) issue((it + 2) % STAGES, it + 2);
+    compute(it % STAGES);
+  }
+
+  // ---- epilogue (same D layout as v1: lane&31 = output channel, register e = pixel) ----
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      if (m >= g.M) continue;
+      size_t opix;
+      if (g.out_identity) {
+        opix = (size_t)m;
+      } else {
+        int n, oy, ox;
+        decode_m(g, m, n, oy, ox);
+        opix = (size_t)out_pixel(g, n, oy, ox);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WTN + j * 32 + lr;
+        if (n >= ldc) continue;
+        float v = acc[i][j][e];
+        if (ws != nullptr) {
+          if (n < wrows) atomicAdd(ws + opix * ldc + n, v);
+        } else {
+          if (n < wrows) {
+            if (bias != nullptr) v += bias[n];
+            v = apply_act(v, act);
+          } else {
+            v = 0.f;
+          }
+          out[opix * ldc + n] = f32_to_bf16(v);
+        }
+      }
+    }
+  }
+}
+
+template <int BN, int WM, int WN>
+static hipError_t launch_v2(const DescPack& pack, const void* src, const void* wgt, int wrows, const float* bias, void* out,
+                            float* ws, int ldc, int act, int splits, hipStream_t st) {
+  constexpr int BM = 256;
+  int tiles_m = 0, Kmax = 0;
+  double flops = 0.0;
+  for (int i = 0; i < pack.n; ++i) {
+    const GatherDesc& g = pack.d[i];
+    tiles_m = std::max(tiles_m, (g.M + BM - 1) / BM);
+    Kmax = std::max(Kmax, g.K);
+    flops += 2.0 * (double)g.M * (double)(g.th * g.tw) * (double)g.Clog * (double)wrows;
+  }
+  const int tiles_n = (ldc + BN - 1) / BN;
+  const int nk = Kmax >> 6;
+  const int kps = (nk + splits - 1) / splits;
+  const int zs = (nk + kps - 1) / kps;
+  const size_t lds = 3 * (size_t)(BM + BN) * 128 + 16 * 256 * sizeof(int);
+  auto kern = gather_gemm_v2_kernel<BN, WM, WN>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  prof_begin(PROF_GATHER_GEMM, flops, st);
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, pack.n, zs), dim3(512), lds, st, pack, (const bf16_t*)src,
+                     (const bf16_t*)wgt, wrows, bias, (bf16_t*)out, zs > 1 ? ws : (float*)nullptr, ldc, act, tiles_n, kps);
+  prof_end(PROF_GATHER_GEMM, st);
+  return hipGetLastError();
+}
+
+// returns hipErrorNotSupported when the shape does not qualify (caller falls through to the v1 kernel)
+hipError_t gather_gemm_v2(const DescPack& pack, const void* src, const void* wgt, int wrows, const float* bias, void* out,
+                          float* ws, size_t ws_bytes, int ldc, int act, int num_cu, hipStream_t st) {
+  int tiles256 = 0, nk = 0;
+  for (int i = 0; i < pack.n; ++i) {
+    const GatherDesc& g = pack.d[i];
+    if (g.Cs % 64 != 0 || g.K % 64 != 0 || g.th * g.tw > 16) return hipErrorNotSupported;
+    if ((long long)g.N * g.Hs * g.Ws * g.Cs >= (1ll << 31)) return hipErrorNotSupported;      // 32-bit offset table
+    tiles256 += (g.M + 255) / 256;
+    nk = std::max(nk, g.K >> 6);
+  }
+  if (ldc <= 32) return hipErrorNotSupported;
+  const int BN = ldc > 64 ? 128 : 64;
+  const int tiles = tiles256 * ((ldc + BN - 1) / BN);
+  if (tiles < num_cu / 2) return hipErrorNotSupported;        // small-M layers: v1 (128-row tiles, split-K) fills the chip better
+  (void)ws_bytes;
+  if (BN == 128) return launch_v2<128, 4, 2>(pack, src, wgt, wrows, bias, out, nullptr, ldc, act, 1, st);
+  return launch_v2<64, 4, 2>(pack, src, wgt, wrows, bias, out, nullptr, ldc, act, 1, st);
+}
+
+}  // namespace dei2i

