@@ -170,27 +170,32 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const DescPack pack, c
 
   const int lr = lane & 31, lh = lane >> 5;
 
+  // fragment reads software-pipelined against the MFMAs through two register sets (see conv_gemm_v2.hip)
   auto compute_tile = [&](int buf) {
     const unsigned char* ab = smem + buf * TILE_BYTES;
     const unsigned char* bb = ab + BM * 128;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      u32x4 af[TM], bf[TN];
+    u32x4 af[2][TM], bf[2][TN];
+    auto load_frags = [&](int ks, u32x4 (&a)[TM], u32x4 (&b)[TN]) {
       const int chunk = ks * 2 + lh;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int row = wm * WTM + i * 32 + lr;
-        af[i] = *reinterpret_cast<const u32x4*>(ab + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+        a[i] = *reinterpret_cast<const u32x4*>(ab + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int row = wn * WTN + j * 32 + lr;
-        bf[j] = *reinterpret_cast<const u32x4*>(bb + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+        b[j] = *reinterpret_cast<const u32x4*>(bb + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
       }
+    };
+    load_frags(0, af[0], bf[0]);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks + 1 < 4) load_frags(ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) Mma<T>::run(af[i], bf[j], acc[i][j]);
+        for (int j = 0; j < TN; ++j) Mma<T>::run(af[ks & 1][i], bf[ks & 1][j], acc[i][j]);
     }
   };
 
@@ -378,9 +383,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GatherDesc g, const T*
     const unsigned char* ab = smem + buf * TILE_BYTES;
     const unsigned char* bb = ab + A_BYTES;
     if constexpr (IS_BF16) {
-#pragma unroll
-      for (int kk = 0; kk < BR / 16; ++kk) {
-        u32x4 af[TM], bf[TN];
+      u32x4 af[BR / 16][TM], bf[BR / 16][TN];
+      auto load_frags = [&](int kk, u32x4 (&a)[TM], u32x4 (&b)[TN]) {
         const int row_lo = kk * 16 + 8 * lh + tr_q;     // rows row_lo (k 0..3) and row_lo+4 (k 4..7)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GatherDesc g, const T*
           s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ab + o0));
           s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ab + o1));
           u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
-          af[i].x = l2.x; af[i].y = l2.y; af[i].z = h2.x; af[i].w = h2.y;
+          a[i].x = l2.x; a[i].y = l2.y; a[i].z = h2.x; a[i].w = h2.y;
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -400,14 +404,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GatherDesc g, const T*
           s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(bb + o0));
           s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(bb + o1));
           u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
-          bf[j].x = l2.x; bf[j].y = l2.y; bf[j].z = h2.x; bf[j].w = h2.y;
+          b[j].x = l2.x; b[j].y = l2.y; b[j].z = h2.x; b[j].w = h2.y;
         }
+      };
+#pragma unroll
+      for (int kk = 0; kk < BR / 16; ++kk) load_frags(kk, af[kk], bf[kk]);     // every fragment read of the chunk in flight
+#pragma unroll
+      for (int kk = 0; kk < BR / 16; ++kk) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]),
-                                                                 __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[kk][i]),
+                                                                 __builtin_bit_cast(bf16x8, bf[kk][j]), acc[i][j], 0, 0, 0);
       }
     } else {
 #pragma unroll 4

@@ -44,7 +44,8 @@ __global__ __launch_bounds__(512) void gather_gemm_v2_kernel(const DescPack pack
                                                              const bf16_t* __restrict__ wgt_base, const int wrows,
                                                              const float* __restrict__ bias, bf16_t* __restrict__ out,
                                                              float* __restrict__ ws, const int ldc, const int act,
-                                                             const int tiles_n, const int ksteps_per_split) {
+                                                             const int tiles_n, const int ksteps_per_split, const int ablate,
+                                                             unsigned long long* __restrict__ dbg) {
   constexpr int BM = 256, STAGES = 3;
   constexpr int STAGE_BYTES = (BM + BN) * 128;
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -54,6 +55,7 @@ __global__ __launch_bounds__(512) void gather_gemm_v2_kernel(const DescPack pack
   static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 block");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned long long t0 = ablate == 5 ? __builtin_amdgcn_s_memtime() : 0ull;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -117,8 +119,7 @@ __global__ __launch_bounds__(512) void gather_gemm_v2_kernel(const DescPack pack
   }
   __syncthreads();
 
-  const int cs = g.Cs;
-  const int steps_per_tap = cs >> 6;
+  const int steps_per_tap = __builtin_amdgcn_readfirstlane(g.Cs >> 6);
   int cur_tap = -1;
   int a_off[LA];
   // k-step order: tap outer, 64-channel chunk inner (matches the packed weight layout [Cout][tap][Cs])
@@ -155,31 +156,38 @@ __global__ __launch_bounds__(512) void gather_gemm_v2_kernel(const DescPack pack
 
   const int lr = lane & 31, lh = lane >> 5;
 
+  // Fragment reads are software-pipelined against the MFMAs through two register sets: the ds_reads of k-substep
+  // ks+1 are issued BEFORE the MFMAs of ks.  (With one set, a ds_read that overwrites the source registers of a
+  // queued MFMA cannot issue until that MFMA has read them, so LDS latency and MFMA time add up instead of overlapping.)
   auto compute = [&](int stage) {
     const unsigned char* ab = smem + stage * STAGE_BYTES;
     const unsigned char* bb = ab + BM * 128;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      u32x4 af[TM], bf[TN];
+    u32x4 af[2][TM], bf[2][TN];
+    auto load_frags = [&](int ks, u32x4 (&a)[TM], u32x4 (&b)[TN]) {
       const int chunk = ks * 2 + lh;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int row = wm * WTM + i * 32 + lr;
-        af[i] = *reinterpret_cast<const u32x4*>(ab + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+        a[i] = *reinterpret_cast<const u32x4*>(ab + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int row = wn * WTN + j * 32 + lr;
-        bf[j] = *reinterpret_cast<const u32x4*>(bb + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+        b[j] = *reinterpret_cast<const u32x4*>(bb + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
       }
-      __builtin_amdgcn_s_setprio(1);
+    };
+    load_frags(0, af[0], bf[0]);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks + 1 < 4) load_frags(ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);   // in flight under the MFMAs of ks
+      __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMAs (else the two register sets are merged)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]),
-                                                               __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[ks & 1][i]),
+                                                               __builtin_bit_cast(bf16x8, bf[ks & 1][j]), acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -188,6 +196,7 @@ __global__ __launch_bounds__(512) void gather_gemm_v2_kernel(const DescPack pack
   // barrier(it) is passed only after every wave finished compute(it-1), so stage (it+2)%3 == (it-1)%3 is free to refill.
   issue(0, 0);
   if (nk > 1) issue(1, 1);
+  const unsigned long long t1 = ablate == 5 ? __builtin_amdgcn_s_memtime() : 0ull;
   for (int it = 0; it < nk; ++it) {
     if (it + 1 < nk) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LA + LB) : "memory");
@@ -195,16 +204,65 @@ __global__ __launch_bounds__(512) void gather_gemm_v2_kernel(const DescPack pack
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    if (it + 2 < nk) issue((it + 2) % STAGES, it + 2);
-    compute(it % STAGES);
+    if (it + 2 < nk && ablate != 1 && ablate != 3) issue((it + 2) % STAGES, it + 2);
+    if (ablate != 2 && ablate != 3) compute(it % STAGES);
   }
 
-  // ---- epilogue (same D layout as v1: lane&31 = output channel, register e = pixel) ----
+  const unsigned long long t2 = ablate == 5 ? __builtin_amdgcn_s_memtime() : 0ull;
+  if (ablate == 4) return;
+  // ---- epilogue ----
+  // D layout: lane&31 = output channel, register e = pixel row.  Direct stores would be 2-byte stores (64 B per
+  // 32 lanes); instead the tile is staged through the (now idle) LDS ring as bf16 [row][BN] and written back with
+  // 16-byte stores, one 2*BN-byte row per BN/8 lanes.  Split-K partials (fp32 atomics) keep the direct path.
+  if (ws != nullptr) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int m = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (m >= g.M) continue;
+        size_t opix;
+        if (g.out_identity) {
+          opix = (size_t)m;
+        } else {
+          int n, oy, ox;
+          decode_m(g, m, n, oy, ox);
+          opix = (size_t)out_pixel(g, n, oy, ox);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + wn * WTN + j * 32 + lr;
+          if (n < wrows) atomicAdd(ws + opix * ldc + n, acc[i][j][e]);
+        }
+      }
+    return;
+  }
+  __syncthreads();                       // every wave is done reading the ring
+  bf16_t* ctile = reinterpret_cast<bf16_t*>(smem);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = wn * WTN + j * 32 + lr;
+    const int n = n0 + col;
+    const float bv = (bias != nullptr && n < wrows) ? bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const float v = n < wrows ? apply_act(acc[i][j][e] + bv, act) : 0.f;
+        ctile[row * BN + col] = f32_to_bf16(v);
+      }
+  }
+  __syncthreads();
+  constexpr int CPR = BN / 8;             // 16-byte chunks per tile row
+  constexpr int RPP = 512 / CPR;          // rows per pass
+  const int chunk = tid % CPR, rsub = tid / CPR;
+  const int ncol = n0 + chunk * 8;
+  if (ncol < ldc) {
+#pragma unroll
+    for (int p = 0; p < BM / RPP; ++p) {
+      const int row = p * RPP + rsub;
+      const int m = m0 + row;
       if (m >= g.M) continue;
       size_t opix;
       if (g.out_identity) {
@@ -214,26 +272,19 @@ __global__ __launch_bounds__(512) void gather_gemm_v2_kernel(const DescPack pack
         decode_m(g, m, n, oy, ox);
         opix = (size_t)out_pixel(g, n, oy, ox);
       }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WTN + j * 32 + lr;
-        if (n >= ldc) continue;
-        float v = acc[i][j][e];
-        if (ws != nullptr) {
-          if (n < wrows) atomicAdd(ws + opix * ldc + n, v);
-        } else {
-          if (n < wrows) {
-            if (bias != nullptr) v += bias[n];
-            v = apply_act(v, act);
-          } else {
-            v = 0.f;
-          }
-          out[opix * ldc + n] = f32_to_bf16(v);
-        }
-      }
+      *reinterpret_cast<u32x4*>(out + opix * ldc + ncol) = *reinterpret_cast<const u32x4*>(ctile + row * BN + chunk * 8);
     }
   }
+  if (ablate == 5 && dbg != nullptr && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+    unsigned long long* d = dbg + (size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 4;
+    d[0] = t0; d[1] = t1; d[2] = t2; d[3] = t3;
+  }
 }
+
+int g_v2_ablate = 0;
+unsigned long long* g_v2_dbg = nullptr;
 
 template <int BN, int WM, int WN>
 static hipError_t launch_v2(const DescPack& pack, const void* src, const void* wgt, int wrows, const float* bias, void* out,
@@ -261,7 +312,7 @@ static hipError_t launch_v2(const DescPack& pack, const void* src, const void* w
   }
   prof_begin(PROF_GATHER_GEMM, flops, st);
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, pack.n, zs), dim3(512), lds, st, pack, (const bf16_t*)src,
-                     (const bf16_t*)wgt, wrows, bias, (bf16_t*)out, zs > 1 ? ws : (float*)nullptr, ldc, act, tiles_n, kps);
+                     (const bf16_t*)wgt, wrows, bias, (bf16_t*)out, zs > 1 ? ws : (float*)nullptr, ldc, act, tiles_n, kps, g_v2_ablate, g_v2_dbg);
   prof_end(PROF_GATHER_GEMM, st);
   return hipGetLastError();
 }

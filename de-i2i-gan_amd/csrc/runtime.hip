@@ -9,6 +9,8 @@
 
 namespace dei2i {
 
+extern int g_v2_ablate;
+extern unsigned long long* g_v2_dbg;
 static int g_cus = 256;
 void set_num_cu_rt(int n) { g_cus = n > 0 ? n : 256; }
 int num_cu() { return g_cus; }
@@ -69,8 +71,11 @@ const char* dei2i_error_string(int code) {
 int dei2i_set_option(const char* name, int value) {
   if (name == nullptr) return DEI2I_ERR_BAD_ARG;
   if (std::string(name) == "gather_gemm_v2") { set_use_v2(value); return 0; }
+  if (std::string(name) == "v2_ablate") { g_v2_ablate = value; return 0; }     // timing-only builds: 1 = no loads, 2 = no MFMA
   return DEI2I_ERR_BAD_ARG;
 }
+
+int dei2i_set_debug_buffer(void* p) { g_v2_dbg = (unsigned long long*)p; return 0; }
 
 int dei2i_prof_enable(int family, int on) {
   if (family < 0 || family >= PROF_FAMILIES) return DEI2I_ERR_BAD_ARG;

@@ -49,6 +49,8 @@ int dei2i_init(int device);                         /* queries the CU count; opt
 const char* dei2i_error_string(int code);
 /* tuning / A-B switches: "gather_gemm_v2" = 0|1 (LDS-DMA 256-row-tile conv kernel for the bf16 hot shapes) */
 int dei2i_set_option(const char* name, int value);
+/* diagnostic builds only: device buffer receiving in-kernel s_memtime stamps (option "v2_ablate" = 5) */
+int dei2i_set_debug_buffer(void* device_ptr);
 
 /* ---- packed weight layouts (replaces nothing in the reference: layout prep for the kernels) ---- */
 size_t dei2i_packed_fwd_elems(const dei2i_conv* c);      /* Cout * kh*kw * CinS */

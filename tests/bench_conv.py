@@ -34,6 +34,9 @@ def timeit(fn, iters=10):
 def main():
     prec = ops.get_precision(sys.argv[1] if len(sys.argv) > 1 else "bf16")
     only = sys.argv[2] if len(sys.argv) > 2 else None
+    if len(sys.argv) > 3:
+        from de_i2i_gan_amd import _lib
+        _lib.load().dei2i_set_option(b"v2_ablate", int(sys.argv[3]))
     for name, cin, cout, k, s, pad, refl, up, H, N in SHAPES:
         if only and only not in name:
             continue
