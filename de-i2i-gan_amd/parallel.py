@@ -26,12 +26,14 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, process_group=None, bucket_bytes: int = 16 << 20, direct_bytes: int = 4 << 20, overlap: bool = True):
+    def __init__(self, process_group=None, bucket_bytes: int = 16 << 20, direct_bytes: int = 4 << 20, overlap: bool = True,
+                 force_collectives: bool = False):
         if not dist.is_initialized():
             raise RuntimeError("GradReducer needs an initialised torch.distributed process group")
         self.pg = process_group
         self.world = dist.get_world_size(process_group)
         self.bucket_bytes, self.direct_bytes, self.overlap = bucket_bytes, direct_bytes, overlap
+        self.active = self.world > 1 or force_collectives      # force: run the collective path on a 1-rank group (tests)
         self._attached = set()
         self._side: Dict[torch.device, torch.cuda.Stream] = {}
         self._bucket: List[torch.Tensor] = []
@@ -62,7 +64,7 @@ class GradReducer:
     # ---- hook path (during backward) ---------------------------------------------------------------------
     def _on_grad_ready(self, p: torch.Tensor) -> None:
         g = p.grad
-        if g is None or self.world == 1:
+        if g is None or not self.active:
             return
         nbytes = g.numel() * g.element_size()
         if nbytes >= self.direct_bytes:
@@ -107,7 +109,7 @@ class GradReducer:
     def reduce(self, net: torch.nn.Module) -> None:
         """Finish the step's gradient exchange: after this returns (stream-ordered), every ``p.grad`` holds the SUM
         over ranks.  Use ``FusedAdam.grad_scale = 1/world`` (set by ``attach_ddp``) for the average."""
-        if self.world == 1:
+        if not self.active:
             return
         if id(net) not in self._attached or not self.overlap:
             for p in net.parameters():                      # no-overlap path: same bucketing, issued now
@@ -132,7 +134,7 @@ class GradReducer:
 
     def broadcast_buffers(self, net: torch.nn.Module, src: int = 0) -> None:
         bufs = [b for b in net.buffers() if b.is_floating_point()]
-        if self.world == 1 or not bufs:
+        if not self.active or not bufs:
             return
         flat = torch.cat([b.reshape(-1) for b in bufs])
         dist.broadcast(flat, src=src, group=self.pg)

@@ -196,3 +196,31 @@ def test_step_wrapper_and_deferred_losses():
     got = [tr.losses["gan"]["D"][0], tr.losses["clf"]["D"][0], tr.losses["gan"]["G"][0], tr.losses["clf"]["G"][0],
            tr.losses["aux"]["rec"][0], tr.losses["aux"]["cyc"][0], tr.losses["aux"]["con"][0]]
     assert maxrel(np.array(got), arr["losses"][0]) < 1e-4
+
+
+def test_ddp_reducer_on_gpu_single_rank_rccl():
+    """One-rank RCCL group on the GPU: the hook-driven side-stream all-reduce path (forced on) must leave the step's
+    numbers unchanged.  Multi-rank correctness is covered on CPU/gloo (tests/test_ddp_gloo.py)."""
+    import os
+    import torch.distributed as dist
+    from de_i2i_gan_amd.parallel import attach_ddp
+    meta, arr, c, cfg = load_golden("t0_img32_b2")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        tr = build(c, "f32")
+        red = attach_ddp(tr, force_collectives=True, bucket_bytes=1 << 14, direct_bytes=1 << 12)
+        bg, labels, df = O.synthetic_batch(c["batch"], c["image_size"])
+        tr.step(bg, labels, df)
+        got = [tr.losses["gan"]["D"][0], tr.losses["clf"]["D"][0], tr.losses["gan"]["G"][0], tr.losses["clf"]["G"][0],
+               tr.losses["aux"]["rec"][0], tr.losses["aux"]["cyc"][0], tr.losses["aux"]["con"][0]]
+        assert maxrel(np.array(got), arr["losses"][0]) < 1e-4
+        tr.step(bg, labels, df)
+        torch.cuda.synchronize()
+        assert red.stats["collectives"] > 10
+        sd = tr.model.netD.state_dict()
+        mine = np.array([float(sd[k].double().norm()) for k in meta["D_check_keys"]])
+        assert maxrel(mine, arr["D_post_norm"]) < 1e-3
+    finally:
+        dist.destroy_process_group()
