@@ -6,6 +6,8 @@
 
 namespace dei2i {
 
+int g_use_wgrad_v2 = 1;
+
 static ConvShape to_shape(const dei2i_conv* c) {
   ConvShape s;
   s.N = c->N; s.H = c->H; s.W = c->W; s.Cin = c->Cin; s.Cout = c->Cout;
@@ -214,6 +216,28 @@ int dei2i_conv2d_wgrad(const dei2i_conv* c, const void* x, const void* dy, float
   hipStream_t st = (hipStream_t)s;
   GatherDesc g = make_fwd_desc(to_shape(c), c->CinS);
   return (int)wgrad_gemm(c->dtype, g, x, dy, c->Cout, c->CoutS, dw_packed, st);
+}
+
+/* wgrad straight to the OIHW fp32 gradient: the bf16 hot shapes take the LDS-DMA slab kernel + fused reduce/un-pack
+ * (scratch >= Cout*kh*kw*CinS floats; more lets it split the pixel range further); other shapes take the v1 kernel
+ * into scratch[0 : packed elems] and the un-pack kernel. */
+int dei2i_conv2d_wgrad_oihw(const dei2i_conv* c, const void* x, const void* dy, float* scratch, size_t scratch_elems,
+                            float* dw_oihw, dei2i_stream s) {
+  if (!valid_conv(c) || !x || !dy || !scratch || !dw_oihw) return DEI2I_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)s;
+  const size_t packed = dei2i_packed_fwd_elems(c);
+  if (scratch_elems < packed) return DEI2I_ERR_WORKSPACE;
+  GatherDesc g = make_fwd_desc(to_shape(c), c->CinS);
+  if (c->dtype == DT_BF16 && g_use_wgrad_v2) {
+    int nsplit = 0;
+    hipError_t e = wgrad_v2(g, x, dy, c->Cout, c->CoutS, scratch, scratch_elems, num_cu(), &nsplit, st);
+    if (e == hipSuccess)
+      return (int)wgrad_reduce_unpack(scratch, nsplit, (long long)packed, dw_oihw, c->Cout, c->Cin, c->CinS, c->kh * c->kw, st);
+    if (e != hipErrorNotSupported) return (int)e;
+  }
+  hipError_t e = wgrad_gemm(c->dtype, g, x, dy, c->Cout, c->CoutS, scratch, st);
+  if (e != hipSuccess) return (int)e;
+  return dei2i_unpack_wgrad(c, scratch, dw_oihw, 0.f, s);
 }
 
 int dei2i_fold_pad(int dtype, int N, int H, int W, int C, int pad, int pad_mode, int up, const void* dx_ext,

@@ -80,11 +80,11 @@ def _lib_for(t: torch.Tensor):
 _workspaces = {}
 
 
-def _workspace(device, nbytes: int) -> torch.Tensor:
-    ws = _workspaces.get(device)
+def _workspace(device, nbytes: int, slot: str = "splitk") -> torch.Tensor:
+    ws = _workspaces.get((device, slot))
     if ws is None or ws.numel() * 4 < nbytes:
         ws = torch.empty(max(nbytes // 4 + 1, 1 << 20), dtype=torch.float32, device=device)
-        _workspaces[device] = ws
+        _workspaces[(device, slot)] = ws
     return ws
 
 
@@ -208,10 +208,11 @@ class _Conv2d(torch.autograd.Function):
             else:
                 dx = ext
         if ctx.needs_input_grad[1]:
-            dwp = torch.empty(lib.dei2i_packed_fwd_elems(byref(d)), dtype=torch.float32, device=x.device)
-            L.check(lib.dei2i_conv2d_wgrad(byref(d), _p(x), _p(g), _p(dwp), st), "conv2d_wgrad")
+            packed = lib.dei2i_packed_fwd_elems(byref(d))
+            scratch = _workspace(x.device, max(packed * 4, min(packed * 4 * 16, 512 << 20)), slot="wgrad")
             dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
-            L.check(lib.dei2i_unpack_wgrad(byref(d), _p(dwp), _p(dw), 0.0, st), "unpack_wgrad")
+            L.check(lib.dei2i_conv2d_wgrad_oihw(byref(d), _p(x), _p(g), _p(scratch), scratch.numel(), _p(dw), st),
+                    "conv2d_wgrad")
         if ctx.has_bias and ctx.needs_input_grad[2]:
             dbf = torch.empty(couts, dtype=torch.float32, device=x.device)
             L.check(lib.dei2i_colsum(prec.code, g.numel() // couts, couts, _p(g), _p(dbf), st), "colsum")

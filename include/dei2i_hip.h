@@ -47,7 +47,7 @@ typedef struct dei2i_conv {
 int dei2i_version(void);
 int dei2i_init(int device);                         /* queries the CU count; optional */
 const char* dei2i_error_string(int code);
-/* tuning / A-B switches: "gather_gemm_v2" = 0|1 (LDS-DMA 256-row-tile conv kernel for the bf16 hot shapes) */
+/* tuning / A-B switches: "gather_gemm_v2" / "wgrad_v2" = 0|1 (LDS-DMA kernels for the bf16 hot shapes) */
 int dei2i_set_option(const char* name, int value);
 /* diagnostic builds only: device buffer receiving in-kernel s_memtime stamps (option "v2_ablate" = 5) */
 int dei2i_set_debug_buffer(void* device_ptr);
@@ -71,6 +71,11 @@ int dei2i_conv2d_dgrad(const dei2i_conv* c, const void* dy, const void* wd_packe
                        size_t ws_bytes, dei2i_stream s);
 /* dw_packed (fp32, dei2i_packed_fwd_elems) is zeroed by the call, then accumulated with fp32 atomics */
 int dei2i_conv2d_wgrad(const dei2i_conv* c, const void* x, const void* dy, float* dw_packed, dei2i_stream s);
+/* wgrad straight to the OIHW fp32 gradient (what autograd hands to the optimizer).  scratch: fp32 device buffer of at
+ * least dei2i_packed_fwd_elems(c) floats; extra capacity lets the LDS-DMA kernel split the pixel range over more
+ * workgroups (one partial slab per split, summed and un-packed by a second kernel: no float atomics). */
+int dei2i_conv2d_wgrad_oihw(const dei2i_conv* c, const void* x, const void* dy, float* scratch, size_t scratch_elems,
+                            float* dw_oihw, dei2i_stream s);
 /* reflection_pad2d_backward + upsample_nearest2d_backward: fold the dgrad output (N,OH,OW,C) back onto the
  * physical input (N,H,W,C); optional addend (residual-branch gradient) is summed in the same pass. */
 int dei2i_fold_pad(int dtype, int N, int H, int W, int C, int pad, int pad_mode, int up, const void* dx_ext,

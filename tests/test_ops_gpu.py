@@ -101,10 +101,11 @@ def test_conv2d_fwd_bwd(ops, pname, case):
     # with a fused activation a pre-activation within rounding of 0 can land on the other side of the kink than in the
     # reference (a full-magnitude outlier in a handful of elements) -> judge those cases by relative L2
     err = (lambda a, b: ((a.detach().double().cpu() - b).norm() / b.norm()).item()) if act != "none" else maxrel
-    assert err(xg.grad, grads[0]) < tol, "dgrad"
-    assert err(wg.grad, grads[1]) < tol, "wgrad"
+    gtol = max(tol, 2e-3) if act != "none" else tol           # a few kink flips among millions of outputs
+    assert err(xg.grad, grads[0]) < gtol, "dgrad"
+    assert err(wg.grad, grads[1]) < gtol, "wgrad"
     if has_bias:
-        assert err(bg.grad, grads[2]) < tol, "bias grad"
+        assert err(bg.grad, grads[2]) < gtol, "bias grad"
 
 
 @pytest.mark.parametrize("pname", ["f32", "bf16"])
