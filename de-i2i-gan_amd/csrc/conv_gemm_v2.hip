@@ -39,14 +39,14 @@ DEI2I_D int xcd_remap2(int bid, int nwg) {
   return base + (bid >> 3);
 }
 
-template <int BN, int WM, int WN>
+template <int BN, int WM, int WN, int STAGES>
 __global__ __launch_bounds__(512) void gather_gemm_v2_kernel(const DescPack pack, const bf16_t* __restrict__ src,
                                                              const bf16_t* __restrict__ wgt_base, const int wrows,
                                                              const float* __restrict__ bias, bf16_t* __restrict__ out,
                                                              float* __restrict__ ws, const int ldc, const int act,
                                                              const int tiles_n, const int ksteps_per_split, const int ablate,
                                                              unsigned long long* __restrict__ dbg) {
-  constexpr int BM = 256, STAGES = 3;
+  constexpr int BM = 256;
   constexpr int STAGE_BYTES = (BM + BN) * 128;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -191,23 +191,24 @@ __global__ __launch_bounds__(512) void gather_gemm_v2_kernel(const DescPack pack
     }
   };
 
-  // ---- 3-stage ring, one barrier per k-step ----
-  //   iteration it:  wait(stage it landed) ; barrier ; issue(stage it+2) ; compute(stage it)
-  // barrier(it) is passed only after every wave finished compute(it-1), so stage (it+2)%3 == (it-1)%3 is free to refill.
+  // ---- LDS ring, one barrier per k-step ----
+  //   iteration it:  wait(stage it landed) ; barrier ; issue(stage it+STAGES-1) ; compute(stage it)
+  // barrier(it) is passed only after every wave finished compute(it-1), so the stage that held it-1 is free to refill.
+  // STAGES = 3: two stages of loads stay in flight under the MFMAs; STAGES = 2 (256x256 tiles): one.
+  constexpr int AHEAD = STAGES - 1;
   issue(0, 0);
-  if (nk > 1) issue(1, 1);
+  if (AHEAD > 1 && nk > 1) issue(1, 1);
   const unsigned long long t1 = ablate == 5 ? __builtin_amdgcn_s_memtime() : 0ull;
   for (int it = 0; it < nk; ++it) {
-    if (it + 1 < nk) {
+    if (AHEAD > 1 && it + 1 < nk) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LA + LB) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    if (it + 2 < nk && ablate != 1 && ablate != 3) issue((it + 2) % STAGES, it + 2);
+    if (it + AHEAD < nk && ablate != 1 && ablate != 3) issue((it + AHEAD) % STAGES, it + AHEAD);
     if (ablate != 2 && ablate != 3) compute(it % STAGES);
   }
-
   const unsigned long long t2 = ablate == 5 ? __builtin_amdgcn_s_memtime() : 0ull;
   if (ablate == 4) return;
   // ---- epilogue ----
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(512) void gather_gemm_v2_kernel(const DescPack pack
 int g_v2_ablate = 0;
 unsigned long long* g_v2_dbg = nullptr;
 
-template <int BN, int WM, int WN>
+template <int BN, int WM, int WN, int STAGES>
 static hipError_t launch_v2(const DescPack& pack, const void* src, const void* wgt, int wrows, const float* bias, void* out,
                             float* ws, int ldc, int act, int splits, hipStream_t st) {
   constexpr int BM = 256;
@@ -302,8 +303,8 @@ static hipError_t launch_v2(const DescPack& pack, const void* src, const void* w
   const int nk = Kmax >> 6;
   const int kps = (nk + splits - 1) / splits;
   const int zs = (nk + kps - 1) / kps;
-  const size_t lds = 3 * (size_t)(BM + BN) * 128 + 16 * 256 * sizeof(int);
-  auto kern = gather_gemm_v2_kernel<BN, WM, WN>;
+  const size_t lds = STAGES * (size_t)(BM + BN) * 128 + 16 * 256 * sizeof(int);
+  auto kern = gather_gemm_v2_kernel<BN, WM, WN, STAGES>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -329,12 +330,20 @@ hipError_t gather_gemm_v2(const DescPack& pack, const void* src, const void* wgt
     nk = std::max(nk, g.K >> 6);
   }
   if (ldc <= 32) return hipErrorNotSupported;
+  (void)ws_bytes;
+  // one 8-wave workgroup owns a CU, so cost ~ rounds x per-tile time; a 256x256 tile does 2x the work of a 256x128 one
+  // in ~1.2x the time (operand bytes per FLOP drop from 48 KB to 32 KB per 128 output columns)
+  if (ldc >= 256 && ldc % 256 == 0) {
+    // measured: wins (~1.2x) when all tiles run in ONE round; with 2+ rounds the exposed 128 KB epilogue and the shallower
+    // 2-stage prefetch eat the gain (res-block dgrad 189 vs 185 us, dec0 dgrad 536 vs 350 us)
+    const int t256 = tiles256 * (ldc / 256);
+    if (t256 >= num_cu / 2 && t256 <= num_cu) return launch_v2<256, 2, 4, 2>(pack, src, wgt, wrows, bias, out, nullptr, ldc, act, 1, st);
+  }
   const int BN = ldc > 64 ? 128 : 64;
   const int tiles = tiles256 * ((ldc + BN - 1) / BN);
   if (tiles < num_cu / 2) return hipErrorNotSupported;        // small-M layers: v1 (128-row tiles, split-K) fills the chip better
-  (void)ws_bytes;
-  if (BN == 128) return launch_v2<128, 4, 2>(pack, src, wgt, wrows, bias, out, nullptr, ldc, act, 1, st);
-  return launch_v2<64, 4, 2>(pack, src, wgt, wrows, bias, out, nullptr, ldc, act, 1, st);
+  if (BN == 128) return launch_v2<128, 4, 2, 3>(pack, src, wgt, wrows, bias, out, nullptr, ldc, act, 1, st);
+  return launch_v2<64, 4, 2, 3>(pack, src, wgt, wrows, bias, out, nullptr, ldc, act, 1, st);
 }
 
 }  // namespace dei2i

@@ -50,6 +50,7 @@ class DefectGanModel(BaseModel):
     def _compute_generator_loss(self, bg_data, df_labels, df_data):
         """defectgan_model.py:173-249"""
         nm_labels, df_labels = self._get_labels(df_labels)
+        self.netG.clear_spade_cache()
         fake_defects, df_prob = self.netG(bg_data, df_labels)
         recover_normals, rec_df_prob = self.netG(fake_defects, nm_labels)
         fake_normals, nm_prob = self.netG(df_data, nm_labels)
@@ -80,6 +81,7 @@ class DefectGanModel(BaseModel):
     def _compute_discriminator_loss(self, bg_data, df_labels, df_data):
         """defectgan_model.py:251-292"""
         nm_labels, df_labels = self._get_labels(df_labels)
+        self.netG.clear_spade_cache()
         with torch.no_grad():
             fake_defects, _ = self.netG(bg_data, df_labels)
             fake_normals, _ = self.netG(df_data, nm_labels)
@@ -100,6 +102,7 @@ class DefectGanModel(BaseModel):
     @torch.no_grad()
     def _generate_fake(self, data, labels):
         """defectgan_model.py:302-314 (spade branch): labels (N,C) or a spatial (N,C,h,w) map"""
+        self.netG.clear_spade_cache()
         return self.netG(data, self._expand_seg(labels))
 
     @staticmethod

@@ -202,19 +202,40 @@ class SPADE(nn.Module):
         self.mlp_gamma = Conv2d(hidden_nc, norm_nc, kernel_size, padding=padding)
         self.mlp_beta = Conv2d(hidden_nc, norm_nc, kernel_size, padding=padding)
         self._packed_gb = ops.PackedWeights()
+        self._gb_cache = {}
+
+    def _gamma_beta(self, segmap, prec, class_mode, h, w):
+        """gamma|beta of the label map: (N,5,5,2C) border-class table (class mode) or (N,H,W,2C) dense."""
+        seg = ops.to_nhwc(segmap, prec, size=(5, 5) if class_mode else (h, w))
+        actv = self.mlp_shared[0](seg, "relu")
+        w_gb = torch.cat([self.mlp_gamma.weight, self.mlp_beta.weight], 0)
+        b_gb = torch.cat([self.mlp_gamma.bias, self.mlp_beta.bias], 0)
+        geom = ops.ConvGeom(self.hidden_nc, 2 * self.norm_nc, self.mlp_gamma.kernel_size, 1, self.mlp_gamma.padding, False, False)
+        return ops.conv2d(actv, w_gb, b_gb, self._packed_gb, geom, "none", sources=(self.mlp_gamma.weight, self.mlp_beta.weight))
 
     def forward(self, x, segmap, up=False):
         prec = ops.precision_of(x)
         n, hs, ws, c = x.shape
         h, w = (2 * hs, 2 * ws) if up else (hs, ws)
         class_mode = segmap.shape[2] == 1 and segmap.shape[3] == 1 and h >= 4 and w >= 4
-        seg = ops.to_nhwc(segmap, prec, size=(5, 5) if class_mode else (h, w))
-        actv = self.mlp_shared[0](seg, "relu")
-        w_gb = torch.cat([self.mlp_gamma.weight, self.mlp_beta.weight], 0)
-        b_gb = torch.cat([self.mlp_gamma.bias, self.mlp_beta.bias], 0)
-        geom = ops.ConvGeom(self.hidden_nc, 2 * self.norm_nc, self.mlp_gamma.kernel_size, 1, self.mlp_gamma.padding, False, False)
-        gb = ops.conv2d(actv, w_gb, b_gb, self._packed_gb, geom, "none", sources=(self.mlp_gamma.weight, self.mlp_beta.weight))
-        return ops.spade_relu(x, gb, up, 1 if class_mode else 0)
+        if not class_mode:
+            return ops.spade_relu(x, self._gamma_beta(segmap, prec, False, h, w), up, 0)
+        # The class table depends only on (label map, this module's weights), not on x: the loss graphs call G several
+        # times with the SAME label tensors (defectgan_model.py:185-190), so the table -- with its autograd history,
+        # autograd sums the gradients of all its uses -- is computed once per (label tensor, weight state, grad mode).
+        params = (self.mlp_shared[0].weight, self.mlp_shared[0].bias, self.mlp_gamma.weight, self.mlp_gamma.bias,
+                  self.mlp_beta.weight, self.mlp_beta.bias)
+        key = (id(segmap), segmap._version, prec.code, torch.is_grad_enabled(),
+               tuple(ops.PackedWeights._stamp(p) + (p.requires_grad,) for p in params))
+        hit = self._gb_cache.get(key)
+        if hit is None:
+            gb = self._gamma_beta(segmap, prec, True, h, w)
+            if len(self._gb_cache) >= 2:
+                self._gb_cache.clear()
+            self._gb_cache[key] = (segmap, gb)          # keep the label tensor alive so its id stays unique
+        else:
+            gb = hit[1]
+        return ops.spade_relu(x, gb, up, 1)
 
 
 def _style_norm(style_norm_block_type, label_nc, f, hidden_nc):

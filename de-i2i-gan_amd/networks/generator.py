@@ -84,6 +84,13 @@ class DefectGanGenerator(BaseNetwork):
         output, spatial_prob = ops.compose(raw, x)
         return output, spatial_prob
 
+    def clear_spade_cache(self):
+        """Drop the memoized SPADE gamma/beta tables (they carry autograd history: a table must not outlive the loss
+        graph it was built in).  The model calls this at the start of every loss computation."""
+        for m in self.modules():
+            if hasattr(m, "_gb_cache"):
+                m._gb_cache.clear()
+
     def update_per_epoch(self, epoch):
         super().update_per_epoch(epoch)
         _ = (1 + math.cos(math.pi * epoch / self.opt.num_epochs)) / 2      # SEAN alpha schedule; SPADE has no use for it

@@ -61,6 +61,7 @@ CONV_CASES = [
     (128, 64, 3, 1, 1, True, True, 32, 32, 8, False, "none"),      # v2 BN=64 with fused upsample; dgrad -> v2 BN=128
     (64, 128, 4, 2, 1, True, False, 128, 128, 8, False, "leaky_relu"),   # stride 2: 4 dgrad parity classes in one launch
     (128, 192, 3, 1, 1, False, False, 30, 34, 32, True, "none"),   # zero padding through the zero page, ragged M, bias
+    (64, 256, 3, 1, 1, True, False, 64, 60, 8, True, "relu"),      # 256x256-tile variant (2-stage ring), ragged M; wgrad v2
 ]
 
 
