@@ -529,9 +529,11 @@ static hipError_t gather_gemm_t(const DescPack& pack, const void* src, const voi
   // split-K when the grid cannot fill the chip: aim for >= 2 workgroups per CU, keep >= 4 k-steps per split
   int splits = 1;
   const size_t out_elems = (size_t)g0.N * g0.OH * g0.OW * ldc;
-  if (tiles < g_num_cu && nk >= 8 && ws != nullptr && ws_bytes >= out_elems * sizeof(float)) {
+  if (tiles < g_num_cu && nk >= 4 && ws != nullptr && ws_bytes >= out_elems * sizeof(float)) {
+    // small-M layers (deep D convs, the 5x5 SPADE table convs) are a serial chain of k-steps on a handful of CUs:
+    // spread K over the idle CUs, down to 2 k-steps per workgroup
     splits = (2 * g_num_cu + tiles - 1) / tiles;
-    if (splits > nk / 4) splits = nk / 4;
+    if (splits > nk / 2) splits = nk / 2;
     if (splits < 1) splits = 1;
   }
   if (splits > 1) {
