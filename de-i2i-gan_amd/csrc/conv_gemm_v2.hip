@@ -39,15 +39,15 @@ DEI2I_D int xcd_remap2(int bid, int nwg) {
   return base + (bid >> 3);
 }
 
-template <int BN, int WM, int WN, int STAGES>
+template <int BM, int BN, int WM, int WN, int STAGES>
 __global__ __launch_bounds__(512) void gather_gemm_v2_kernel(const DescPack pack, const bf16_t* __restrict__ src,
                                                              const bf16_t* __restrict__ wgt_base, const int wrows,
                                                              const float* __restrict__ bias, bf16_t* __restrict__ out,
                                                              float* __restrict__ ws, const int ldc, const int act,
                                                              const int tiles_n, const int ksteps_per_split, const int ablate,
                                                              unsigned long long* __restrict__ dbg) {
-  constexpr int BM = 256;
   constexpr int STAGE_BYTES = (BM + BN) * 128;
+  static_assert(BM % 64 == 0 && (BM / WM) % 32 == 0, "tile rows");
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int LA = BM / 64, LB = BN / 64;         // LDS-DMA instructions per wave per stage
@@ -98,24 +98,20 @@ __global__ __launch_bounds__(512) void gather_gemm_v2_kernel(const DescPack pack
   // instructions per LDS-DMA: address generation (reflect / bounds / upsample math) is off the critical path.
   int* tab = reinterpret_cast<int*>(smem + STAGES * STAGE_BYTES);
   const int ntaps = g.th * g.tw;
-  {
-    const int r = tid & 255;
+  for (int idx = tid; idx < ntaps * BM; idx += 512) {
+    const int t = idx / BM, r = idx - t * BM;
     const int m = m0 + r;
-    int n = -1, by = 0, bx = 0;
+    int off = -1;
     if (m < g.M) {
-      int oy, ox;
+      int n, oy, ox;
       decode_m(g, m, n, oy, ox);
-      by = oy * g.sh + g.by0;
-      bx = ox * g.sw + g.bx0;
-    }
-    for (int t = tid >> 8; t < ntaps; t += 2) {
       const int ty = (int)fd_div((uint32_t)t, g.fd_tw);
       const int tx = t - ty * g.tw;
-      const int y = bound_coord(by + ty * g.ys, g.Hl, g.pad_mode);
-      const int x = bound_coord(bx + tx * g.xs, g.Wl, g.pad_mode);
-      const int pix = (n * g.Hs + (y >> g.up)) * g.Ws + (x >> g.up);
-      tab[t * 256 + r] = ((y | x | n) < 0) ? -1 : pix * g.Cs;
+      const int y = bound_coord(oy * g.sh + g.by0 + ty * g.ys, g.Hl, g.pad_mode);
+      const int x = bound_coord(ox * g.sw + g.bx0 + tx * g.xs, g.Wl, g.pad_mode);
+      if ((y | x) >= 0) off = ((n * g.Hs + (y >> g.up)) * g.Ws + (x >> g.up)) * g.Cs;
     }
+    tab[idx] = off;
   }
   __syncthreads();
 
@@ -130,7 +126,7 @@ __global__ __launch_bounds__(512) void gather_gemm_v2_kernel(const DescPack pack
     if (tap != cur_tap) {
       cur_tap = tap;
 #pragma unroll
-      for (int j = 0; j < LA; ++j) a_off[j] = tab[tap * 256 + j * 64 + wave * 8 + lrow];
+      for (int j = 0; j < LA; ++j) a_off[j] = tab[tap * BM + j * 64 + wave * 8 + lrow];
     }
     unsigned char* sbase = smem + stage * STAGE_BYTES;
 #pragma unroll
@@ -287,10 +283,9 @@ __global__ __launch_bounds__(512) void gather_gemm_v2_kernel(const DescPack pack
 int g_v2_ablate = 0;
 unsigned long long* g_v2_dbg = nullptr;
 
-template <int BN, int WM, int WN, int STAGES>
+template <int BM, int BN, int WM, int WN, int STAGES>
 static hipError_t launch_v2(const DescPack& pack, const void* src, const void* wgt, int wrows, const float* bias, void* out,
                             float* ws, int ldc, int act, int splits, hipStream_t st) {
-  constexpr int BM = 256;
   int tiles_m = 0, Kmax = 0;
   double flops = 0.0;
   for (int i = 0; i < pack.n; ++i) {
@@ -303,8 +298,8 @@ static hipError_t launch_v2(const DescPack& pack, const void* src, const void* w
   const int nk = Kmax >> 6;
   const int kps = (nk + splits - 1) / splits;
   const int zs = (nk + kps - 1) / kps;
-  const size_t lds = STAGES * (size_t)(BM + BN) * 128 + 16 * 256 * sizeof(int);
-  auto kern = gather_gemm_v2_kernel<BN, WM, WN, STAGES>;
+  const size_t lds = STAGES * (size_t)(BM + BN) * 128 + 16 * BM * sizeof(int);
+  auto kern = gather_gemm_v2_kernel<BM, BN, WM, WN, STAGES>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -321,29 +316,36 @@ static hipError_t launch_v2(const DescPack& pack, const void* src, const void* w
 // returns hipErrorNotSupported when the shape does not qualify (caller falls through to the v1 kernel)
 hipError_t gather_gemm_v2(const DescPack& pack, const void* src, const void* wgt, int wrows, const float* bias, void* out,
                           float* ws, size_t ws_bytes, int ldc, int act, int num_cu, hipStream_t st) {
-  int tiles256 = 0, nk = 0;
+  int tiles256 = 0, tiles192 = 0, nk = 0;
   for (int i = 0; i < pack.n; ++i) {
     const GatherDesc& g = pack.d[i];
     if (g.Cs % 64 != 0 || g.K % 64 != 0 || g.th * g.tw > 16) return hipErrorNotSupported;
     if ((long long)g.N * g.Hs * g.Ws * g.Cs >= (1ll << 31)) return hipErrorNotSupported;      // 32-bit offset table
     tiles256 += (g.M + 255) / 256;
+    tiles192 += (g.M + 191) / 192;
     nk = std::max(nk, g.K >> 6);
   }
   if (ldc <= 32) return hipErrorNotSupported;
   (void)ws_bytes;
-  // one 8-wave workgroup owns a CU, so cost ~ rounds x per-tile time; a 256x256 tile does 2x the work of a 256x128 one
-  // in ~1.2x the time (operand bytes per FLOP drop from 48 KB to 32 KB per 128 output columns)
+  // One 8-wave workgroup owns a CU (LDS), every tile of a launch takes the same time, so cost ~ rounds x tile size.
   if (ldc >= 256 && ldc % 256 == 0) {
-    // measured: wins (~1.2x) when all tiles run in ONE round; with 2+ rounds the exposed 128 KB epilogue and the shallower
-    // 2-stage prefetch eat the gain (res-block dgrad 189 vs 185 us, dec0 dgrad 536 vs 350 us)
+    // measured: 256x256 wins (~1.2x) when all tiles run in ONE round; with 2+ rounds the exposed 128 KB epilogue and the
+    // shallower 2-stage prefetch eat the gain (res-block dgrad 189 vs 185 us, dec0 dgrad 536 vs 350 us)
     const int t256 = tiles256 * (ldc / 256);
-    if (t256 >= num_cu / 2 && t256 <= num_cu) return launch_v2<256, 2, 4, 2>(pack, src, wgt, wrows, bias, out, nullptr, ldc, act, 1, st);
+    if (t256 >= num_cu / 2 && t256 <= num_cu)
+      return launch_v2<256, 256, 2, 4, 2>(pack, src, wgt, wrows, bias, out, nullptr, ldc, act, 1, st);
   }
   const int BN = ldc > 64 ? 128 : 64;
-  const int tiles = tiles256 * ((ldc + BN - 1) / BN);
-  if (tiles < num_cu / 2) return hipErrorNotSupported;        // small-M layers: v1 (128-row tiles, split-K) fills the chip better
-  if (BN == 128) return launch_v2<128, 4, 2, 3>(pack, src, wgt, wrows, bias, out, nullptr, ldc, act, 1, st);
-  return launch_v2<64, 4, 2, 3>(pack, src, wgt, wrows, bias, out, nullptr, ldc, act, 1, st);
+  const int ntn = (ldc + BN - 1) / BN;
+  if (tiles256 * ntn < num_cu / 2) return hipErrorNotSupported;   // small-M layers: v1 (128-row tiles, split-K) fills the chip better
+  if (BN == 128) {
+    // ragged M (dgrad on the padded frame: 69696 rows -> 546 tiles = 2.13 rounds): 192-row tiles waste less of the last round
+    const long long c256 = (long long)((tiles256 * ntn + num_cu - 1) / num_cu) * 256;
+    const long long c192 = (long long)((tiles192 * ntn + num_cu - 1) / num_cu) * 192;
+    if (c192 < c256) return launch_v2<192, 128, 2, 4, 3>(pack, src, wgt, wrows, bias, out, nullptr, ldc, act, 1, st);
+    return launch_v2<256, 128, 4, 2, 3>(pack, src, wgt, wrows, bias, out, nullptr, ldc, act, 1, st);
+  }
+  return launch_v2<256, 64, 4, 2, 3>(pack, src, wgt, wrows, bias, out, nullptr, ldc, act, 1, st);
 }
 
 }  // namespace dei2i
