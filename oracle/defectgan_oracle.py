@@ -63,9 +63,62 @@ def conv2d(x: Tensor, w: Tensor, *, stride: int = 1, pad: int = 0, mode: str = "
     return F.conv2d(x, w, bias, stride=stride, padding=pad)
 
 
+# Test hook -- branch tape.  The loss graphs hold ~1e5 piecewise-linear kinks (ReLU, LeakyReLU, |a-b|) behind
+# BatchNorm over as few as 16 samples, which amplifies fp32 rounding noise to ~1e-5..1e-4 by the fourth chained
+# generator pass (measured: the fp32 run of THIS oracle takes a different branch than its fp64 run on 0-12 elements of
+# most inputs).  An element within noise of a kink may take either slope -- both are correct -- but the choice moves
+# every upstream gradient by percents.  To compare gradients exactly, the path under test records the branch it took
+# at every kink on the gradient path (one tensor per site, in forward order) and the oracle replays those branches;
+# the tape counts the elements where the replayed branch differs from the oracle's own and how far from the kink they
+# sit, so a test can assert they are all within noise.
+KINK_TAPE = None
+
+
+class KinkTape:
+    def __init__(self, decisions):
+        self._it = iter(decisions)
+        self.sites = 0
+        self.flips = 0
+        self.worst = 0.0            # largest |x| / rms(x) over the flipped elements
+
+    def exhausted(self) -> bool:
+        return next(self._it, None) is None
+
+    def replay(self, x: Tensor, natural: Tensor, kind: str) -> Tensor:
+        """Recorded branch for kink argument ``x`` (NCHW): 'relu' / 'leaky' sites record the activation OUTPUT in
+        NHWC with channels possibly zero-padded (branch = output > 0 / >= 0); 'l1' sites record sign(a - b)."""
+        rec_kind, rec = next(self._it)
+        assert rec_kind == kind, (self.sites, rec_kind, kind)
+        if kind == "l1":
+            assert tuple(rec.shape) == tuple(x.shape), (self.sites, tuple(rec.shape), tuple(x.shape))
+            forced = rec.to(x.dtype)
+        else:
+            assert rec.shape[0] == x.shape[0] and tuple(rec.shape[1:3]) == tuple(x.shape[2:]) and rec.shape[3] >= x.shape[1], \
+                (self.sites, kind, tuple(rec.shape), tuple(x.shape))
+            y = rec.permute(0, 3, 1, 2)[:, :x.shape[1]]
+            forced = (y > 0) if kind == "relu" else (y >= 0)
+        dis = forced != natural
+        n = int(dis.sum())
+        if n:
+            d = x.detach()
+            self.flips += n
+            self.worst = max(self.worst, float(d[dis].abs().max() / (d.pow(2).mean().sqrt() + 1e-30)))
+        self.sites += 1
+        return forced
+
+
+def relu(x: Tensor) -> Tensor:
+    if KINK_TAPE is None or not x.requires_grad:
+        return torch.relu(x)
+    return x * KINK_TAPE.replay(x, x > 0, "relu").to(x.dtype)
+
+
 def leaky_relu(x: Tensor) -> Tensor:
     """architecture.py:15 -- LeakyReLU(0.2)."""
-    return torch.where(x >= 0, x, 0.2 * x)
+    pos = x >= 0
+    if KINK_TAPE is not None and x.requires_grad:
+        pos = KINK_TAPE.replay(x, pos, "leaky")
+    return torch.where(pos, x, 0.2 * x)
 
 
 def batchnorm(S: Dict[str, Tensor], prefix: str, x: Tensor, training: bool) -> Tensor:
@@ -117,7 +170,7 @@ def spade(S: Dict[str, Tensor], prefix: str, x: Tensor, seg: Tensor) -> Tensor:
     """normalization.py:24-37 -- IN(x)*(1+gamma)+beta, gamma/beta from the resized label map."""
     normalized = instancenorm(x)
     seg = nearest_resize(seg, (x.shape[2], x.shape[3]))
-    actv = torch.relu(conv2d(seg, S[prefix + ".mlp_shared.0.weight"], pad=1,
+    actv = torch.relu(conv2d(seg, S[prefix + ".mlp_shared.0.weight"], pad=1,      # label path: exact inputs, no kink note
                              bias=S[prefix + ".mlp_shared.0.bias"]))
     gamma = conv2d(actv, S[prefix + ".mlp_gamma.weight"], pad=1, bias=S[prefix + ".mlp_gamma.bias"])
     beta = conv2d(actv, S[prefix + ".mlp_beta.weight"], pad=1, bias=S[prefix + ".mlp_beta.bias"])
@@ -155,16 +208,16 @@ def generator_forward(S: Dict[str, Tensor], x: Tensor, labels: Tensor, cfg: Cfg,
     # NormResBlocks (up_scale=False: norm_s/conv_s never run) -- architecture.py:343-357
     for i in range(cfg.num_res // 2):
         p = f"dec_res_blk.{i}"
-        h = conv2d(torch.relu(spade(S, p + ".norm_0", feat, labels)), S[p + ".conv_0.weight"],
+        h = conv2d(relu(spade(S, p + ".norm_0", feat, labels)), S[p + ".conv_0.weight"],
                    pad=1, mode="reflect")
-        h = conv2d(torch.relu(spade(S, p + ".norm_1", h, labels)), S[p + ".conv_1.weight"],
+        h = conv2d(relu(spade(S, p + ".norm_1", h, labels)), S[p + ".conv_1.weight"],
                    pad=1, mode="reflect")
         feat = h + feat
     # NormConvBlocks: up -> SPADE -> ReLU -> conv -- architecture.py:241-245
     for i in range(cfg.num_scales):
         p = f"dec_blk.{i}"
         feat = upsample2x(feat)
-        feat = conv2d(torch.relu(spade(S, p + ".norm", feat, labels)), S[p + ".conv.weight"],
+        feat = conv2d(relu(spade(S, p + ".norm", feat, labels)), S[p + ".conv.weight"],
                       pad=1, mode="reflect")
     # NaN guard -- generator.py:266-267
     if torch.isnan(feat).any():
@@ -193,8 +246,12 @@ def bce_logits(x: Tensor, t: Tensor) -> Tensor:
     return (torch.clamp_min(x, 0) - x * t + torch.log1p(torch.exp(-x.abs()))).mean()
 
 
-def l1(a: Tensor, b: Tensor) -> Tensor:
-    return (a - b).abs().mean()
+def l1(a: Tensor, b: Tensor, kink: bool = True) -> Tensor:
+    """l1_loss, mean.  ``kink=False``: the argument cannot change sign (sd_con: a sigmoid against zeros)."""
+    d = a - b
+    if kink and KINK_TAPE is not None and d.requires_grad:
+        return (d * KINK_TAPE.replay(d, torch.sign(d.detach()), "l1")).mean()
+    return d.abs().mean()
 
 
 def _labels(df_labels: Tensor) -> Tuple[Tensor, Tensor]:
@@ -241,7 +298,8 @@ def generator_losses(SG, SD, bg: Tensor, df_labels: Tensor, df: Tensor, cfg: Cfg
     rec = torch.stack([l1(recover_defects, df), l1(recover_normals, bg)]).mean()
     cyc = torch.stack([l1(df_prob, rec_df_prob), l1(nm_prob, rec_nm_prob)]).mean()
     zero = torch.zeros_like(df_prob)
-    con = torch.stack([l1(df_prob, zero), l1(nm_prob, zero), l1(rec_df_prob, zero), l1(rec_nm_prob, zero)]).mean()
+    con = torch.stack([l1(df_prob, zero, False), l1(nm_prob, zero, False), l1(rec_df_prob, zero, False),
+                       l1(rec_nm_prob, zero, False)]).mean()
     return gan, clf, rec, cyc, con
 
 

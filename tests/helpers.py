@@ -41,3 +41,46 @@ def formula_fill(net):
     with torch.no_grad():
         for k, v in sd.items():
             v.copy_(O.formula_tensor(k, tuple(v.shape)).to(v.device))
+
+
+class record_kinks:
+    """Context manager: record, in forward order, the branch the HIP path took at every piecewise-linear kink on the
+    gradient path -- the input format of ``oracle.KinkTape`` (see the note above ``KINK_TAPE`` in the oracle).
+    'relu' / 'leaky' entries hold the fused op's NHWC output, 'l1' entries hold sign(a - b)."""
+
+    def __enter__(self):
+        from de_i2i_gan_amd import _lib as L
+        from de_i2i_gan_amd import ops
+        self.tape, self._patched = [], []
+        kind_of = {L.ACT_RELU: "relu", L.ACT_LRELU: "leaky"}
+
+        def conv(a, out):                # (x, weight, bias, cache, sources, geom, act); the SPADE label-path ReLU is exact
+            return (kind_of[a[6]], out) if a[6] == L.ACT_LRELU else None
+
+        def bn(a, out):                  # (..., act)
+            return (kind_of[a[-1]], out) if a[-1] != L.ACT_NONE else None
+
+        def spade(a, out):
+            return ("relu", out)
+
+        def l1(a, out):                  # (a, b); b None = zeros (sigmoid output: no sign change possible)
+            return ("l1", torch.sign(a[0].detach().float() - a[1].detach().float())) if a[1] is not None else None
+
+        for cls, pick in ((ops._Conv2d, conv), (ops._BatchNormAct, bn), (ops._SpadeRelu, spade), (ops._L1, l1)):
+            orig = cls.apply
+
+            def apply(*a, _orig=orig, _pick=pick):
+                out = _orig(*a)
+                if out.requires_grad:
+                    r = _pick(a, out)
+                    if r is not None:
+                        self.tape.append((r[0], r[1].detach().double().cpu()))
+                return out
+            cls.apply = apply
+            self._patched.append(cls)
+        return self.tape
+
+    def __exit__(self, *exc):
+        for cls in self._patched:
+            del cls.apply                # fall back to torch.autograd.Function.apply
+        return False

@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import formula_fill, load_golden, make_opt
+from helpers import record_kinks, formula_fill, load_golden, make_opt
 from oracle import defectgan_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -86,23 +86,38 @@ def test_forward_matches_reference_goldens(name, pname):
 ])
 def test_step_gradients_match_oracle_fp64(name, c):
     """Every live parameter gradient of the D loss graph and of the G loss graph (4 chained G passes + 2 D passes),
-    f32 HIP path vs the oracle evaluated in fp64 on the same weights."""
+    f32 HIP path vs the oracle evaluated in fp64 on the same weights and the same piecewise-linear branches: the
+    branch the HIP path took at every ReLU / LeakyReLU / |a-b| is recorded and replayed by the oracle (KinkTape), and
+    the elements where that differs from the oracle's own branch must all sit within fp32 noise of the kink."""
     cfg = O.Cfg(image_size=c["image_size"], ngf=c["ngf"], ndf=c["ndf"], num_layers=c["num_layers"], hidden_nc=c["hidden_nc"])
     bg, labels, df = O.synthetic_batch(c["batch"], c["image_size"])
     SG = {k: (v.double() if v.is_floating_point() else v) for k, v in O.make_state(O.generator_state_shapes(cfg)).items()}
     SD = {k: v.double() for k, v in O.make_state(O.discriminator_state_shapes(cfg)).items()}
-    g_losses, gG = O.train_generator_once({k: v.clone() for k, v in SG.items()}, SD, None, bg.double(), labels.double(),
-                                          df.double(), cfg)
-    d_gan, d_clf, gD = O.train_discriminator_once(SG, SD, None, bg.double(), labels.double(), df.double(), cfg)
     tr = build(c, "f32")
     G, D = tr.model.netG, tr.model.netD
-    gan, clf = tr.model("discriminator", bg, labels, df)
+    with record_kinks() as d_tape:
+        gan, clf = tr.model("discriminator", bg, labels, df)
     (gan + 2 * clf).backward()
+    with record_kinks() as g_tape:
+        ls = tr.model("generator", bg, labels, df)
+    (ls[0] + 5 * ls[1] + 5 * ls[2] + 5 * ls[3] + ls[4]).backward()
+
+    def oracle(fn, decisions, *a):
+        O.KINK_TAPE = tape = O.KinkTape(decisions)
+        try:
+            out = fn(*a)
+        finally:
+            O.KINK_TAPE = None
+        assert tape.exhausted() and tape.sites == len(decisions)
+        assert tape.worst < 2e-3, (tape.flips, tape.worst)      # replayed branches differ only within noise of a kink
+        return out
+
+    d_gan, d_clf, gD = oracle(O.train_discriminator_once, d_tape, SG, SD, None, bg.double(), labels.double(), df.double(), cfg)
+    g_losses, gG = oracle(O.train_generator_once, g_tape, {k: v.clone() for k, v in SG.items()},
+                          {k: v.detach() for k, v in SD.items()}, None, bg.double(), labels.double(), df.double(), cfg)
     assert abs(float(gan) - float(d_gan)) < 1e-5 and abs(float(clf) - float(d_clf)) < 1e-5
     for k, p in D.named_parameters():
         assert ((p.grad.double().cpu() - gD[k]).norm() / gD[k].norm()).item() < 1e-4, k
-    ls = tr.model("generator", bg, labels, df)
-    (ls[0] + 5 * ls[1] + 5 * ls[2] + 5 * ls[3] + ls[4]).backward()
     for a, b in zip(ls, g_losses):
         assert abs(float(a) - float(b)) < 1e-5
     scale = max(float(v.norm()) for v in gG.values() if v is not None)
@@ -114,7 +129,7 @@ def test_step_gradients_match_oracle_fp64(name, c):
         if float(ref.norm()) < 1e-7 * scale:              # gradients that are zero by construction (bias before IN)
             assert float(p.grad.double().norm()) < 1e-4 * scale, k
             continue
-        assert ((p.grad.double().cpu() - ref).norm() / ref.norm()).item() < 2e-3, k
+        assert ((p.grad.double().cpu() - ref).norm() / ref.norm()).item() < 1e-3, k
 
 
 @pytest.mark.parametrize("pname", ["f32", "bf16"])

@@ -89,3 +89,52 @@ def test_two_steps_match_reference_t0():
     for k in meta["G_keys"]:
         if "running_" in k:
             assert close(SG[k], arr["bn::" + k], 5e-2)
+
+
+def test_kink_tape_replay_makes_fp32_and_fp64_gradients_agree():
+    """The branch tape (oracle.KinkTape): record the fp32 oracle run's branch at every ReLU / LeakyReLU / |a-b| on the
+    gradient path in the HIP recorder's format, replay it in fp64 -> the G-step gradients agree to ~1e-4, where the
+    free-running fp64 gradients differ by percents whenever an element sits within rounding noise of a kink."""
+    import torch
+    cfg = O.Cfg(image_size=16, ngf=8, ndf=8, num_layers=1, hidden_nc=8)
+    bg, labels, df = O.synthetic_batch(1, 16)
+    SG32, SD32 = O.make_state(O.generator_state_shapes(cfg)), O.make_state(O.discriminator_state_shapes(cfg))
+    tape = []
+    saved = O.relu, O.leaky_relu, O.l1
+
+    def relu(x):
+        y = torch.relu(x)
+        if x.requires_grad:                                         # NHWC, channels zero-padded like the HIP layout
+            tape.append(("relu", torch.nn.functional.pad(y.detach().permute(0, 2, 3, 1), (0, 3)).double()))
+        return y
+
+    def leaky(x):
+        y = torch.where(x >= 0, x, 0.2 * x)
+        if x.requires_grad:
+            tape.append(("leaky", y.detach().permute(0, 2, 3, 1).double()))
+        return y
+
+    def l1(a, b, kink=True):
+        d = a - b
+        if kink and d.requires_grad:
+            tape.append(("l1", torch.sign(d.detach()).double()))
+        return d.abs().mean()
+
+    O.relu, O.leaky_relu, O.l1 = relu, leaky, l1
+    try:
+        _, g32 = O.train_generator_once({k: v.clone() for k, v in SG32.items()}, SD32, None, bg, labels, df, cfg)
+    finally:
+        O.relu, O.leaky_relu, O.l1 = saved
+    SG = {k: (v.double() if v.is_floating_point() else v) for k, v in SG32.items()}
+    SD = {k: v.double() for k, v in SD32.items()}
+    O.KINK_TAPE = t = O.KinkTape(tape)
+    try:
+        _, g64 = O.train_generator_once({k: v.clone() for k, v in SG.items()}, SD, None, bg.double(), labels.double(),
+                                        df.double(), cfg)
+    finally:
+        O.KINK_TAPE = None
+    assert t.exhausted() and t.sites == len(tape) == 64
+    assert t.worst < 1e-4                                           # any replayed flip sits on the kink
+    worst = max(((g32[k].double() - g64[k]).norm() / g64[k].norm()).item() for k in g64
+                if g64[k] is not None and g64[k].norm() > 1e-6)
+    assert worst < 2e-3, worst
