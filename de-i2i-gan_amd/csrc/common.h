@@ -106,6 +106,15 @@ DEI2I_D float act_grad_from_out(float z, int act) {
   return 1.f;
 }
 
+// VEC consecutive fp32 coefficients (16-byte aligned) -> registers through 16-byte loads
+template <int VEC> DEI2I_D void ldcoef(const float* __restrict__ p, float (&v)[VEC]) {
+#pragma unroll
+  for (int q = 0; q < VEC / 4; ++q) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p + 4 * q);
+    v[4 * q + 0] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+  }
+}
+
 DEI2I_D float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

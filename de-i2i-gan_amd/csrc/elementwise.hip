@@ -104,10 +104,12 @@ __global__ void spade_act_kernel(const T* __restrict__ x, const float* __restric
     else gpix = ((size_t)n * 5 + border_class(h, H)) * 5 + border_class(w, W);
     Elem<T>::unpack(*reinterpret_cast<const u32x4*>(gb + gpix * 2 * C + c), gm);
     Elem<T>::unpack(*reinterpret_cast<const u32x4*>(gb + gpix * 2 * C + C + c), bt);
-    float o[VEC];
+    float o[VEC], mv[VEC], rv[VEC];
+    ldcoef<VEC>(mean + (size_t)n * C + c, mv);
+    ldcoef<VEC>(rstd + (size_t)n * C + c, rv);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      const float xh = (xv[e] - mean[n * C + c + e]) * rstd[n * C + c + e];
+      const float xh = (xv[e] - mv[e]) * rv[e];
       const float v = fmaf(xh, 1.f + gm[e], bt[e]);
       o[e] = v > 0.f ? v : 0.f;
     }

@@ -56,12 +56,22 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const T* __restric
 #pragma unroll
   for (int e = 0; e < VEC; ++e) v[0][e] = v[1][e] = 0.f;
   if (prow < rpp) {
-    for (int r = rbeg + prow; r < rend; r += rpp) {
+    const T* __restrict__ base = x + (size_t)n * HW * C + (size_t)vcol * VEC;
+    auto acc = [&](const u32x4& q) {
       float f[VEC];
-      Elem<T>::unpack(*reinterpret_cast<const u32x4*>(x + ((size_t)n * HW + r) * C + (size_t)vcol * VEC), f);
+      Elem<T>::unpack(q, f);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) { v[0][e] += f[e]; v[1][e] = fmaf(f[e], f[e], v[1][e]); }
+    };
+    int r = rbeg + prow;
+    for (; r + 3 * rpp < rend; r += 4 * rpp) {       // four 16-byte loads in flight per thread
+      const u32x4 q0 = *reinterpret_cast<const u32x4*>(base + (size_t)r * C);
+      const u32x4 q1 = *reinterpret_cast<const u32x4*>(base + (size_t)(r + rpp) * C);
+      const u32x4 q2 = *reinterpret_cast<const u32x4*>(base + (size_t)(r + 2 * rpp) * C);
+      const u32x4 q3 = *reinterpret_cast<const u32x4*>(base + (size_t)(r + 3 * rpp) * C);
+      acc(q0); acc(q1); acc(q2); acc(q3);
     }
+    for (; r < rend; r += rpp) acc(*reinterpret_cast<const u32x4*>(base + (size_t)r * C));
   }
   block_combine<2, VEC>(v, cv, rpp, smem);
   if (prow == 0 && prow < rpp) {
@@ -71,29 +81,51 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const T* __restric
   }
 }
 
+// Cross-workgroup combine of the partial records, in fp64 (deterministic, no atomics).  One workgroup per channel
+// (64 or 256 threads, by record count): the threads stride over the records -- C * blockDim independent 4-byte loads
+// keep the (L2-resident, <= 2 MB) partial buffer's latency covered even for narrow layers -- then meet through
+// wave shuffles and LDS.  record r, quantity q, channel c lives at partial[(r * NQ + q) * C + c].
+// Result valid in thread 0.
 DEI2I_D double wave_sum_f64(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
 
-// one 64-lane wave per channel: lanes stride over the N*chunks partial records, fp64 combine
-__global__ __launch_bounds__(64) void bn_finalize_train_kernel(const float* __restrict__ partial, int N, int chunks, int C, double count,
+template <int NQ>
+DEI2I_D void combine_records(const float* __restrict__ partial, size_t rec0, int nrec, int C, int c, double (&s)[NQ]) {
+  __shared__ double red[NQ][4];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) s[q] = 0.0;
+  for (int r = threadIdx.x; r < nrec; r += blockDim.x)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) s[q] += (double)partial[((rec0 + r) * NQ + q) * C + c];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) s[q] = wave_sum_f64(s[q]);
+  if (blockDim.x > 64) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) red[q][wave] = s[q];
+    __syncthreads();
+    if (threadIdx.x == 0)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) s[q] = red[q][0] + red[q][1] + red[q][2] + red[q][3];
+  }
+}
+static inline int combine_threads(int nrec) { return nrec > 256 ? 256 : 64; }
+
+__global__ __launch_bounds__(256) void bn_finalize_train_kernel(const float* __restrict__ partial, int N, int chunks, int C, double count,
                                          const float* __restrict__ weight, const float* __restrict__ bias,
                                          float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
                                          float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ a,
                                          float* __restrict__ b) {
   const int c = blockIdx.x;
-  double s = 0.0, ss = 0.0;
-  for (int i = threadIdx.x; i < N * chunks; i += 64) {
-    s += (double)partial[(size_t)i * 2 * C + c];
-    ss += (double)partial[(size_t)i * 2 * C + C + c];
-  }
-  s = wave_sum_f64(s);
-  ss = wave_sum_f64(ss);
+  double sq[2];
+  combine_records<2>(partial, 0, N * chunks, C, c, sq);
   if (threadIdx.x != 0) return;
-  const double mu = s / count;
-  double var = ss / count - mu * mu;
+  const double mu = sq[0] / count;
+  double var = sq[1] / count - mu * mu;
   if (var < 0.0) var = 0.0;
   const float rs = (float)(1.0 / sqrt(var + (double)eps));
   mean[c] = (float)mu;
@@ -118,21 +150,17 @@ __global__ void bn_finalize_eval_kernel(int C, const float* __restrict__ weight,
   b[c] = bias[c] - rmean[c] * av;
 }
 
-__global__ void in_finalize_kernel(const float* __restrict__ partial, int N, int chunks, int C, double count, float eps,
-                                   float* __restrict__ mean, float* __restrict__ rstd) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N * C) return;
-  const int n = i / C, c = i % C;
-  double s = 0.0, ss = 0.0;
-  for (int k = 0; k < chunks; ++k) {
-    s += (double)partial[((size_t)n * chunks + k) * 2 * C + c];
-    ss += (double)partial[((size_t)n * chunks + k) * 2 * C + C + c];
-  }
-  const double mu = s / count;
-  double var = ss / count - mu * mu;
+__global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restrict__ partial, int N, int chunks, int C, double count,
+                                                          float eps, float* __restrict__ mean, float* __restrict__ rstd) {
+  const int c = blockIdx.x, n = blockIdx.y;
+  double sq[2];
+  combine_records<2>(partial, (size_t)n * chunks, chunks, C, c, sq);
+  if (threadIdx.x != 0) return;
+  const double mu = sq[0] / count;
+  double var = sq[1] / count - mu * mu;
   if (var < 0.0) var = 0.0;
-  mean[i] = (float)mu;
-  rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+  mean[(size_t)n * C + c] = (float)mu;
+  rstd[(size_t)n * C + c] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
 // ---- BatchNorm backward ----
@@ -156,15 +184,12 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
   for (int e = 0; e < VEC; ++e) v[0][e] = v[1][e] = 0.f;
   if (prow < rpp) {
     float av[VEC], bv[VEC], mv[VEC], rv[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      const int c = vcol * VEC + e;
-      av[e] = a[c]; bv[e] = b[c]; mv[e] = mean[c]; rv[e] = rstd[c];
-    }
-    for (size_t r = rbeg + prow; r < rend; r += rpp) {
+    const int c = vcol * VEC;
+    ldcoef<VEC>(a + c, av); ldcoef<VEC>(b + c, bv); ldcoef<VEC>(mean + c, mv); ldcoef<VEC>(rstd + c, rv);
+    auto acc = [&](const u32x4& dq, const u32x4& yq) {
       float d[VEC], yy[VEC];
-      Elem<T>::unpack(*reinterpret_cast<const u32x4*>(dz + r * C + (size_t)vcol * VEC), d);
-      Elem<T>::unpack(*reinterpret_cast<const u32x4*>(y + r * C + (size_t)vcol * VEC), yy);
+      Elem<T>::unpack(dq, d);
+      Elem<T>::unpack(yq, yy);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         const float z = fmaf(av[e], yy[e], bv[e]);
@@ -172,7 +197,18 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
         v[0][e] += g;
         v[1][e] = fmaf(g, (yy[e] - mv[e]) * rv[e], v[1][e]);
       }
+    };
+    const T* __restrict__ dzb = dz + c;
+    const T* __restrict__ yb = y + c;
+    size_t r = rbeg + prow;
+    for (; r + rpp < rend; r += 2 * (size_t)rpp) {      // four 16-byte loads in flight per thread
+      const u32x4 d0 = *reinterpret_cast<const u32x4*>(dzb + r * C);
+      const u32x4 y0 = *reinterpret_cast<const u32x4*>(yb + r * C);
+      const u32x4 d1 = *reinterpret_cast<const u32x4*>(dzb + (r + rpp) * C);
+      const u32x4 y1 = *reinterpret_cast<const u32x4*>(yb + (r + rpp) * C);
+      acc(d0, y0); acc(d1, y1);
     }
+    if (r < rend) acc(*reinterpret_cast<const u32x4*>(dzb + r * C), *reinterpret_cast<const u32x4*>(yb + r * C));
   }
   block_combine<2, VEC>(v, cv, rpp, smem);
   if (prow == 0 && prow < rpp) {
@@ -182,54 +218,72 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
   }
 }
 
-__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int C,
-                                                             float* __restrict__ dweight, float* __restrict__ dbias) {
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int C,
+                                                              float* __restrict__ dweight, float* __restrict__ dbias) {
   const int c = blockIdx.x;
-  double s1 = 0.0, s2 = 0.0;
-  for (int k = threadIdx.x; k < chunks; k += 64) {
-    s1 += (double)partial[(size_t)k * 2 * C + c];
-    s2 += (double)partial[(size_t)k * 2 * C + C + c];
-  }
-  s1 = wave_sum_f64(s1);
-  s2 = wave_sum_f64(s2);
-  if (threadIdx.x == 0) {
-    dbias[c] = (float)s1;
-    dweight[c] = (float)s2;
-  }
+  double sq[2];
+  combine_records<2>(partial, 0, chunks, C, c, sq);
+  if (threadIdx.x != 0) return;
+  dbias[c] = (float)sq[0];
+  dweight[c] = (float)sq[1];
 }
 
+// dy = a*(g - sum_g/M - xhat*sum_gx/M) with g = dz*act'(a*y+b), xhat = (y-mean)*rstd, folded per channel into
+//   dy = a*g + c2*(y - mean) + c3,   c2 = -a*rstd*sum_gx/M,  c3 = -a*sum_g/M        (eval mode: c2 = c3 = 0)
 template <typename T, bool INVARIANT>
-__global__ void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ y, const float* __restrict__ a,
-                                    const float* __restrict__ b, const float* __restrict__ mean,
-                                    const float* __restrict__ rstd, int act, int train, const float* __restrict__ dweight,
-                                    const float* __restrict__ dbias, float inv_count, T* __restrict__ dy, size_t nvec,
-                                    int cv) {
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ y,
+                                                           const float* __restrict__ a, const float* __restrict__ b,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           int act, int train, const float* __restrict__ dweight,
+                                                           const float* __restrict__ dbias, float inv_count,
+                                                           T* __restrict__ dy, size_t nvec, int cv) {
   constexpr int VEC = Elem<T>::VEC;
-  float av[VEC], bv[VEC], mv[VEC], rv[VEC], k1[VEC], k2[VEC];
+  float av[VEC], bv[VEC], mv[VEC], c2[VEC], c3[VEC];
   auto load_coef = [&](int c) {
+    float rv[VEC], dw[VEC], db[VEC];
+    ldcoef<VEC>(a + c, av); ldcoef<VEC>(b + c, bv); ldcoef<VEC>(mean + c, mv);
+    if (train) {
+      ldcoef<VEC>(rstd + c, rv); ldcoef<VEC>(dweight + c, dw); ldcoef<VEC>(dbias + c, db);
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      av[e] = a[c + e]; bv[e] = b[c + e]; mv[e] = mean[c + e]; rv[e] = rstd[c + e];
-      k1[e] = train ? dbias[c + e] * inv_count : 0.f;
-      k2[e] = train ? dweight[c + e] * inv_count : 0.f;
+      for (int e = 0; e < VEC; ++e) { c2[e] = -av[e] * rv[e] * (dw[e] * inv_count); c3[e] = -av[e] * (db[e] * inv_count); }
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) c2[e] = c3[e] = 0.f;
     }
   };
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (INVARIANT) load_coef((int)(i % cv) * VEC);
-  for (; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
-    if (!INVARIANT) load_coef((int)(i % cv) * VEC);
+  auto apply = [&](const u32x4& dq, const u32x4& yq) {
     float d[VEC], yy[VEC];
-    Elem<T>::unpack(*reinterpret_cast<const u32x4*>(dz + i * VEC), d);
-    Elem<T>::unpack(*reinterpret_cast<const u32x4*>(y + i * VEC), yy);
+    Elem<T>::unpack(dq, d);
+    Elem<T>::unpack(yq, yy);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       const float z = fmaf(av[e], yy[e], bv[e]);
-      float g = d[e] * act_grad_from_out(z, act);
-      const float xh = (yy[e] - mv[e]) * rv[e];
-      g = g - k1[e] - xh * k2[e];
-      d[e] = av[e] * g;
+      const float g = d[e] * act_grad_from_out(z, act);
+      d[e] = fmaf(av[e], g, fmaf(c2[e], yy[e] - mv[e], c3[e]));
     }
-    *reinterpret_cast<u32x4*>(dy + i * VEC) = Elem<T>::pack(d);
+    return Elem<T>::pack(d);
+  };
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (INVARIANT) {                       // stride % cv == 0: the thread keeps its channel vector
+    load_coef((int)(i % cv) * VEC);
+    for (; i + stride < nvec; i += 2 * stride) {       // four 16-byte loads in flight per thread
+      const u32x4 d0 = *reinterpret_cast<const u32x4*>(dz + i * VEC);
+      const u32x4 y0 = *reinterpret_cast<const u32x4*>(y + i * VEC);
+      const u32x4 d1 = *reinterpret_cast<const u32x4*>(dz + (i + stride) * VEC);
+      const u32x4 y1 = *reinterpret_cast<const u32x4*>(y + (i + stride) * VEC);
+      *reinterpret_cast<u32x4*>(dy + i * VEC) = apply(d0, y0);
+      *reinterpret_cast<u32x4*>(dy + (i + stride) * VEC) = apply(d1, y1);
+    }
+    if (i < nvec)
+      *reinterpret_cast<u32x4*>(dy + i * VEC) = apply(*reinterpret_cast<const u32x4*>(dz + i * VEC),
+                                                      *reinterpret_cast<const u32x4*>(y + i * VEC));
+  } else {
+    for (; i < nvec; i += stride) {
+      load_coef((int)(i % cv) * VEC);
+      *reinterpret_cast<u32x4*>(dy + i * VEC) = apply(*reinterpret_cast<const u32x4*>(dz + i * VEC),
+                                                      *reinterpret_cast<const u32x4*>(y + i * VEC));
+    }
   }
 }
 
@@ -261,25 +315,29 @@ __global__ __launch_bounds__(256) void spade_bwd_partial_kernel(const T* __restr
   if (prow < rpp) {
     const int c = vcol * VEC;
     float mv[VEC], rv[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) { mv[e] = mean[n * C + c + e]; rv[e] = rstd[n * C + c + e]; }
-    for (int r = rbeg + prow; r < rend; r += rpp) {
+    ldcoef<VEC>(mean + (size_t)n * C + c, mv);
+    ldcoef<VEC>(rstd + (size_t)n * C + c, rv);
+    struct Row { u32x4 d, z, x, gm; size_t opix; bool interior; };
+    auto load = [&](int r) {
+      Row q;
       const int h = r / W, w = r - h * W;
-      const size_t opix = (size_t)n * HW + r;
-      float d[VEC], zz[VEC], xv[VEC], gm[VEC];
-      Elem<T>::unpack(*reinterpret_cast<const u32x4*>(dz + opix * C + c), d);
-      Elem<T>::unpack(*reinterpret_cast<const u32x4*>(z + opix * C + c), zz);
-      Elem<T>::unpack(*reinterpret_cast<const u32x4*>(x + (((size_t)n * Hs + (h >> up)) * Ws + (w >> up)) * C + c), xv);
-      size_t gpix;
-      int cy = 2, cx = 2;
-      if (gb_mode == 0) {
-        gpix = opix;
-      } else {
-        cy = border_class(h, H); cx = border_class(w, W);
+      q.opix = (size_t)n * HW + r;
+      q.d = *reinterpret_cast<const u32x4*>(dz + q.opix * C + c);
+      q.z = *reinterpret_cast<const u32x4*>(z + q.opix * C + c);
+      q.x = *reinterpret_cast<const u32x4*>(x + (((size_t)n * Hs + (h >> up)) * Ws + (w >> up)) * C + c);
+      size_t gpix = q.opix;
+      q.interior = true;
+      if (gb_mode != 0) {
+        const int cy = border_class(h, H), cx = border_class(w, W);
         gpix = ((size_t)n * 5 + cy) * 5 + cx;
+        q.interior = cy == 2 && cx == 2;
       }
-      Elem<T>::unpack(*reinterpret_cast<const u32x4*>(gb + gpix * 2 * C + c), gm);
-      float dg[VEC], db[VEC], dxh[VEC];
+      q.gm = *reinterpret_cast<const u32x4*>(gb + gpix * 2 * C + c);
+      return q;
+    };
+    auto use = [&](const Row& q) {
+      float d[VEC], zz[VEC], xv[VEC], gm[VEC], dg[VEC], db[VEC], dxh[VEC];
+      Elem<T>::unpack(q.d, d); Elem<T>::unpack(q.z, zz); Elem<T>::unpack(q.x, xv); Elem<T>::unpack(q.gm, gm);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         const float g = zz[e] > 0.f ? d[e] : 0.f;
@@ -290,15 +348,21 @@ __global__ __launch_bounds__(256) void spade_bwd_partial_kernel(const T* __restr
         v[0][e] += dxh[e];
         v[1][e] = fmaf(dxh[e], xh, v[1][e]);
       }
-      *reinterpret_cast<u32x4*>(dxhat + opix * C + c) = Elem<T>::pack(dxh);
+      *reinterpret_cast<u32x4*>(dxhat + q.opix * C + c) = Elem<T>::pack(dxh);
       if (gb_mode == 0) {
-        *reinterpret_cast<u32x4*>(dgb_dense + opix * 2 * C + c) = Elem<T>::pack(dg);
-        *reinterpret_cast<u32x4*>(dgb_dense + opix * 2 * C + C + c) = Elem<T>::pack(db);
-      } else if (cy == 2 && cx == 2) {
+        *reinterpret_cast<u32x4*>(dgb_dense + q.opix * 2 * C + c) = Elem<T>::pack(dg);
+        *reinterpret_cast<u32x4*>(dgb_dense + q.opix * 2 * C + C + c) = Elem<T>::pack(db);
+      } else if (q.interior) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) { v[2][e] += dg[e]; v[3][e] += db[e]; }
       }             // border classes are reduced by spade_bwd_border_kernel (no atomics)
+    };
+    int r = rbeg + prow;
+    for (; r + rpp < rend; r += 2 * rpp) {           // two rows (eight 16-byte loads) in flight per thread
+      const Row q0 = load(r), q1 = load(r + rpp);
+      use(q0); use(q1);
     }
+    if (r < rend) use(load(r));
   }
   block_combine<4, VEC>(v, cv, rpp, smem);
   if (prow == 0 && prow < rpp) {
@@ -335,8 +399,8 @@ __global__ __launch_bounds__(256) void spade_bwd_border_kernel(const T* __restri
   if (prow < rpp) {
     const int c = vcol * VEC;
     float mv[VEC], rv[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) { mv[e] = mean[n * C + c + e]; rv[e] = rstd[n * C + c + e]; }
+    ldcoef<VEC>(mean + (size_t)n * C + c, mv);
+    ldcoef<VEC>(rstd + (size_t)n * C + c, rv);
     for (int i = prow; i < count; i += rpp) {
       const int h = y0 + i / nx, w = x0 + i % nx;
       const size_t opix = ((size_t)n * H + h) * W + w;
@@ -361,20 +425,19 @@ __global__ __launch_bounds__(256) void spade_bwd_border_kernel(const T* __restri
 }
 
 // coef[(n*2 + {0,1})*C + c] = s1/M, s2/M ; interior-class gamma/beta sums added into dgb_cls[n,2,2,:]
-__global__ void spade_bwd_finalize_kernel(const float* __restrict__ partial, int N, int chunks, int C, double count,
-                                          float* __restrict__ coef, float* __restrict__ dgb_cls) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N * C) return;
-  const int n = i / C, c = i % C;
-  double s[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int k = 0; k < chunks; ++k)
-    for (int q = 0; q < 4; ++q) s[q] += (double)partial[(((size_t)n * chunks + k) * 4 + q) * C + c];
-  coef[((size_t)n * 2 + 0) * C + c] = (float)(s[0] / count);
-  coef[((size_t)n * 2 + 1) * C + c] = (float)(s[1] / count);
+__global__ __launch_bounds__(256) void spade_bwd_finalize_kernel(const float* __restrict__ partial, int N, int chunks, int C,
+                                                                 double count, float* __restrict__ coef,
+                                                                 float* __restrict__ dgb_cls) {
+  const int c = blockIdx.x, n = blockIdx.y;
+  double sq[4];
+  combine_records<4>(partial, (size_t)n * chunks, chunks, C, c, sq);
+  if (threadIdx.x != 0) return;
+  coef[((size_t)n * 2 + 0) * C + c] = (float)(sq[0] / count);
+  coef[((size_t)n * 2 + 1) * C + c] = (float)(sq[1] / count);
   if (dgb_cls != nullptr) {
     const size_t gpix = ((size_t)n * 5 + 2) * 5 + 2;
-    dgb_cls[gpix * 2 * C + c] += (float)s[2];
-    dgb_cls[gpix * 2 * C + C + c] += (float)s[3];
+    dgb_cls[gpix * 2 * C + c] += (float)sq[2];
+    dgb_cls[gpix * 2 * C + C + c] += (float)sq[3];
   }
 }
 
@@ -408,11 +471,15 @@ __global__ void spade_bwd_apply_kernel(const T* __restrict__ dxhat, const T* __r
     Elem<T>::unpack(*reinterpret_cast<const u32x4*>(x + i * VEC), xv);
     float ad[VEC];
     if (addend != nullptr) Elem<T>::unpack(*reinterpret_cast<const u32x4*>(addend + i * VEC), ad);
+    float mv[VEC], rv[VEC], k1[VEC], k2[VEC];
+    ldcoef<VEC>(mean + (size_t)n * C + c, mv);
+    ldcoef<VEC>(rstd + (size_t)n * C + c, rv);
+    ldcoef<VEC>(coef + ((size_t)n * 2) * C + c, k1);
+    ldcoef<VEC>(coef + ((size_t)n * 2 + 1) * C + c, k2);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      const float rs = rstd[n * C + c + e];
-      const float xh = (xv[e] - mean[n * C + c + e]) * rs;
-      float v = rs * (acc[e] - cnt * coef[((size_t)n * 2) * C + c + e] - cnt * xh * coef[((size_t)n * 2 + 1) * C + c + e]);
+      const float xh = (xv[e] - mv[e]) * rv[e];
+      float v = rv[e] * (acc[e] - cnt * k1[e] - cnt * xh * k2[e]);
       if (addend != nullptr) v += ad[e];
       acc[e] = v;
     }
@@ -434,12 +501,22 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, fl
 #pragma unroll
   for (int e = 0; e < VEC; ++e) v[0][e] = 0.f;
   if (prow < rpp) {
-    for (size_t r = rbeg + prow; r < rend; r += rpp) {
+    const T* __restrict__ base = g + (size_t)vcol * VEC;
+    auto acc = [&](const u32x4& q) {
       float f[VEC];
-      Elem<T>::unpack(*reinterpret_cast<const u32x4*>(g + r * C + (size_t)vcol * VEC), f);
+      Elem<T>::unpack(q, f);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) v[0][e] += f[e];
+    };
+    size_t r = rbeg + prow;
+    for (; r + 3 * (size_t)rpp < rend; r += 4 * (size_t)rpp) {
+      const u32x4 q0 = *reinterpret_cast<const u32x4*>(base + r * C);
+      const u32x4 q1 = *reinterpret_cast<const u32x4*>(base + (r + rpp) * C);
+      const u32x4 q2 = *reinterpret_cast<const u32x4*>(base + (r + 2 * (size_t)rpp) * C);
+      const u32x4 q3 = *reinterpret_cast<const u32x4*>(base + (r + 3 * (size_t)rpp) * C);
+      acc(q0); acc(q1); acc(q2); acc(q3);
     }
+    for (; r < rend; r += rpp) acc(*reinterpret_cast<const u32x4*>(base + r * C));
   }
   block_combine<1, VEC>(v, cv, rpp, smem);
   if (prow == 0 && prow < rpp) {
@@ -512,10 +589,10 @@ static inline size_t combine_lds(int dtype, int nv) { return (size_t)nv * (dtype
 
 extern "C" {
 
-int dei2i_moments_chunks(int HW) {
-  int c = HW / 512;
+int dei2i_moments_chunks(int HW) {            // per image: >= 64 rows per workgroup, up to 256 workgroups
+  int c = HW / 64;
   if (c < 1) c = 1;
-  if (c > 128) c = 128;
+  if (c > 256) c = 256;
   return c;
 }
 
@@ -535,7 +612,7 @@ int dei2i_bn_finalize_train(int N, int HW, int C, const float* partial, const fl
                             float* running_mean, float* running_var, float momentum, float eps, float* mean, float* rstd,
                             float* a, float* b, dei2i_stream s) {
   if (N <= 0 || HW <= 0 || C <= 0 || !partial || !weight || !bias || !mean || !rstd || !a || !b) return DEI2I_ERR_BAD_ARG;
-  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(C), dim3(64), 0, (hipStream_t)s, partial, N,
+  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(C), dim3(combine_threads(N * dei2i_moments_chunks(HW))), 0, (hipStream_t)s, partial, N,
                      dei2i_moments_chunks(HW), C, (double)N * (double)HW, weight, bias, running_mean, running_var, momentum,
                      eps, mean, rstd, a, b);
   return (int)hipGetLastError();
@@ -551,7 +628,7 @@ int dei2i_bn_finalize_eval(int C, const float* weight, const float* bias, const 
 
 int dei2i_in_finalize(int N, int HW, int C, const float* partial, float eps, float* mean, float* rstd, dei2i_stream s) {
   if (N <= 0 || HW <= 0 || C <= 0 || !partial || !mean || !rstd) return DEI2I_ERR_BAD_ARG;
-  hipLaunchKernelGGL(in_finalize_kernel, dim3((N * C + 63) / 64), dim3(64), 0, (hipStream_t)s, partial, N,
+  hipLaunchKernelGGL(in_finalize_kernel, dim3(C, N), dim3(combine_threads(dei2i_moments_chunks(HW))), 0, (hipStream_t)s, partial, N,
                      dei2i_moments_chunks(HW), C, (double)HW, eps, mean, rstd);
   return (int)hipGetLastError();
 }
@@ -561,9 +638,9 @@ int dei2i_colsum(int dtype, size_t rows, int C, const void* g, float* out, dei2i
   hipStream_t st = (hipStream_t)s;
   hipError_t e = hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st);
   if (e != hipSuccess) return (int)e;
-  size_t blocks = rows / 256;
+  size_t blocks = rows / 256;       // every workgroup ends in C same-address atomics: keep the count low, the loads deep
   if (blocks < 1) blocks = 1;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 256) blocks = 256;
   if (dtype == DT_BF16)
     hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), combine_lds(dtype, 1), st, (const bf16_t*)g, out, rows, C);
   else
@@ -571,10 +648,10 @@ int dei2i_colsum(int dtype, size_t rows, int C, const void* g, float* out, dei2i
   return (int)hipGetLastError();
 }
 
-int dei2i_bn_bwd_chunks(size_t pixels) {
-  size_t c = pixels / 512;
+int dei2i_bn_bwd_chunks(size_t pixels) {      // one workgroup per chunk: >= 64 rows each, up to 8 workgroups per CU
+  size_t c = pixels / 64;
   if (c < 1) c = 1;
-  if (c > 512) c = 512;
+  if (c > 2048) c = 2048;
   return (int)c;
 }
 
@@ -598,9 +675,9 @@ int dei2i_bn_bwd_apply(int dtype, size_t pixels, int C, const void* dz, const vo
   if (pixels == 0 || !cv_ok(dtype, C) || !dz || !y || !a || !b || !mean || !rstd || !partial || !dweight || !dbias || !dy)
     return DEI2I_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)s;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, partial, chunks, C, dweight, dbias);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(combine_threads(chunks)), 0, st, partial, chunks, C, dweight, dbias);
   const size_t nvec = pixels * (size_t)(C / vec);
-  const unsigned grid = grid_for(nvec, 256, 256u * 16u);
+  const unsigned grid = grid_for((nvec + 1) / 2, 256, 256u * 8u);
   const float inv = 1.f / (float)pixels;
   const int cv = C / vec;
   const bool invc = (256 % cv) == 0;
@@ -656,7 +733,7 @@ int dei2i_spade_bwd_apply(int dtype, int N, int H, int W, int C, int up, const v
       !coef || !dx)
     return DEI2I_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)s;
-  hipLaunchKernelGGL(spade_bwd_finalize_kernel, dim3((N * C + 63) / 64), dim3(64), 0, st, partial, N, chunks, C,
+  hipLaunchKernelGGL(spade_bwd_finalize_kernel, dim3(C, N), dim3(combine_threads(chunks)), 0, st, partial, N, chunks, C,
                      (double)H * (double)W, coef, dgb_cls);
   const size_t total = (size_t)N * (H >> up) * (W >> up) * (C / vec);
   const unsigned grid = grid_for(total, 256, 256u * 16u);

@@ -12,7 +12,8 @@ DEV = "cuda:0"
 name = sys.argv[1] if len(sys.argv) > 1 else "tiny16"
 prec = "bf16" if "bf16" in sys.argv else "f32"
 c = dict(tiny16=dict(image_size=16, batch=1, num_layers=1, ngf=8, ndf=8, hidden_nc=8),
-         t0=dict(image_size=32, batch=2, num_layers=3, ngf=8, ndf=8, hidden_nc=16))[name]
+         t0=dict(image_size=32, batch=2, num_layers=3, ngf=8, ndf=8, hidden_nc=16),
+         t1=dict(image_size=64, batch=4, num_layers=4, ngf=16, ndf=16, hidden_nc=32))[name]
 trace = []
 def wrap(cls):
     fwd, bwd = cls.forward, cls.backward
@@ -56,5 +57,5 @@ for i, (x, y) in enumerate(zip(a, b)):
         if d > float(sys.argv[-1]):
             print("#%d %s %s out%d shape %s rel diff %.3e  |v| %.3e  %s" % (i, x[0], x[1], j, tuple(u.shape), d, float(v.norm()), x[3]))
             shown += 1
-    if shown >= 12:
+    if shown >= 40:
         break

@@ -3,7 +3,7 @@ fixtures captured from the reference (tests/golden/gen_goldens.py) and against t
 
 Tolerances
   f32 mode (exact-f32 MFMA)  -- forward <= 1e-3 of the tensor max (north_star's bound; measured ~5e-6), losses 1e-4,
-                                gradients vs the oracle in fp64 <= 2e-3 relative L2 per tensor (measured ~1e-4).
+                                gradients vs the oracle in fp64, same branches (KinkTape) <= 1e-3 relative L2 per tensor (measured ~1e-4).
   bf16 mode (bf16 MFMA, fp32 accumulate) -- bf16 rounds every stored activation to 2^-9.  On the formula-filled tiny
       nets of the goldens (He-gain weights, 8..16 channels) that noise is amplified by the normalisation layers:
       forward RMS error <= 0.12 (measured 4e-2..9e-2), step-1 losses 2e-2, step-2 losses 0.2.  With the reference's real init (N(0,0.02)) bf16 tracks the f32 path to
@@ -171,7 +171,14 @@ def test_two_train_steps_match_reference_goldens(name, pname):
     assert int(sdg["stem.conv_block.1.num_batches_tracked"]) == 8
     for k in meta["G_keys"]:
         if "running_" in k:
-            assert maxrel(sdg[k], arr["bn::" + k]) < (5e-2 if pname == "f32" else 0.35), k
+            if pname == "f32":
+                assert maxrel(sdg[k], arr["bn::" + k]) < 5e-2, k
+            elif k.startswith(("stem.", "enc_blk.")):
+                # bf16: the formula-filled nets are chaotic -- a one-ulp difference grows ~4x per res-block layer
+                # (tests/diag_first_use.py t1 bf16: 1e-4 -> 3e-2 over five layers, run to run) -- so the 2^-9 activation
+                # rounding swamps the deep res-block statistics; only the first three BatchNorms are comparable
+                # (measured <= 0.09).  test_bf16_tracks_f32_with_reference_init covers the realistic case.
+                assert maxrel(sdg[k], arr["bn::" + k]) < 0.2, k
     for k in ("enc_blk.0.conv_block.0.weight", "src_clf.conv_block.0.weight"):
         d = (sd[k].cpu() - torch.from_numpy(arr["Dp::" + k])).abs()
         assert d.max().item() <= 5 * cfg.lr          # sign-like early Adam steps (|update| <= ~1.1 lr each): see test_oracle_goldens.py
