@@ -44,6 +44,7 @@ SIGNATURES = {
     "dei2i_conv2d_workspace_bytes": (c_size_t, [_CD]),
     "dei2i_conv2d_fwd": (c_int, [_CD, _P, _P, _P, c_int, _P, _P, c_size_t, _P]),
     "dei2i_conv2d_dgrad": (c_int, [_CD, _P, _P, _P, _P, c_size_t, _P]),
+    "dei2i_conv2d_dgrad_input": (c_int, [_CD, _P, _P, _P, _P, _P, c_size_t, _P]),
     "dei2i_conv2d_wgrad": (c_int, [_CD, _P, _P, _P, _P]),
     "dei2i_conv2d_wgrad_oihw": (c_int, [_CD, _P, _P, _P, c_size_t, _P, _P]),
     "dei2i_fold_pad": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),

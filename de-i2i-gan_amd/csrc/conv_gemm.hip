@@ -117,6 +117,10 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const DescPack pack, c
   int cur_tap = -1;
   int a_pix[RA];
 
+  // Dead-tap skipping (reflect-ring launches: 2 of 3 tap rows / columns read outside dY for every row of a tile).
+  // Needs every thread of the workgroup on the same tap within a k-step: channel stride a multiple of the k-step.
+  const bool skip_dead = pack.skip_dead_taps != 0 && (g.Cs % BKE) == 0;
+  bool tap_live = true;          // liveness of the tap of the most recently loaded k-step (workgroup-uniform)
   auto load_tile = [&](int kstep) {
     const int k = kstep * BKE + kv * VEC;
     const bool kval = k < g.K;
@@ -127,14 +131,18 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const DescPack pack, c
       const int ty = (int)fd_div((uint32_t)tap, g.fd_tw);
       const int tx = tap - ty * g.tw;
       const int dy = ty * g.ys, dx = tx * g.xs;
+      int any = 0;
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
         const int y = bound_coord(a_by[i] + dy, g.Hl, g.pad_mode);
         const int x = bound_coord(a_bx[i] + dx, g.Wl, g.pad_mode);
         const int pix = (a_nb[i] * g.Hs + (y >> g.up)) * g.Ws + (x >> g.up);
         a_pix[i] = ((y | x | a_nb[i]) < 0) ? -1 : pix;
+        any |= a_pix[i] >= 0;
       }
+      if (skip_dead) tap_live = __syncthreads_or(any) != 0;
     }
+    if (!tap_live) return;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       areg[i] = (kval && a_pix[i] >= 0) ? ld16(src + (size_t)a_pix[i] * g.Cs + ci) : zero16();
@@ -201,19 +209,24 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const DescPack pack, c
 
   // ---- main loop: register-staged, double-buffered LDS, one barrier per k-step ----
   load_tile(kbeg);
-  store_tile(0);
+  bool live_cur = tap_live, any_live = false;
+  if (live_cur) store_tile(0);
   __syncthreads();
   int buf = 0;
   for (int ks = kbeg; ks < kend; ++ks) {
     const bool more = ks + 1 < kend;
     if (more) load_tile(ks + 1);          // global loads in flight under the MFMAs
-    compute_tile(buf);
-    if (more) store_tile(buf ^ 1);
+    const bool live_next = more && tap_live;
+    any_live |= live_cur;
+    if (live_cur) compute_tile(buf);
+    if (live_next) store_tile(buf ^ 1);
     __syncthreads();
     buf ^= 1;
+    live_cur = live_next;
   }
 
   // ---- epilogue: D[i][j], j = lane&31 (output channel), i = (e&3) + 8*(e>>2) + 4*(lane>>5) (pixel) ----
+  if (!any_live && ws != nullptr) return;       // a split-K slice of dead taps adds nothing
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -234,7 +247,8 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const DescPack pack, c
         if (n >= ldc) continue;
         float v = acc[i][j][e];
         if (ws != nullptr) {
-          if (n < wrows) atomicAdd(ws + opix * ldc + n, v);
+          const size_t wpix = pack.ws_compact ? (size_t)(pack.m_base[blockIdx.y] + m) : opix;
+          if (n < wrows) atomicAdd(ws + wpix * ldc + n, v);
         } else {
           if (n < wrows) {
             if (bias != nullptr) v += bias[n];
@@ -264,6 +278,32 @@ __global__ void splitk_finalize_kernel(const float* __restrict__ ws, const float
       v = apply_act(v, act);
     }
     Elem<T>::store(out + i, v);
+  }
+}
+
+// compact variant: ws row r belongs to class k (m_base[k] <= r < m_base[k+1]), local row m = r - m_base[k]; only the
+// output pixels the classes cover are written (the reflect ring of a dgrad frame)
+template <typename T>
+__global__ void splitk_finalize_compact_kernel(const DescPack pack, const float* __restrict__ ws, const float* __restrict__ bias,
+                                               T* __restrict__ out, size_t total, int ldc, int co, int act) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const int c = (int)(i % (size_t)ldc);
+    const int r = (int)(i / (size_t)ldc);
+    int k = 0;
+    while (k + 1 < pack.n && r >= pack.m_base[k + 1]) ++k;
+    const GatherDesc& g = pack.d[k];
+    int n, oy, ox;
+    decode_m(g, r - pack.m_base[k], n, oy, ox);
+    const size_t opix = (size_t)out_pixel(g, n, oy, ox);
+    float v = 0.f;
+    if (c < co) {
+      v = ws[i];
+      if (bias != nullptr) v += bias[c];
+      v = apply_act(v, act);
+    }
+    Elem<T>::store(out + opix * ldc + c, v);
   }
 }
 
@@ -475,6 +515,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GatherDesc g, const T*
 static int g_num_cu = 256;
 static int g_use_v2 = 1;
 void set_use_v2(int on) { g_use_v2 = on; }
+static int g_use_halo = 1;
+void set_use_halo(int on) { g_use_halo = on; }
 
 template <typename T, int BM, int BN, int WM, int WN>
 static hipError_t launch_gg(const DescPack& pack, const void* src, const void* wgt, int wrows, const float* bias,
@@ -488,6 +530,7 @@ static hipError_t launch_gg(const DescPack& pack, const void* src, const void* w
     Kmax = std::max(Kmax, g.K);
     flops += 2.0 * (double)g.M * (double)(g.th * g.tw) * (double)g.Clog * (double)wrows;
   }
+  if (pack.skip_dead_taps) flops = 0.0;      // reflect-ring launches skip most taps: left out of the executed-FLOP count
   const int tiles_n = (ldc + BN - 1) / BN;
   const int nk = (Kmax + BKE - 1) / BKE;
   const int kps = (nk + splits - 1) / splits;
@@ -528,7 +571,8 @@ static hipError_t gather_gemm_t(const DescPack& pack, const void* src, const voi
   const GatherDesc& g0 = pack.d[0];
   // split-K when the grid cannot fill the chip: aim for >= 2 workgroups per CU, keep >= 4 k-steps per split
   int splits = 1;
-  const size_t out_elems = (size_t)g0.N * g0.OH * g0.OW * ldc;
+  size_t out_elems = (size_t)g0.N * g0.OH * g0.OW * ldc;
+  if (pack.ws_compact) out_elems = (size_t)(pack.m_base[pack.n - 1] + pack.d[pack.n - 1].M) * ldc;
   if (tiles < g_num_cu && nk >= 4 && ws != nullptr && ws_bytes >= out_elems * sizeof(float)) {
     // small-M layers (deep D convs, the 5x5 SPADE table convs) are a serial chain of k-steps on a handful of CUs:
     // spread K over the idle CUs, down to 2 k-steps per workgroup
@@ -549,8 +593,12 @@ static hipError_t gather_gemm_t(const DescPack& pack, const void* src, const voi
     const int threads = 256;
     size_t blocks = (out_elems + threads - 1) / threads;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(splitk_finalize_kernel<T>, dim3((unsigned)blocks), dim3(threads), 0, st, (const float*)ws, bias,
-                       (T*)out, out_elems, ldc, wrows, act);
+    if (pack.ws_compact)
+      hipLaunchKernelGGL(splitk_finalize_compact_kernel<T>, dim3((unsigned)blocks), dim3(threads), 0, st, pack, (const float*)ws,
+                         bias, (T*)out, out_elems, ldc, wrows, act);
+    else
+      hipLaunchKernelGGL(splitk_finalize_kernel<T>, dim3((unsigned)blocks), dim3(threads), 0, st, (const float*)ws, bias,
+                         (T*)out, out_elems, ldc, wrows, act);
     e = hipGetLastError();
   }
   return e;
@@ -558,20 +606,28 @@ static hipError_t gather_gemm_t(const DescPack& pack, const void* src, const voi
 
 hipError_t gather_gemm_multi(int dtype, const GatherDesc* descs, const long long* woffs, int n, const void* src,
                              const void* wgt, int wrows, const float* bias, void* out, float* ws, size_t ws_bytes, int ldc,
-                             int act, hipStream_t st) {
+                             int act, hipStream_t st, bool compact_ws) {
   if (n < 1 || n > 4) return hipErrorInvalidValue;
   DescPack pack;
   pack.n = 0;
+  pack.ws_compact = compact_ws ? 1 : 0;
+  pack.skip_dead_taps = compact_ws ? 1 : 0;      // the reflect-ring launches are the compact ones
   for (int i = 0; i < n; ++i) {
     if (descs[i].M <= 0) continue;           // empty parity class
     pack.d[pack.n] = descs[i];
     pack.woff[pack.n] = woffs[i];
     pack.fd_taps[pack.n] = make_fastdiv((uint32_t)(descs[i].th * descs[i].tw));
+    pack.m_base[pack.n] = pack.n == 0 ? 0 : pack.m_base[pack.n - 1] + pack.d[pack.n - 1].M;
     pack.n++;
   }
   if (pack.n == 0) return hipSuccess;
-  for (int i = pack.n; i < 4; ++i) { pack.d[i] = pack.d[0]; pack.woff[i] = 0; pack.fd_taps[i] = pack.fd_taps[0]; }
+  for (int i = pack.n; i < 4; ++i) { pack.d[i] = pack.d[0]; pack.woff[i] = 0; pack.fd_taps[i] = pack.fd_taps[0]; pack.m_base[i] = 0; }
   if (dtype == DT_BF16) {
+    if (g_use_halo && pack.n == 1) {      // stride-1 3x3 layers: halo-resident kernel (conv_halo.hip)
+      hipError_t e = halo_conv(pack.d[0], src, (const bf16_t*)wgt + pack.woff[0],
+                               wrows, bias, out, ldc, act, g_num_cu, st);
+      if (e != hipErrorNotSupported) return e;
+    }
     if (g_use_v2) {
       hipError_t e = gather_gemm_v2(pack, src, wgt, wrows, bias, out, ws, ws_bytes, ldc, act, g_num_cu, st);
       if (e != hipErrorNotSupported) return e;

@@ -1,0 +1,363 @@
+// Halo-resident conv (bf16, stride 1, up to 3x3 taps): forward convs and zero-boundary dgrads of the 3x3 layers.
+//
+// The gather GEMM (conv_gemm_v2.hip) re-fetches the activation tile for every tap: 9 x (256 rows x 128 B) per
+// 64-channel slice, so its k-step moves 48 KB L2->LDS for 4.2 MFLOP and the loop runs at the operand-delivery rate
+// (~21 B/clk/CU), not at the MFMA rate.  Here a workgroup owns an 8 x 32 pixel output tile of ONE image and keeps the
+// (8+th-1) x (32+tw-1) input halo of the current 64-channel slice in LDS (<= 340 pixels x 128 B = 43.5 KB, double
+// buffered); all th*tw taps read their A fragments from that halo at shifted pixel addresses.  Per k-step only the
+// weight tile (BN x 128 B) comes from L2: 16 KB + 4.8 KB of amortised halo for the same 4.2 MFLOP -- 2.3x less
+// operand traffic, which also frees LDS for a 4-stage weight ring (three k-steps of prefetch).
+//
+//   k-step order : 64-channel slice outer, tap inner (weights are packed [Cout][tap][Cs]: k = tap*Cs + slice*64)
+//   LDS          : halo[2] (2 x 44,032 B) | weight ring STAGES x BN x 128 B | halo source-offset table
+//   LDS image    : 128-byte rows, 16-byte chunk c of row r at slot c ^ ((r>>1)&7) (conflict-free ds_read_b128);
+//                  LDS-DMA lands lane-linear, so the swizzle is applied to the SOURCE chunk each lane fetches
+//   waves        : 8 (4 x 2): wave (wm, wn) owns tile rows 2wm, 2wm+1 (64 pixels) x BN/2 output channels
+//   halo pixel   : output (py, px), tap (ty, tx) reads halo pixel (py + dy(ty), px + dx(tx)), dy = ty for ys = +1 and
+//                  th-1-ty for ys = -1 (dgrad: the tap sign flip is the kernel flip, geom.h)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <algorithm>
+
+#include "common.h"
+#include "geom.h"
+#include "launch.h"
+
+namespace dei2i {
+
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page_halo[256];
+extern int g_v2_ablate;
+extern unsigned long long* g_v2_dbg;
+
+typedef __attribute__((address_space(3))) void lds_void_h;
+typedef __attribute__((address_space(1))) const void gbl_void_h;
+
+DEI2I_D void glds16h(const void* gptr, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gbl_void_h*)gptr, (lds_void_h*)lds_wave_base, 16, 0, 0);
+}
+
+DEI2I_D int xcd_remap_h(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+constexpr int HALO_TH = 8, HALO_TW = 32;
+constexpr int HALO_GROUPS = 43;                       // 8-pixel LDS-DMA groups per halo slice (344 >= 10*34 pixels)
+constexpr int HALO_BYTES = HALO_GROUPS * 8 * 128;     // 44,032
+constexpr int HALO_HL = 6;                            // halo LDS-DMA instructions per wave per slice (48 >= 43 groups)
+
+template <int N> DEI2I_D void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BN, int STAGES, int MODE>
+__global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, const bf16_t* __restrict__ src,
+                                                        const bf16_t* __restrict__ wgt, const int wrows,
+                                                        const float* __restrict__ bias, bf16_t* __restrict__ out,
+                                                        const int ldc, const int act, const int tiles_n, const int ablate,
+                                                        unsigned long long* __restrict__ dbg) {
+  constexpr int BM = HALO_TH * HALO_TW;             // 256 output pixels
+  constexpr int WN = 2, WTN = BN / WN, TM = 2, TN = WTN / 32;
+  constexpr int LB = BN / 64;                       // weight LDS-DMA instructions per wave per stage
+  constexpr int B_STAGE = BN * 128;
+  constexpr int AHEAD = STAGES - 1;
+  static_assert(TN >= 1 && STAGES >= 3, "tile shape");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const halo = smem;
+  unsigned char* const ring = smem + 2 * HALO_BYTES;
+  int* const htab = reinterpret_cast<int*>(ring + STAGES * B_STAGE);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int bid = xcd_remap_h(blockIdx.x, gridDim.x);
+  const int tile_n = bid % tiles_n, tile_m = bid / tiles_n;
+  const int tiles_x = g.Wo / HALO_TW, tiles_y = g.Ho / HALO_TH;
+  const int img = tile_m / (tiles_x * tiles_y);
+  const int trem = tile_m - img * (tiles_x * tiles_y);
+  const int y0 = (trem / tiles_x) * HALO_TH, x0 = (trem % tiles_x) * HALO_TW;
+  const int n0 = tile_n * BN;
+
+  const int hwd = HALO_TW + g.tw - 1;                // halo width in pixels
+  const int npix = (HALO_TH + g.th - 1) * hwd;
+  const int hy0 = y0 + g.by0 + (g.ys < 0 ? -(g.th - 1) : 0);
+  const int hx0 = x0 + g.bx0 + (g.xs < 0 ? -(g.tw - 1) : 0);
+
+  // ---- halo source-offset table (element offset of each halo pixel's channel 0, -1 = contributes zero) ----
+  for (int p = tid; p < HALO_GROUPS * 8; p += 512) {
+    int off = -1;
+    if (p < npix) {
+      const int hy = p / hwd, hx = p - hy * hwd;
+      const int y = bound_coord(hy0 + hy, g.Hl, g.pad_mode);
+      const int x = bound_coord(hx0 + hx, g.Wl, g.pad_mode);
+      if ((y | x) >= 0) off = ((img * g.Hs + (y >> g.up)) * g.Ws + (x >> g.up)) * g.Cs;
+    }
+    htab[p] = off;
+  }
+  __syncthreads();
+
+  // ---- per-lane LDS-DMA roles ----
+  const int lrow = lane >> 3, lslot = lane & 7;
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_halo);
+  int h_off[HALO_HL], h_group[HALO_HL];
+#pragma unroll
+  for (int j = 0; j < HALO_HL; ++j) {
+    int grp = j * 8 + wave;                          // 48 slots for 43 groups: the surplus re-fetches groups 0..4
+    if (grp >= HALO_GROUPS) grp -= HALO_GROUPS;      // (identical bytes land twice; keeps vmcnt uniform across waves)
+    const int pix = grp * 8 + lrow;
+    const int o = htab[pix];
+    h_group[j] = grp;
+    h_off[j] = o >= 0 ? o + ((lslot ^ ((pix >> 1) & 7)) << 3) : -1;
+  }
+  const bf16_t* b_ptr[LB];
+#pragma unroll
+  for (int j = 0; j < LB; ++j) {
+    const int r = j * 64 + wave * 8 + lrow;
+    const int n = n0 + r;
+    b_ptr[j] = n < wrows ? wgt + (size_t)n * g.K + ((lslot ^ ((r >> 1) & 7)) << 3) : nullptr;
+  }
+
+  const int ntaps = __builtin_amdgcn_readfirstlane(g.th * g.tw);
+  const int nslices = __builtin_amdgcn_readfirstlane(g.Cs >> 6);
+  const int nk = ntaps * nslices;
+
+  auto issue_halo = [&](int slice) {
+    unsigned char* hb = halo + (slice & 1) * HALO_BYTES;
+    const int ci0 = slice << 6;
+#pragma unroll
+    for (int j = 0; j < HALO_HL; ++j) {
+      const bf16_t* p = h_off[j] >= 0 ? src + ((size_t)(unsigned)h_off[j] + (unsigned)ci0) : zero;
+      glds16h(p, hb + h_group[j] * 1024);
+    }
+  };
+  int is_tap = 0, is_slice = 0;                      // (tap, slice) of the next weight k-step to issue
+  auto issue_b = [&](int stage) {
+    unsigned char* sb = ring + stage * B_STAGE;
+    const int kb = is_tap * g.Cs + (is_slice << 6);
+#pragma unroll
+    for (int j = 0; j < LB; ++j) {
+      const bf16_t* p = b_ptr[j] != nullptr ? b_ptr[j] + kb : zero;
+      glds16h(p, sb + (j * 64 + wave * 8) * 128);
+    }
+    if (++is_tap == ntaps) { is_tap = 0; ++is_slice; }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int lr = lane & 31, lh = lane >> 5;
+
+  // ---- fragment reads: ALL four 16-wide k-substeps of a k-step live in registers (Frags); the reads of k-step it+1
+  //      are issued between the MFMA groups of k-step it, so LDS latency never sits between a barrier and an MFMA ----
+  struct Frags { u32x4 a[4][TM]; u32x4 b[4][TN]; };
+  int a_pix0[TM];                                    // halo pixel of this lane's row for tap offset 0
+#pragma unroll
+  for (int i = 0; i < TM; ++i) a_pix0[i] = (wm * 2 + i) * hwd + lr;
+  int b_lane[TN], b_rsw[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int row = wn * WTN + j * 32 + lr;
+    b_lane[j] = row * 128;
+    b_rsw[j] = (row >> 1) & 7;
+  }
+  // state of the k-step whose fragments are being LOADED (one ahead of the one being computed)
+  int ld_tx = 0, ld_ty = 0, ld_slice = 0, ld_stage = 0;
+  const int step_x = g.xs > 0 ? 1 : -1, step_y = g.ys > 0 ? hwd : -hwd;
+  int ld_toff = (g.ys > 0 ? 0 : (g.th - 1) * hwd) + (g.xs > 0 ? 0 : g.tw - 1);     // halo pixel offset of tap (0,0)
+  const int toff_row_wrap = step_y - (g.tw - 1) * step_x;                            // (ty,tw-1) -> (ty+1,0)
+  const int toff_origin = ld_toff;
+  const unsigned char* la_base[TM];
+  int la_swz[TM];
+  const unsigned char* lb_base;
+  auto prep_load = [&]() {                            // addresses for the k-step (ld_tap, ld_slice, ld_stage)
+    const unsigned char* hb = halo + (ld_slice & 1) * HALO_BYTES;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int pix = a_pix0[i] + ld_toff;
+      la_base[i] = hb + pix * 128;
+      la_swz[i] = (pix >> 1) & 7;
+    }
+    lb_base = ring + ld_stage * B_STAGE;
+  };
+  auto advance_load = [&]() {
+    if (++ld_tx == g.tw) {
+      ld_tx = 0;
+      if (++ld_ty == g.th) { ld_ty = 0; ++ld_slice; ld_toff = toff_origin; }
+      else ld_toff += toff_row_wrap;
+    } else {
+      ld_toff += step_x;
+    }
+    if (++ld_stage == STAGES) ld_stage = 0;
+  };
+  auto read_frags = [&](Frags& f, int ks) {
+    const int chunk = ks * 2 + lh;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) f.a[ks][i] = *reinterpret_cast<const u32x4*>(la_base[i] + ((chunk ^ la_swz[i]) << 4));
+#pragma unroll
+    for (int j = 0; j < TN; ++j) f.b[ks][j] = *reinterpret_cast<const u32x4*>(lb_base + b_lane[j] + ((chunk ^ b_rsw[j]) << 4));
+  };
+  auto mfma_group = [&](const Frags& f, int ks) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[ks][i]),
+                                                             __builtin_bit_cast(bf16x8, f.b[ks][j]), acc[i][j], 0, 0, 0);
+  };
+
+  // ---- main loop ----
+  // Weights: ring of STAGES stages, weights(j) are issued at iteration j - STAGES (the prologue issues 0..STAGES-1).
+  // Halo: slice s+1 is issued at the iteration BEFORE the first k-step of slice s (prologue: slices 0 and 1), always
+  // ahead of that iteration's weight issue, so "weights(it+1) landed" implies "halo of k-step it+1 landed".
+  // Iteration it:  wait(weights(it+1) landed) ; lgkmcnt(0) (own fragments of k-step it are in registers) ; barrier
+  //                -> stage it % STAGES and (at a slice boundary) the older halo buffer are free for every wave
+  //                [halo issue] ; issue weights(it+STAGES) ; MFMAs of k-step it interleaved with the fragment reads
+  //                of k-step it+1.
+  // Loads retire in order, so the wait counts the loads YOUNGER than weights(it+1): STAGES-2 weight stages, plus one
+  // halo slice while it is younger (taps 0..STAGES-3 of a slice that has a successor and a predecessor).
+  int tap = 0, slice = 0;                             // k-step being computed
+  Frags f0, f1;
+  auto body = [&](Frags& cur, Frags& nxt, int it) {
+    const int younger = min(STAGES - 2, nk - 2 - it);                   // weight stages issued after weights(it+1)
+    // a halo slice was issued after weights(it+1) iff one of the last STAGES-2 iterations computed a slice's last tap
+    const bool halo_young = tap <= STAGES - 3 && slice >= 1 && slice + 1 < nslices;
+    if (younger == STAGES - 2) {
+      if (halo_young) wait_vm<(STAGES - 2) * LB + HALO_HL>();
+      else wait_vm<(STAGES - 2) * LB>();
+    } else if (younger == 1 && STAGES > 3) {
+      wait_vm<LB>();
+    } else {
+      wait_vm<0>();
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (MODE != 3) __builtin_amdgcn_s_barrier();
+    mfma_group(MODE == 1 ? f0 : cur, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // the k-step after this one starts slice `slice+1` when tap is the last tap: fetch the halo of slice+2 now
+    if (MODE != 2) {
+      if (tap == ntaps - 1 && slice + 2 < nslices) issue_halo(slice + 2);
+      if (it + STAGES < nk) issue_b(it % STAGES);
+    }
+    prep_load();                                                         // ld_* describe k-step it+1
+    __builtin_amdgcn_sched_barrier(0);
+    if (MODE != 1) read_frags(nxt, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(MODE == 1 ? f0 : cur, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (MODE != 1) read_frags(nxt, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(MODE == 1 ? f0 : cur, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (MODE != 1) { read_frags(nxt, 2); read_frags(nxt, 3); }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(MODE == 1 ? f0 : cur, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    advance_load();
+    if (++tap == ntaps) { tap = 0; ++slice; }
+  };
+
+  const unsigned long long st0 = ablate == 5 ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long sr0 = ablate == 5 ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  issue_halo(0);
+  if (nslices > 1) issue_halo(1);
+  for (int s = 0; s < STAGES; ++s)
+    if (s < nk) issue_b(s);
+  // k-step 0: wait for halo 0 and weights(0) (everything older than weights(1))
+  if (nk >= STAGES) wait_vm<(STAGES - 1) * LB>(); else wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+  prep_load();
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) read_frags(f0, ks);
+  advance_load();
+  int it = 0;
+  for (; it + 1 < nk; it += 2) {
+    body(f0, f1, it);
+    body(f1, f0, it + 1);
+  }
+  if (it < nk) body(f0, f1, it);
+  if (ablate == 5 && dbg != nullptr && lane == 0) {      // diagnostic build path: loop cycles and the clock held
+    unsigned long long* d = dbg + ((size_t)blockIdx.x * 8 + wave) * 4;
+    d[0] = __builtin_amdgcn_s_memtime() - st0;
+    d[1] = __builtin_amdgcn_s_memrealtime() - sr0;
+    d[2] = (unsigned long long)nk;
+    d[3] = st0;
+  }
+
+  // ---- epilogue: stage the tile through LDS as bf16 [row][BN], write back with 16-byte stores ----
+  __syncthreads();
+  bf16_t* ctile = reinterpret_cast<bf16_t*>(smem);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = wn * WTN + j * 32 + lr;
+    const int n = n0 + col;
+    const float bv = (bias != nullptr && n < wrows) ? bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (wm * 2 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const float v = n < wrows ? apply_act(acc[i][j][e] + bv, act) : 0.f;
+        ctile[row * BN + col] = f32_to_bf16(v);
+      }
+  }
+  __syncthreads();
+  constexpr int CPR = BN / 8;             // 16-byte chunks per tile row
+  constexpr int RPP = 512 / CPR;          // rows per pass
+  const int chunk = tid % CPR, rsub = tid / CPR;
+  const int ncol = n0 + chunk * 8;
+  if (ncol < ldc) {
+#pragma unroll
+    for (int p = 0; p < BM / RPP; ++p) {
+      const int row = p * RPP + rsub;
+      const size_t opix = (size_t)out_pixel(g, img, y0 + (row >> 5), x0 + (row & 31));
+      *reinterpret_cast<u32x4*>(out + opix * ldc + ncol) = *reinterpret_cast<const u32x4*>(ctile + row * BN + chunk * 8);
+    }
+  }
+}
+
+template <int BN, int STAGES>
+static hipError_t launch_halo(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out,
+                              int ldc, int act, hipStream_t st) {
+  const int tiles_m = g.N * (g.Ho / HALO_TH) * (g.Wo / HALO_TW);
+  const int tiles_n = (ldc + BN - 1) / BN;
+  const size_t lds = 2 * (size_t)HALO_BYTES + (size_t)STAGES * BN * 128 + HALO_GROUPS * 8 * sizeof(int);
+  auto kern = halo_conv_kernel<BN, STAGES, 0>;
+  if (BN == 128 && g_v2_ablate == 11) kern = halo_conv_kernel<BN, STAGES, 1>;       // timing-only diagnostic variants
+  if (BN == 128 && g_v2_ablate == 12) kern = halo_conv_kernel<BN, STAGES, 2>;
+  if (BN == 128 && g_v2_ablate == 13) kern = halo_conv_kernel<BN, STAGES, 3>;
+  {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  prof_begin(PROF_GATHER_GEMM, 2.0 * (double)g.M * (double)(g.th * g.tw) * (double)g.Clog * (double)wrows, st);
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, st, g, (const bf16_t*)src, (const bf16_t*)wgt, wrows, bias,
+                     (bf16_t*)out, ldc, act, tiles_n, g_v2_ablate, g_v2_dbg);
+  prof_end(PROF_GATHER_GEMM, st);
+  return hipGetLastError();
+}
+
+// returns hipErrorNotSupported when the shape does not qualify (the caller falls through to the gather GEMMs)
+hipError_t halo_conv(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out, int ldc,
+                     int act, int num_cu, hipStream_t st) {
+  if (g.sh != 1 || g.sw != 1 || (g.ys != 1 && g.ys != -1) || (g.xs != 1 && g.xs != -1)) return hipErrorNotSupported;
+  if (g.th > 3 || g.tw > 3 || g.th * g.tw < 3) return hipErrorNotSupported;        // taps >= prefetch depth (see the loop)
+  if (g.Cs % 64 != 0 || g.Ho % HALO_TH != 0 || g.Wo % HALO_TW != 0 || g.M != g.N * g.Ho * g.Wo) return hipErrorNotSupported;
+  if ((long long)g.N * g.Hs * g.Ws * g.Cs >= (1ll << 31)) return hipErrorNotSupported;   // 32-bit offset table
+  if (ldc < 64 || ldc % 8 != 0) return hipErrorNotSupported;
+  const int tiles_m = g.N * (g.Ho / HALO_TH) * (g.Wo / HALO_TW);
+  if (ldc >= 128) {
+    if (tiles_m * ((ldc + 127) / 128) < num_cu / 2) return hipErrorNotSupported;   // small grids: split-K v1 fills the chip better
+    return launch_halo<128, 4>(g, src, wgt, wrows, bias, out, ldc, act, st);
+  }
+  if (tiles_m < num_cu / 2) return hipErrorNotSupported;
+  return launch_halo<64, 4>(g, src, wgt, wrows, bias, out, ldc, act, st);
+}
+
+}  // namespace dei2i

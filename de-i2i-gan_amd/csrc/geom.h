@@ -156,6 +156,17 @@ inline GatherDesc make_dgrad_desc(const ConvShape& c, int CoutS, int ay, int ax)
   return g;
 }
 
+// The same gather restricted to the output sub-rectangle rows [ry0, ry0+rh) x cols [rx0, rx0+rw) of g's output grid
+// (output placement follows).  Used to compute only the reflect ring of a dgrad frame.
+inline GatherDesc sub_rect_desc(const GatherDesc& g, int ry0, int rh, int rx0, int rw) {
+  GatherDesc r = g;
+  r.Ho = rh; r.Wo = rw;
+  r.by0 = g.by0 + ry0 * g.sh; r.bx0 = g.bx0 + rx0 * g.sw;
+  r.oy0 = g.oy0 + ry0 * g.oys; r.ox0 = g.ox0 + rx0 * g.oxs;
+  finish_desc(r);
+  return r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Index maps shared by the device kernels and the CPU geometry check
 // ---------------------------------------------------------------------------------------------

@@ -18,6 +18,9 @@ struct DescPack {
   long long woff[4];      // element offset of each class's packed weights
   FastDiv fd_taps[4];     // divide by th*tw (v2 k-step order)
   int n;
+  int ws_compact;         // split-K partials indexed by (m_base[class] + m) instead of the output pixel
+  int skip_dead_taps;     // v1: skip the k-steps of a tap that contributes zero to every row of the tile (reflect ring)
+  int m_base[4];
 };
 
 void set_num_cu(int n);
@@ -25,12 +28,15 @@ void set_use_v2(int on);
 hipError_t gather_gemm_v2(const DescPack& pack, const void* src, const void* wgt, int wrows, const float* bias, void* out,
                           float* ws, size_t ws_bytes, int ldc, int act, int num_cu, hipStream_t st);
 int num_cu();
+void set_use_halo(int on);
+hipError_t halo_conv(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out, int ldc,
+                     int act, int num_cu, hipStream_t st);
 
 hipError_t gather_gemm(int dtype, const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias,
                        void* out, float* ws, size_t ws_bytes, int ldc, int act, hipStream_t st);
 hipError_t gather_gemm_multi(int dtype, const GatherDesc* descs, const long long* woffs, int n, const void* src,
                              const void* wgt, int wrows, const float* bias, void* out, float* ws, size_t ws_bytes, int ldc,
-                             int act, hipStream_t st);
+                             int act, hipStream_t st, bool compact_ws = false);
 hipError_t wgrad_gemm(int dtype, const GatherDesc& g, const void* src, const void* dy, int co_rows, int ldy, float* dw,
                       hipStream_t st);
 

@@ -73,6 +73,7 @@ int dei2i_set_option(const char* name, int value) {
   if (name == nullptr) return DEI2I_ERR_BAD_ARG;
   if (std::string(name) == "gather_gemm_v2") { set_use_v2(value); return 0; }
   if (std::string(name) == "wgrad_v2") { g_use_wgrad_v2 = value; return 0; }
+  if (std::string(name) == "halo_conv") { set_use_halo(value); return 0; }
   if (std::string(name) == "v2_ablate") { g_v2_ablate = value; return 0; }     // timing-only builds: 1 = no loads, 2 = no MFMA
   return DEI2I_ERR_BAD_ARG;
 }

@@ -196,17 +196,15 @@ class _Conv2d(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             _, wd = ctx.cache.get(weight, ctx.sources, prec, geom, cins, couts, need_dgrad=True)
-            oh, ow = c_int(), c_int()
-            lib.dei2i_conv2d_dgrad_shape(byref(d), byref(oh), byref(ow))
-            ext = torch.empty((n, oh.value, ow.value, cins), dtype=prec.dtype, device=x.device)
             ws = _workspace(x.device, lib.dei2i_conv2d_workspace_bytes(byref(d)))
-            L.check(lib.dei2i_conv2d_dgrad(byref(d), _p(g), _p(wd), _p(ext), _p(ws), ws.numel() * 4, st), "conv2d_dgrad")
-            if (geom.reflect and geom.pad > 0) or geom.up:
-                dx = torch.empty_like(x)
-                L.check(lib.dei2i_fold_pad(prec.code, n, h, w, cins, geom.pad, d.pad_mode, d.up, _p(ext), None, _p(dx), st),
-                        "fold_pad")
-            else:
-                dx = ext
+            dx = torch.empty_like(x)
+            ext = None
+            if (geom.reflect and geom.pad > 0) or geom.up:           # the dgrad frame differs from the input: scratch
+                oh, ow = c_int(), c_int()
+                lib.dei2i_conv2d_dgrad_shape(byref(d), byref(oh), byref(ow))
+                ext = _workspace(x.device, n * oh.value * ow.value * cins * x.element_size(), slot="dgrad_frame")
+            L.check(lib.dei2i_conv2d_dgrad_input(byref(d), _p(g), _p(wd), _p(ext), _p(dx), _p(ws), ws.numel() * 4, st),
+                    "conv2d_dgrad_input")
         if ctx.needs_input_grad[1]:
             packed = lib.dei2i_packed_fwd_elems(byref(d))
             scratch = _workspace(x.device, max(packed * 4, min(packed * 4 * 16, 512 << 20)), slot="wgrad")

@@ -69,6 +69,12 @@ int dei2i_conv2d_fwd(const dei2i_conv* c, const void* x, const void* w_packed, c
                      float* ws, size_t ws_bytes, dei2i_stream s);
 int dei2i_conv2d_dgrad(const dei2i_conv* c, const void* dy, const void* wd_packed, void* dx_ext, float* ws,
                        size_t ws_bytes, dei2i_stream s);
+/* convolution_backward's grad_input in one call: dx (N,H,W,CinS) = the dgrad frame folded back onto the physical
+ * input (reflection_pad2d_backward + upsample_nearest2d_backward).  ext_scratch: N*OH*OW*CinS elements of the compute
+ * dtype (dei2i_conv2d_dgrad_shape), may be NULL for zero-padded convs without upsample.  Stride-1 reflect convs run
+ * as interior GEMM (straight into dx) + reflect-ring GEMM + border fold; everything else as dgrad + dei2i_fold_pad. */
+int dei2i_conv2d_dgrad_input(const dei2i_conv* c, const void* dy, const void* wd_packed, void* ext_scratch, void* dx,
+                             float* ws, size_t ws_bytes, dei2i_stream s);
 /* dw_packed (fp32, dei2i_packed_fwd_elems) is zeroed by the call, then accumulated with fp32 atomics */
 int dei2i_conv2d_wgrad(const dei2i_conv* c, const void* x, const void* dy, float* dw_packed, dei2i_stream s);
 /* wgrad straight to the OIHW fp32 gradient (what autograd hands to the optimizer).  scratch: fp32 device buffer of at

@@ -8,12 +8,12 @@ tag=${1:-r01}
 root=$(pwd)
 mkdir -p "$root/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d "$root/gpurun_out/prof_$tag" -o runc -- python3 "$root/bench.py" --steps 5 --warmup 2 --no-cpu-baseline \
+rocprofv3 --kernel-trace --stats --output-format csv -d "$root/gpurun_out/prof_$tag" -o runc -- python3 "$root/bench.py" --steps 5 --warmup 2 --no-cpu-baseline \
     > "$root/gpurun_out/bench_prof_$tag.log" 2>&1
 echo "[collect] kernel stats done"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$root/gpurun_out/pmc_fetch_$tag" -o runc -- python3 "$root/bench.py" --steps 2 --warmup 1 \
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$root/gpurun_out/pmc_fetch_$tag" -o runc -- python3 "$root/bench.py" --steps 2 --warmup 1 \
     --no-cpu-baseline --no-roofline > "$root/gpurun_out/pmc_fetch_$tag.log" 2>&1
 echo "[collect] FETCH_SIZE pass done"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$root/gpurun_out/pmc_write_$tag" -o runc -- python3 "$root/bench.py" --steps 2 --warmup 1 \
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$root/gpurun_out/pmc_write_$tag" -o runc -- python3 "$root/bench.py" --steps 2 --warmup 1 \
     --no-cpu-baseline --no-roofline > "$root/gpurun_out/pmc_write_$tag.log" 2>&1
 echo "[collect] WRITE_SIZE pass done"

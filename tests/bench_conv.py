@@ -18,6 +18,12 @@ SHAPES = [
     ("D5_1024>2048@8", 1024, 2048, 4, 2, 1, True, False, 8, 16),
     ("D3_256>512@32", 256, 512, 4, 2, 1, True, False, 32, 16),
     ("heads_64>4@256", 64, 4, 3, 1, 1, True, False, 256, 16),
+    ("dec0up_256>128@64", 256, 128, 3, 1, 1, True, True, 64, 16),
+    ("dec1up_128>64@128", 128, 64, 3, 1, 1, True, True, 128, 16),
+    ("D0_3>64@256", 3, 64, 4, 2, 1, True, False, 256, 16),
+    ("D1_64>128@128", 64, 128, 4, 2, 1, True, False, 128, 16),
+    ("D2_128>256@64", 128, 256, 4, 2, 1, True, False, 64, 16),
+    ("D4_512>1024@16", 512, 1024, 4, 2, 1, True, False, 16, 16),
 ]
 
 

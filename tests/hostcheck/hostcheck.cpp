@@ -123,6 +123,55 @@ void hc_fold(int N, int H, int W, int C, int pad, int reflect, int up, const flo
       }
 }
 
+// Decomposed grad_input of a stride-1 reflect conv (dei2i_conv2d_dgrad_input, conv_api.hip): interior = the
+// zero-boundary dgrad on the input grid written straight into dx; reflect ring = four sub-rectangle descriptors of the
+// padded frame written into ext (every other ext element stays untouched); border pixels add the ring's images.
+// Returns the number of ext elements the ring descriptors wrote (must be the ring, nothing else).
+long long hc_conv_dgrad_decomposed(const int* p, const float* dy, const float* wd, float* ext, float* dx) {
+  ConvShape s = shape_of(p);
+  const int CinS = p[5], CoutS = p[6], pad = s.pad;
+  const GatherDesc frame = make_dgrad_desc(s, CoutS, 0, 0);
+  ConvShape z = s;
+  z.pad_mode = PAD_ZERO;
+  const GatherDesc interior = make_dgrad_desc(z, CoutS, 0, 0);
+  run_gather_gemm(interior, dy, wd, CinS, dx, CinS);
+  const int OH = s.H + 2 * pad, OW = s.W + 2 * pad;
+  const GatherDesc ring[4] = {sub_rect_desc(frame, 0, pad, 0, OW), sub_rect_desc(frame, s.H + pad, pad, 0, OW),
+                              sub_rect_desc(frame, pad, s.H, 0, pad), sub_rect_desc(frame, pad, s.H, s.W + pad, pad)};
+  long long written = 0;
+  for (int k = 0; k < 4; ++k) {
+    run_gather_gemm(ring[k], dy, wd, CinS, ext, CinS);
+    written += (long long)ring[k].M * CinS;
+  }
+  // border fold, same pixel enumeration as fold_border_kernel
+  const int per_img = 2 * pad * s.W + 2 * pad * (s.H - 2 * pad);
+  for (int n = 0; n < s.N; ++n)
+    for (int q = 0; q < per_img; ++q) {
+      int h, w;
+      if (q < 2 * pad * s.W) {
+        const int k = q / s.W;
+        w = q - k * s.W;
+        h = k < pad ? 1 + k : s.H - 1 - pad + (k - pad);
+      } else {
+        const int q2 = q - 2 * pad * s.W;
+        const int k = q2 % (2 * pad);
+        const int hr = q2 / (2 * pad);
+        w = k < pad ? 1 + k : s.W - 1 - pad + (k - pad);
+        h = hr == 0 ? 0 : (hr <= s.H - 2 - 2 * pad ? pad + hr : s.H - 1);
+      }
+      int ys[6], xs[6];
+      const int ny = fold_sources(h, 0, s.H, pad, 1, ys), nx = fold_sources(w, 0, s.W, pad, 1, xs);
+      for (int c = 0; c < CinS; ++c) {
+        double acc = dx[(((long long)n * s.H + h) * s.W + w) * CinS + c];
+        for (int a = 0; a < ny; ++a)
+          for (int b = 0; b < nx; ++b)
+            if (a != 0 || b != 0) acc += ext[(((long long)n * OH + ys[a]) * OW + xs[b]) * CinS + c];
+        dx[(((long long)n * s.H + h) * s.W + w) * CinS + c] = (float)acc;
+      }
+    }
+  return written;
+}
+
 int hc_fastdiv_selftest(void) {
   const unsigned ds[] = {1, 2, 3, 4, 5, 7, 8, 9, 16, 25, 49, 64, 100, 147, 255, 256, 1000, 4096, 65536, 1048576, 16777215};
   const unsigned ns[] = {0, 1, 2, 3, 7, 8, 63, 64, 65, 999, 1000, 1001, 65535, 65536, 1048575, 16777216, 2147483647u};

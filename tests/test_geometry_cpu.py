@@ -89,6 +89,18 @@ def test_conv_geometry(hc, case):
     hc.hc_fold(N, H, W, cins, pad, int(mode == 1 and pad > 0), up, ptr(ext0), ptr(dx))
     np.testing.assert_allclose(dx[..., :cin], gx.permute(0, 2, 3, 1).numpy(), rtol=1e-4, atol=1e-4)
 
+    # decomposed grad_input of stride-1 reflect convs: interior GEMM straight into dx + reflect-ring GEMM + border fold
+    if mode == 1 and pad > 0 and s == 1 and not up and H >= 2 * pad + 2 and W >= 2 * pad + 2:
+        ext2 = np.full((N, dims[2], dims[3], cins), np.nan, np.float32)
+        dx2 = np.full((N, H, W, cins), np.nan, np.float32)                 # every element must be written
+        hc.hc_conv_dgrad_decomposed.restype = ctypes.c_longlong
+        written = hc.hc_conv_dgrad_decomposed(ptr(p), ptr(gyn), ptr(wd), ptr(ext2), ptr(dx2))
+        ring = np.ones((dims[2], dims[3]), bool)
+        ring[pad:pad + H, pad:pad + W] = False
+        assert written == N * int(ring.sum()) * cins
+        assert np.isnan(ext2[:, ~ring]).all() and not np.isnan(ext2[:, ring]).any()      # the ring and only the ring
+        np.testing.assert_allclose(dx2[..., :cin], gx.permute(0, 2, 3, 1).numpy(), rtol=1e-4, atol=1e-4)
+
     # wgrad
     dwp = np.zeros(cout * k * k * cins, np.float32)
     hc.hc_conv_wgrad(ptr(p), ptr(xn), ptr(gyn), ptr(dwp))

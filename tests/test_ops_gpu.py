@@ -62,6 +62,10 @@ CONV_CASES = [
     (64, 128, 4, 2, 1, True, False, 128, 128, 8, False, "leaky_relu"),   # stride 2: 4 dgrad parity classes in one launch
     (128, 192, 3, 1, 1, False, False, 30, 34, 32, True, "none"),   # zero padding through the zero page, ragged M, bias
     (64, 256, 3, 1, 1, True, False, 64, 60, 8, True, "relu"),      # 256x256-tile variant (2-stage ring), ragged M; wgrad v2
+    # halo-resident kernel (bf16, stride-1 3x3, H % 8 == 0, W % 32 == 0, >= 128 tiles); the (64,128,...,64,64,8) and the
+    # fused-upsample case above take it too
+    (128, 128, 3, 1, 1, True, False, 64, 32, 16, False, "none"),   # two 64-channel slices (halo double buffer), BN=128
+    (64, 136, 3, 1, 1, False, False, 32, 64, 16, True, "relu"),    # zero boundary via the zero page, bias, ragged N tile
 ]
 
 
