@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--set-option", action="append", default=[], metavar="NAME=INT",
+                    help="library option for A/B runs on one box, e.g. halo_conv=0 (dei2i_set_option)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child process of the default run
     return ap.parse_args()
 
@@ -147,6 +149,9 @@ def main():
     from de_i2i_gan_amd.parallel import attach_ddp
     from de_i2i_gan_amd.trainers.defectgan_trainer import DefectGanTrainer
 
+    for kv in args.set_option:
+        name, val = kv.split("=")
+        _lib.check(_lib.load().dei2i_set_option(name.encode(), int(val)), "set_option " + kv)
     opt = make_opt(args, device)
     torch.manual_seed(123)                           # reference default (utils/util.py:21); same weights on every rank
     tr = DefectGanTrainer(opt)

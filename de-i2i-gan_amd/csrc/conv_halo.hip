@@ -49,7 +49,7 @@ constexpr int HALO_HL = 6;                            // halo LDS-DMA instructio
 
 template <int N> DEI2I_D void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BN, int STAGES, int MODE>
+template <int BN, int STAGES, bool DIAG>
 __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, const bf16_t* __restrict__ src,
                                                         const bf16_t* __restrict__ wgt, const int wrows,
                                                         const float* __restrict__ bias, bf16_t* __restrict__ out,
@@ -212,82 +212,115 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, cons
                                                              __builtin_bit_cast(bf16x8, f.b[ks][j]), acc[i][j], 0, 0, 0);
   };
 
-  // ---- main loop ----
-  // Weights: ring of STAGES stages, weights(j) are issued at iteration j - STAGES (the prologue issues 0..STAGES-1).
-  // Halo: slice s+1 is issued at the iteration BEFORE the first k-step of slice s (prologue: slices 0 and 1), always
-  // ahead of that iteration's weight issue, so "weights(it+1) landed" implies "halo of k-step it+1 landed".
-  // Iteration it:  wait(weights(it+1) landed) ; lgkmcnt(0) (own fragments of k-step it are in registers) ; barrier
-  //                -> stage it % STAGES and (at a slice boundary) the older halo buffer are free for every wave
-  //                [halo issue] ; issue weights(it+STAGES) ; MFMAs of k-step it interleaved with the fragment reads
-  //                of k-step it+1.
-  // Loads retire in order, so the wait counts the loads YOUNGER than weights(it+1): STAGES-2 weight stages, plus one
-  // halo slice while it is younger (taps 0..STAGES-3 of a slice that has a successor and a predecessor).
-  int tap = 0, slice = 0;                             // k-step being computed
+  // ---- main loop: two wave groups in anti-phase ("ping-pong") ----
+  // With one barrier per k-step all eight waves run in lockstep: both waves of a SIMD issue their LDS reads / address
+  // math / LDS-DMA at the same time and the MFMA pipe idles meanwhile (measured: 1 990 cycles per k-step against 1 024
+  // of MFMA issue).  Here every k-step of a wave is two phases -- M(j): issue LDS-DMA, read the 16 fragments of k-step j
+  // into registers; C(j): 16 MFMAs, nothing else -- each closed by a workgroup barrier, and waves 4..7 run one phase
+  // behind waves 0..3 (one extra barrier up front).  Every SIMD hosts one wave of each group, so in every phase one of
+  // its waves owns the MFMA pipe while the other owns the LDS / VALU / DMA issue slots.
+  //
+  //   phase:      P0     P1     P2     P3     P4 ...
+  //   group 0:    M(0)   C(0)   M(1)   C(1)   M(2)
+  //   group 1:    -      M(0)   C(0)   M(1)   C(1)
+  //
+  // LDS-DMA protocol (every wave fetches its own share of each weight stage / halo slice):
+  //   C(j) issues weights(j-1+STAGES) into stage (j-1) % STAGES: its last reader was group 1's M(j-1), two phases before
+  //        group 0's C(j).  At tap 1 of a slice it also issues the NEXT slice's halo (into the buffer of the previous
+  //        slice, last read by group 1 at that slice's last tap).  (Measured alternatives, res-block shape, cycles per
+  //        k-step: DMA issue in M 2 695; in C after the first MFMA group 1 658; staggered per wave 2 048; halo spread one
+  //        instruction per tap 1 953; one barrier per k-step without phases 1 990.)
+  //   M(j) ends with "my share of weights(j+1) has landed" + barrier: the earliest reader of stage j+1 is group 0's
+  //        M(j+1), which starts after the barrier that closes group 1's M(j).  Halo slices are issued >= 4 k-steps
+  //        before that and are older than the weights waited for, so they have landed too.
+  const int grp = wave >> 2;
+  int tap = 0, slice = 0;                             // k-step of this wave's current M / C phase
   Frags f0, f1;
-  auto body = [&](Frags& cur, Frags& nxt, int it) {
-    const int younger = min(STAGES - 2, nk - 2 - it);                   // weight stages issued after weights(it+1)
-    // a halo slice was issued after weights(it+1) iff one of the last STAGES-2 iterations computed a slice's last tap
-    const bool halo_young = tap <= STAGES - 3 && slice >= 1 && slice + 1 < nslices;
-    if (younger == STAGES - 2) {
-      if (halo_young) wait_vm<(STAGES - 2) * LB + HALO_HL>();
-      else wait_vm<(STAGES - 2) * LB>();
-    } else if (younger == 1 && STAGES > 3) {
-      wait_vm<LB>();
-    } else {
-      wait_vm<0>();
-    }
+  unsigned long long dg[6] = {0, 0, 0, 0, 0, 0};      // DIAG: cycles in [issue | reads issued | vmcnt | lgkmcnt | barrier M | C+barrier]
+  auto now = [&]() -> unsigned long long {
+    if (!DIAG) return 0ull;
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (MODE != 3) __builtin_amdgcn_s_barrier();
-    mfma_group(MODE == 1 ? f0 : cur, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    // the k-step after this one starts slice `slice+1` when tap is the last tap: fetch the halo of slice+2 now
-    if (MODE != 2) {
-      if (tap == ntaps - 1 && slice + 2 < nslices) issue_halo(slice + 2);
-      if (it + STAGES < nk) issue_b(it % STAGES);
-    }
-    prep_load();                                                         // ld_* describe k-step it+1
-    __builtin_amdgcn_sched_barrier(0);
-    if (MODE != 1) read_frags(nxt, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_group(MODE == 1 ? f0 : cur, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (MODE != 1) read_frags(nxt, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_group(MODE == 1 ? f0 : cur, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    if (MODE != 1) { read_frags(nxt, 2); read_frags(nxt, 3); }
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_group(MODE == 1 ? f0 : cur, 3);
-    __builtin_amdgcn_sched_barrier(0);
+    return t;
+  };
+  auto phase_m = [&](Frags& f, int j) {
+    const unsigned long long q0 = now();
+    prep_load();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) read_frags(f, ks);
     advance_load();
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long q2 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
+    // my share of weights(j+1) [issued in C(j-2)] must have landed; younger: weights(j+2) [C(j-1)] and the halo slice
+    // C(j-1) issued at tap 1 (this k-step is then tap 2)
+    const bool halo_young = tap == 2 && slice + 1 < nslices;
+    if (j + 1 >= nk) wait_vm<0>();
+    else if (j + 2 < nk) { if (halo_young) wait_vm<LB + HALO_HL>(); else wait_vm<LB>(); }
+    else { if (halo_young) wait_vm<HALO_HL>(); else wait_vm<0>(); }
+    const unsigned long long q3 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long q4 = now();
+    __builtin_amdgcn_s_barrier();
+    if (DIAG) {
+      const unsigned long long q5 = now();
+      dg[1] += q2 - q0; dg[2] += q3 - q2; dg[3] += q4 - q3; dg[4] += q5 - q4;
+    }
+  };
+  // C(j): the 16 MFMAs, with this wave's LDS-DMA issue in the gaps (an MFMA holds the vector issue 8 of its 32 cycles;
+  // a 16-byte-per-lane load instruction occupies the CU's address path ~64 cycles, the hard floor of this kernel:
+  // 20.8 KB per k-step = 1 300 cycles)
+  auto phase_c = [&](const Frags& f, int j) {
+    const unsigned long long q0 = now();
+    mfma_group(f, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (j - 1 + STAGES < nk) issue_b((j + STAGES - 1) % STAGES);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(f, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tap == 1 && slice + 1 < nslices) issue_halo(slice + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(f, 2);
+    mfma_group(f, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    if (DIAG) dg[5] += now() - q0;
     if (++tap == ntaps) { tap = 0; ++slice; }
   };
 
   const unsigned long long st0 = ablate == 5 ? __builtin_amdgcn_s_memtime() : 0ull;
   const unsigned long long sr0 = ablate == 5 ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  // prologue: halo slice 0 and weights(0 .. STAGES-2); weights(STAGES-1) is issued by C(0)
   issue_halo(0);
-  if (nslices > 1) issue_halo(1);
-  for (int s = 0; s < STAGES; ++s)
-    if (s < nk) issue_b(s);
-  // k-step 0: wait for halo 0 and weights(0) (everything older than weights(1))
-  if (nk >= STAGES) wait_vm<(STAGES - 1) * LB>(); else wait_vm<0>();
-  __builtin_amdgcn_s_barrier();
-  prep_load();
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) read_frags(f0, ks);
-  advance_load();
-  int it = 0;
-  for (; it + 1 < nk; it += 2) {
-    body(f0, f1, it);
-    body(f1, f0, it + 1);
+  for (int s2 = 0; s2 < STAGES - 1; ++s2)
+    if (s2 < nk) issue_b(s2);
+  {
+    const int nb = min(STAGES - 2, max(nk - 1, 0));      // stages younger than weights(0)
+    if (nb >= 2) wait_vm<2 * LB>(); else if (nb == 1) wait_vm<LB>(); else wait_vm<0>();
   }
-  if (it < nk) body(f0, f1, it);
-  if (ablate == 5 && dbg != nullptr && lane == 0) {      // diagnostic build path: loop cycles and the clock held
+  __builtin_amdgcn_s_barrier();                          // halo 0 and weights(0) complete for every wave
+  if (grp == 1) __builtin_amdgcn_s_barrier();            // group 1 starts one phase late
+  int j = 0;
+  for (; j + 1 < nk; j += 2) {
+    phase_m(f0, j);
+    phase_c(f0, j);
+    phase_m(f1, j + 1);
+    phase_c(f1, j + 1);
+  }
+  if (j < nk) {
+    phase_m(f0, j);
+    phase_c(f0, j);
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();            // pairs with group 1's last phase
+  if (ablate == 5 && dbg != nullptr && lane == 0) {      // diagnostic: loop cycles and the clock held
     unsigned long long* d = dbg + ((size_t)blockIdx.x * 8 + wave) * 4;
     d[0] = __builtin_amdgcn_s_memtime() - st0;
     d[1] = __builtin_amdgcn_s_memrealtime() - sr0;
     d[2] = (unsigned long long)nk;
     d[3] = st0;
+    if (DIAG) {
+      unsigned long long* e = dbg + (size_t)gridDim.x * 8 * 4 + ((size_t)blockIdx.x * 8 + wave) * 6;
+      for (int q = 0; q < 6; ++q) e[q] = dg[q];
+    }
   }
 
   // ---- epilogue: stage the tile through LDS as bf16 [row][BN], write back with 16-byte stores ----
@@ -328,17 +361,15 @@ static hipError_t launch_halo(const GatherDesc& g, const void* src, const void* 
   const int tiles_m = g.N * (g.Ho / HALO_TH) * (g.Wo / HALO_TW);
   const int tiles_n = (ldc + BN - 1) / BN;
   const size_t lds = 2 * (size_t)HALO_BYTES + (size_t)STAGES * BN * 128 + HALO_GROUPS * 8 * sizeof(int);
-  auto kern = halo_conv_kernel<BN, STAGES, 0>;
-  if (BN == 128 && g_v2_ablate == 11) kern = halo_conv_kernel<BN, STAGES, 1>;       // timing-only diagnostic variants
-  if (BN == 128 && g_v2_ablate == 12) kern = halo_conv_kernel<BN, STAGES, 2>;
-  if (BN == 128 && g_v2_ablate == 13) kern = halo_conv_kernel<BN, STAGES, 3>;
+  auto kern = halo_conv_kernel<BN, STAGES, false>;
+  if (g_v2_ablate == 6) kern = halo_conv_kernel<BN, STAGES, true>;        // diagnostic build: per-phase cycle stamps
   {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
   prof_begin(PROF_GATHER_GEMM, 2.0 * (double)g.M * (double)(g.th * g.tw) * (double)g.Clog * (double)wrows, st);
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, st, g, (const bf16_t*)src, (const bf16_t*)wgt, wrows, bias,
-                     (bf16_t*)out, ldc, act, tiles_n, g_v2_ablate, g_v2_dbg);
+                     (bf16_t*)out, ldc, act, tiles_n, g_v2_ablate == 6 ? 5 : g_v2_ablate, g_v2_dbg);
   prof_end(PROF_GATHER_GEMM, st);
   return hipGetLastError();
 }
@@ -347,7 +378,7 @@ static hipError_t launch_halo(const GatherDesc& g, const void* src, const void* 
 hipError_t halo_conv(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out, int ldc,
                      int act, int num_cu, hipStream_t st) {
   if (g.sh != 1 || g.sw != 1 || (g.ys != 1 && g.ys != -1) || (g.xs != 1 && g.xs != -1)) return hipErrorNotSupported;
-  if (g.th > 3 || g.tw > 3 || g.th * g.tw < 3) return hipErrorNotSupported;        // taps >= prefetch depth (see the loop)
+  if (g.th != 3 || g.tw != 3) return hipErrorNotSupported;       // tap count >= ring depth + 1 (halo issue at tap 1)
   if (g.Cs % 64 != 0 || g.Ho % HALO_TH != 0 || g.Wo % HALO_TW != 0 || g.M != g.N * g.Ho * g.Wo) return hipErrorNotSupported;
   if ((long long)g.N * g.Hs * g.Ws * g.Cs >= (1ll << 31)) return hipErrorNotSupported;   // 32-bit offset table
   if (ldc < 64 || ldc % 8 != 0) return hipErrorNotSupported;

