@@ -7,6 +7,7 @@
 namespace dei2i {
 
 int g_use_wgrad_v2 = 1;
+int g_use_wgrad_halo = 1;
 
 static ConvShape to_shape(const dei2i_conv* c) {
   ConvShape s;
@@ -323,6 +324,13 @@ int dei2i_conv2d_wgrad_oihw(const dei2i_conv* c, const void* x, const void* dy, 
   const size_t packed = dei2i_packed_fwd_elems(c);
   if (scratch_elems < packed) return DEI2I_ERR_WORKSPACE;
   GatherDesc g = make_fwd_desc(to_shape(c), c->CinS);
+  if (c->dtype == DT_BF16 && g_use_wgrad_halo) {       // stride-1 3x3: (co, ci, 9 taps) block resident in registers
+    int nsplit = 0;
+    hipError_t e = wgrad_halo(g, x, dy, c->Cout, c->CoutS, scratch, scratch_elems, num_cu(), &nsplit, st);
+    if (e == hipSuccess)
+      return (int)wgrad_reduce_unpack(scratch, nsplit, (long long)packed, dw_oihw, c->Cout, c->Cin, c->CinS, c->kh * c->kw, st);
+    if (e != hipErrorNotSupported) return (int)e;
+  }
   if (c->dtype == DT_BF16 && g_use_wgrad_v2) {
     int nsplit = 0;
     hipError_t e = wgrad_v2(g, x, dy, c->Cout, c->CoutS, scratch, scratch_elems, num_cu(), &nsplit, st);

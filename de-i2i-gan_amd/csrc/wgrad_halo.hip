@@ -1,0 +1,198 @@
+// Halo-resident wgrad (bf16, stride-1 3x3): dw[co][tap][ci] = sum over pixels p of dy[p][co] * x[p + tap][ci].
+//
+// wgrad_v2 streams, per 64-pixel chunk, a dy tile and ONE tap's gathered x tile: 48 KB of LDS-DMA for 4.2 MFLOP, and
+// the CU's global->LDS path moves ~16 B/clk (one 16-byte-per-lane instruction per ~64 cycles), so its loop runs at
+// 3 000 cycles per chunk against 1 024 cycles of MFMA issue -- and every k-tile of a pixel split re-reads dy
+// (measured 576 MB of HBM/MALL traffic per launch against 67 MB algorithmic).  Here a workgroup owns a
+// (128 output channels) x (64 input channels) x (all 9 taps) block of dw -- 144 accumulator registers per thread --
+// and walks 4 x 32 pixel half-tiles of its pixel range: per half-tile it loads the dy tile (128 px x 128 co, 32 KB)
+// and the 6 x 34 input halo of its 64-channel slice (26 KB) once and runs all nine taps from LDS: 58 KB per 18.9 MFLOP,
+// 3 600 cycles of DMA under 4 600 cycles of MFMA issue.
+//
+//   grid     : (pixel splits, combos) with combos = ceil(Cout/128) * Cs/64; the combos of one split share an XCD's L2
+//   LDS      : 2 stages x [dy 128 px x 256 B | halo 208 px x 128 B]; both pixel-major (the reduction index is the row),
+//              fragments fetched with ds_read_b64_tr_b16; rows swizzled for its 2 x 32 lane groups (tr_swz)
+//   waves    : 8 = 4 (32-channel blocks of co) x 2 (32-channel blocks of ci); wave (cb, ib) owns dw[cb][ib] for 9 taps
+//   output   : each split's partial block goes to its fp32 slab [Cout][9][Cs] with plain 128-byte stores; the slabs are
+//              summed and un-packed to OIHW by wgrad_reduce_unpack_kernel (wgrad_v2.hip) -- no atomics, deterministic
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <algorithm>
+
+#include "common.h"
+#include "geom.h"
+#include "launch.h"
+
+namespace dei2i {
+
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page_hw[256];
+
+typedef __attribute__((address_space(3))) void lds_void_hw;
+typedef __attribute__((address_space(1))) const void gbl_void_hw;
+
+DEI2I_D void glds16hw(const void* gptr, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gbl_void_hw*)gptr, (lds_void_hw*)lds_wave_base, 16, 0, 0);
+}
+
+constexpr int HW_TH = 4, HW_TW = 32;                  // half-tile: 128 pixels
+constexpr int HW_HH = HW_TH + 2, HW_HWD = HW_TW + 2;  // 6 x 34 halo
+constexpr int HW_HPIX = HW_HH * HW_HWD;               // 204
+constexpr int HW_HGROUPS = 26;                        // 8-pixel DMA groups (208 >= 204)
+constexpr int HW_A_BYTES = 128 * 256;                 // dy tile: 128 px x 128 co
+constexpr int HW_B_BYTES = HW_HGROUPS * 8 * 128;      // halo: 208 px x 64 ci
+constexpr int HW_STAGE = HW_A_BYTES + HW_B_BYTES;     // 59,392
+
+__global__ __launch_bounds__(512) void wgrad_halo_kernel(const GatherDesc g, const bf16_t* __restrict__ src,
+                                                         const bf16_t* __restrict__ dy, const int co_rows, const int ldy,
+                                                         float* __restrict__ slabs, const int nslices, const int tiles_per_split,
+                                                         const long long slab_elems) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cb = wave >> 1, ib = wave & 1;            // 32-channel block of co / of ci
+
+  const int combo = blockIdx.y, split = blockIdx.x;
+  const int tile_c = combo / nslices, slice = combo - tile_c * nslices;
+  const int c0 = tile_c * 128, ci0 = slice << 6;
+
+  const int tiles_x = g.Wo / HW_TW, tiles_y = g.Ho / HW_TH;
+  const int tiles_img = tiles_x * tiles_y;
+  const int ntiles = g.N * tiles_img;
+  const int tbeg = split * tiles_per_split;
+  const int tend = min(ntiles, tbeg + tiles_per_split);
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_hw);
+
+  // ---- LDS-DMA roles ----
+  // dy: one instruction = 4 pixel rows x 256 B: lane l -> row (l>>4), 16-byte slot (l&15); 32 instructions per tile
+  // x : one instruction = 8 halo pixels x 128 B: lane l -> pixel (l>>3), slot (l&7); 26 groups in 32 slots
+  auto issue = [&](int stage, int t) {
+    unsigned char* sa = smem + stage * HW_STAGE;
+    unsigned char* sb = sa + HW_A_BYTES;
+    const int img = t / tiles_img;
+    const int rem = t - img * tiles_img;
+    const int ty = rem / tiles_x;
+    const int y0 = ty * HW_TH, x0 = (rem - ty * tiles_x) * HW_TW;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int rgrp = (j * 8 + wave) * 4;
+      const int r = rgrp + (lane >> 4);                                   // pixel of the half-tile: (r>>5, r&31)
+      const int off = ((lane & 15) * 16) ^ ((r & 3) << 6);               // source byte offset that belongs at this slot
+      const int c = c0 + (off >> 1);
+      const size_t pix = ((size_t)img * g.Ho + y0 + (r >> 5)) * g.Wo + x0 + (r & 31);
+      const bf16_t* p = c < ldy ? dy + pix * ldy + c : zero;
+      glds16hw(p, sa + rgrp * 256);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int grp = j * 8 + wave;
+      if (grp >= HW_HGROUPS) grp -= HW_HGROUPS;                           // surplus slots re-fetch groups 0..5
+      const int hp = grp * 8 + (lane >> 3);
+      const int hy = hp / HW_HWD, hx = hp - hy * HW_HWD;
+      const int off = ((lane & 7) * 16) ^ (((hp >> 1) & 1) << 6);
+      const bf16_t* p = zero;
+      if (hp < HW_HPIX) {
+        const int y = bound_coord(y0 + g.by0 + hy, g.Hl, g.pad_mode);
+        const int x = bound_coord(x0 + g.bx0 + hx, g.Wl, g.pad_mode);
+        if ((y | x) >= 0) p = src + ((size_t)((img * g.Hs + (y >> g.up)) * g.Ws + (x >> g.up))) * g.Cs + ci0 + (off >> 1);
+      }
+      glds16hw(p, sb + grp * 1024);
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  const int lr = lane & 31, lh = lane >> 5;
+  // transposed-read lane roles (ds_read_b64_tr_b16): lane i = 4q+p of a 16-lane group supplies row q, cols 4p..4p+3
+  const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_half = (lane >> 4) & 1;
+  const int a_colb = (cb * 32 + 16 * tr_half + 4 * tr_p) * 2;           // byte column in a 256-byte dy row
+  const int b_colb = (ib * 32 + 16 * tr_half + 4 * tr_p) * 2;           // byte column in a 128-byte halo row
+
+  auto tr_read = [&](const unsigned char* base, int o0, int o1) {
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + o0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + o1));
+    u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+    u32x4 r;
+    r.x = l2.x; r.y = l2.y; r.z = h2.x; r.w = h2.y;
+    return r;
+  };
+
+  auto compute = [&](int stage) {
+    const unsigned char* ab = smem + stage * HW_STAGE;
+    const unsigned char* bb = ab + HW_A_BYTES;
+#pragma unroll 2
+    for (int kb = 0; kb < 8; ++kb) {                                      // 16-pixel reduction blocks of the half-tile
+      const int ra = kb * 16 + 8 * lh + tr_q;                             // dy rows ra, ra+4
+      const u32x4 af = tr_read(ab, ra * 256 + (a_colb ^ ((ra & 3) << 6)), (ra + 4) * 256 + (a_colb ^ (((ra + 4) & 3) << 6)));
+      const int py = kb >> 1, px0 = (kb & 1) * 16;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int ty = t / 3, tx = t - ty * 3;
+        const int rb = (py + ty) * HW_HWD + px0 + tx + 8 * lh + tr_q;     // halo pixels rb, rb+4
+        const u32x4 bf = tr_read(bb, rb * 128 + (b_colb ^ (((rb >> 1) & 1) << 6)),
+                                 (rb + 4) * 128 + (b_colb ^ ((((rb + 4) >> 1) & 1) << 6)));
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf), acc[t], 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- two-stage ring over the half-tiles of this split: one barrier per half-tile (~4 600 cycles of MFMA) ----
+  const int nt = tend - tbeg;
+  if (nt > 0) {
+    issue(0, tbeg);
+    for (int it = 0; it < nt; ++it) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // my share of stage `it` has landed
+      __builtin_amdgcn_s_barrier();                                       // ... everyone's; compute(it-1) is done everywhere
+      if (it + 1 < nt) issue((it + 1) & 1, tbeg + it + 1);
+      compute(it & 1);
+    }
+  }
+
+  // ---- partial block -> this split's slab [Cout][9][Cs] (lanes run along ci: 128-byte segments) ----
+  float* slab = slabs + (size_t)split * slab_elems;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int co = c0 + cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      if (co < co_rows) slab[(size_t)co * g.K + t * g.Cs + ci0 + ib * 32 + lr] = acc[t][e];
+    }
+}
+
+// returns hipErrorNotSupported when the shape does not qualify (the caller falls through to wgrad_v2 / v1)
+hipError_t wgrad_halo(const GatherDesc& g, const void* src, const void* dy, int co_rows, int ldy, float* slabs,
+                      size_t slab_capacity_elems, int num_cu, int* nsplit_out, hipStream_t st) {
+  if (g.sh != 1 || g.sw != 1 || g.ys != 1 || g.xs != 1 || g.th != 3 || g.tw != 3) return hipErrorNotSupported;
+  if (g.Cs % 64 != 0 || g.Ho % HW_TH != 0 || g.Wo % HW_TW != 0 || co_rows < 96) return hipErrorNotSupported;
+  if ((long long)g.N * g.Hs * g.Ws * g.Cs >= (1ll << 31)) return hipErrorNotSupported;
+  const int nslices = g.Cs / 64, tiles_c = (co_rows + 127) / 128;
+  const int combos = nslices * tiles_c;
+  const int ntiles = g.N * (g.Ho / HW_TH) * (g.Wo / HW_TW);
+  int splits = std::max(1, num_cu / combos);                  // one workgroup per CU (119 KB LDS), a single round
+  if (splits > 8) splits -= splits % 8;                       // the combos of a split land on one XCD (linear id % 8)
+  if (splits > ntiles / 4) splits = std::max(1, ntiles / 4);
+  const long long slab_elems = (long long)co_rows * g.K;
+  if ((size_t)slab_elems * splits > slab_capacity_elems) splits = (int)(slab_capacity_elems / (size_t)slab_elems);
+  if (splits < 1) return hipErrorNotSupported;
+  if (combos * splits < num_cu / 2) return hipErrorNotSupported;      // too little parallelism: wgrad_v2 fills the chip better
+  const int tps = (ntiles + splits - 1) / splits;
+  const int zs = (ntiles + tps - 1) / tps;
+  const size_t lds = 2 * (size_t)HW_STAGE;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_halo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  prof_begin(PROF_WGRAD, 2.0 * (double)g.M * 9.0 * (double)g.Clog * (double)co_rows, st);
+  hipLaunchKernelGGL(wgrad_halo_kernel, dim3(zs, combos), dim3(512), lds, st, g, (const bf16_t*)src, (const bf16_t*)dy, co_rows, ldy,
+                     slabs, nslices, tps, slab_elems);
+  prof_end(PROF_WGRAD, st);
+  *nsplit_out = zs;
+  return hipGetLastError();
+}
+
+}  // namespace dei2i

@@ -66,6 +66,9 @@ CONV_CASES = [
     # fused-upsample case above take it too
     (128, 128, 3, 1, 1, True, False, 64, 32, 16, False, "none"),   # two 64-channel slices (halo double buffer), BN=128
     (64, 136, 3, 1, 1, False, False, 32, 64, 16, True, "relu"),    # zero boundary via the zero page, bias, ragged N tile
+    # halo-resident wgrad (bf16, stride-1 3x3, Cout >= 96, H % 4 == 0, W % 32 == 0, combos x splits >= 128)
+    (128, 256, 3, 1, 1, True, False, 16, 32, 16, False, "none"),   # 2 co tiles x 2 ci slices, 32 pixel splits of 2 half-tiles
+    (64, 160, 3, 1, 1, True, True, 8, 16, 16, False, "none"),      # fused upsample, ragged Cout (160 = 128 + 32)
 ]
 
 
