@@ -326,7 +326,7 @@ int dei2i_conv2d_wgrad_oihw(const dei2i_conv* c, const void* x, const void* dy, 
   GatherDesc g = make_fwd_desc(to_shape(c), c->CinS);
   if (c->dtype == DT_BF16 && g_use_wgrad_halo) {       // stride-1 3x3: (co, ci, 9 taps) block resident in registers
     int nsplit = 0;
-    hipError_t e = wgrad_halo(g, x, dy, c->Cout, c->CoutS, scratch, scratch_elems, num_cu(), &nsplit, st);
+    hipError_t e = wgrad_halo(g, x, dy, c->Cout, c->CoutS, scratch, scratch_elems, num_cu(), &nsplit, g_use_wgrad_halo == 2, st);
     if (e == hipSuccess)
       return (int)wgrad_reduce_unpack(scratch, nsplit, (long long)packed, dw_oihw, c->Cout, c->Cin, c->CinS, c->kh * c->kw, st);
     if (e != hipErrorNotSupported) return (int)e;

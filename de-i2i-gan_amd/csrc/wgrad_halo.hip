@@ -38,10 +38,17 @@ constexpr int HW_TH = 4, HW_TW = 32;                  // half-tile: 128 pixels
 constexpr int HW_HH = HW_TH + 2, HW_HWD = HW_TW + 2;  // 6 x 34 halo
 constexpr int HW_HPIX = HW_HH * HW_HWD;               // 204
 constexpr int HW_HGROUPS = 26;                        // 8-pixel DMA groups (208 >= 204)
-constexpr int HW_A_BYTES = 128 * 256;                 // dy tile: 128 px x 128 co
-constexpr int HW_B_BYTES = HW_HGROUPS * 8 * 128;      // halo: 208 px x 64 ci
-constexpr int HW_STAGE = HW_A_BYTES + HW_B_BYTES;     // 59,392
+constexpr int HW_HPAD = HW_HGROUPS * 8;                // 208 halo pixel rows per stage
 
+// 256-byte rows: spread 4 consecutive rows over the four 64-byte quarters; 128-byte rows: rows r and r+2 alias, flip
+// the 64-byte half (the tr-read swizzles of conv_gemm.hip)
+template <int ROWB> DEI2I_D int hw_swz(int row) {
+  if constexpr (ROWB == 256) return (row & 3) << 6;
+  else return ((row >> 1) & 1) << 6;
+}
+
+// BCO x BCI = 128 x 64 (Cout >= 96) or 64 x 128 (Cout <= 64): 8 waves = (BCO/32) x (BCI/32) blocks, 9 taps each
+template <int BCO, int BCI>
 __global__ __launch_bounds__(512) void wgrad_halo_kernel(const GatherDesc g, const bf16_t* __restrict__ src,
                                                          const bf16_t* __restrict__ dy, const int co_rows, const int ldy,
                                                          float* __restrict__ slabs, const int nslices, const int tiles_per_split,
@@ -49,11 +56,19 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const GatherDesc g, con
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cb = wave >> 1, ib = wave & 1;            // 32-channel block of co / of ci
+  constexpr int NIB = BCI / 32;
+  static_assert((BCO / 32) * NIB == 8, "8 waves");
+  constexpr int ROWB_A = BCO * 2, ROWB_B = BCI * 2;
+  constexpr int HW_A_BYTES = 128 * ROWB_A, HW_B_BYTES = HW_HPAD * ROWB_B, HW_STAGE = HW_A_BYTES + HW_B_BYTES;
+  constexpr int RPI_A = 1024 / ROWB_A, SPR_A = ROWB_A / 16;      // dy rows per DMA instruction, 16-byte slots per row
+  constexpr int RPI_B = 1024 / ROWB_B, SPR_B = ROWB_B / 16;
+  constexpr int NA = 128 / RPI_A / 8, NB = (HW_HPAD / RPI_B + 7) / 8;   // DMA instructions per wave per half-tile
+  constexpr int GROUPS_B = HW_HPAD / RPI_B;
+  const int cb = wave / NIB, ib = wave % NIB;         // 32-channel block of co / of ci
 
   const int combo = blockIdx.y, split = blockIdx.x;
   const int tile_c = combo / nslices, slice = combo - tile_c * nslices;
-  const int c0 = tile_c * 128, ci0 = slice << 6;
+  const int c0 = tile_c * BCO, ci0 = slice * BCI;
 
   const int tiles_x = g.Wo / HW_TW, tiles_y = g.Ho / HW_TH;
   const int tiles_img = tiles_x * tiles_y;
@@ -73,22 +88,22 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const GatherDesc g, con
     const int ty = rem / tiles_x;
     const int y0 = ty * HW_TH, x0 = (rem - ty * tiles_x) * HW_TW;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int rgrp = (j * 8 + wave) * 4;
-      const int r = rgrp + (lane >> 4);                                   // pixel of the half-tile: (r>>5, r&31)
-      const int off = ((lane & 15) * 16) ^ ((r & 3) << 6);               // source byte offset that belongs at this slot
+    for (int j = 0; j < NA; ++j) {
+      const int rgrp = (j * 8 + wave) * RPI_A;
+      const int r = rgrp + lane / SPR_A;                                  // pixel of the half-tile: (r>>5, r&31)
+      const int off = ((lane % SPR_A) * 16) ^ hw_swz<ROWB_A>(r);          // source byte offset that belongs at this slot
       const int c = c0 + (off >> 1);
       const size_t pix = ((size_t)img * g.Ho + y0 + (r >> 5)) * g.Wo + x0 + (r & 31);
       const bf16_t* p = c < ldy ? dy + pix * ldy + c : zero;
-      glds16hw(p, sa + rgrp * 256);
+      glds16hw(p, sa + rgrp * ROWB_A);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NB; ++j) {
       int grp = j * 8 + wave;
-      if (grp >= HW_HGROUPS) grp -= HW_HGROUPS;                           // surplus slots re-fetch groups 0..5
-      const int hp = grp * 8 + (lane >> 3);
+      if (grp >= GROUPS_B) grp -= GROUPS_B;                               // surplus slots re-fetch the first groups
+      const int hp = grp * RPI_B + lane / SPR_B;
       const int hy = hp / HW_HWD, hx = hp - hy * HW_HWD;
-      const int off = ((lane & 7) * 16) ^ (((hp >> 1) & 1) << 6);
+      const int off = ((lane % SPR_B) * 16) ^ hw_swz<ROWB_B>(hp);
       const bf16_t* p = zero;
       if (hp < HW_HPIX) {
         const int y = bound_coord(y0 + g.by0 + hy, g.Hl, g.pad_mode);
@@ -108,8 +123,8 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const GatherDesc g, con
   const int lr = lane & 31, lh = lane >> 5;
   // transposed-read lane roles (ds_read_b64_tr_b16): lane i = 4q+p of a 16-lane group supplies row q, cols 4p..4p+3
   const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_half = (lane >> 4) & 1;
-  const int a_colb = (cb * 32 + 16 * tr_half + 4 * tr_p) * 2;           // byte column in a 256-byte dy row
-  const int b_colb = (ib * 32 + 16 * tr_half + 4 * tr_p) * 2;           // byte column in a 128-byte halo row
+  const int a_colb = (cb * 32 + 16 * tr_half + 4 * tr_p) * 2;           // byte column in a dy row
+  const int b_colb = (ib * 32 + 16 * tr_half + 4 * tr_p) * 2;           // byte column in a halo row
 
   auto tr_read = [&](const unsigned char* base, int o0, int o1) {
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + o0));
@@ -126,14 +141,13 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const GatherDesc g, con
 #pragma unroll 2
     for (int kb = 0; kb < 8; ++kb) {                                      // 16-pixel reduction blocks of the half-tile
       const int ra = kb * 16 + 8 * lh + tr_q;                             // dy rows ra, ra+4
-      const u32x4 af = tr_read(ab, ra * 256 + (a_colb ^ ((ra & 3) << 6)), (ra + 4) * 256 + (a_colb ^ (((ra + 4) & 3) << 6)));
+      const u32x4 af = tr_read(ab, ra * ROWB_A + (a_colb ^ hw_swz<ROWB_A>(ra)), (ra + 4) * ROWB_A + (a_colb ^ hw_swz<ROWB_A>(ra + 4)));
       const int py = kb >> 1, px0 = (kb & 1) * 16;
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int ty = t / 3, tx = t - ty * 3;
         const int rb = (py + ty) * HW_HWD + px0 + tx + 8 * lh + tr_q;     // halo pixels rb, rb+4
-        const u32x4 bf = tr_read(bb, rb * 128 + (b_colb ^ (((rb >> 1) & 1) << 6)),
-                                 (rb + 4) * 128 + (b_colb ^ ((((rb + 4) >> 1) & 1) << 6)));
+        const u32x4 bf = tr_read(bb, rb * ROWB_B + (b_colb ^ hw_swz<ROWB_B>(rb)), (rb + 4) * ROWB_B + (b_colb ^ hw_swz<ROWB_B>(rb + 4)));
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf), acc[t], 0, 0, 0);
       }
     }
@@ -162,37 +176,49 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const GatherDesc g, con
     }
 }
 
-// returns hipErrorNotSupported when the shape does not qualify (the caller falls through to wgrad_v2 / v1)
-hipError_t wgrad_halo(const GatherDesc& g, const void* src, const void* dy, int co_rows, int ldy, float* slabs,
-                      size_t slab_capacity_elems, int num_cu, int* nsplit_out, hipStream_t st) {
-  if (g.sh != 1 || g.sw != 1 || g.ys != 1 || g.xs != 1 || g.th != 3 || g.tw != 3) return hipErrorNotSupported;
-  if (g.Cs % 64 != 0 || g.Ho % HW_TH != 0 || g.Wo % HW_TW != 0 || co_rows < 96) return hipErrorNotSupported;
-  if ((long long)g.N * g.Hs * g.Ws * g.Cs >= (1ll << 31)) return hipErrorNotSupported;
-  const int nslices = g.Cs / 64, tiles_c = (co_rows + 127) / 128;
+template <int BCO, int BCI>
+static hipError_t launch_wgrad_halo(const GatherDesc& g, const void* src, const void* dy, int co_rows, int ldy, float* slabs,
+                                    size_t slab_capacity_elems, int num_cu, int* nsplit_out, bool force, hipStream_t st) {
+  const int nslices = g.Cs / BCI, tiles_c = (co_rows + BCO - 1) / BCO;
   const int combos = nslices * tiles_c;
   const int ntiles = g.N * (g.Ho / HW_TH) * (g.Wo / HW_TW);
-  int splits = std::max(1, num_cu / combos);                  // one workgroup per CU (119 KB LDS), a single round
+  int splits = std::max(1, num_cu / combos);                  // one workgroup per CU, a single round
   if (splits > 8) splits -= splits % 8;                       // the combos of a split land on one XCD (linear id % 8)
   if (splits > ntiles / 4) splits = std::max(1, ntiles / 4);
   const long long slab_elems = (long long)co_rows * g.K;
   if ((size_t)slab_elems * splits > slab_capacity_elems) splits = (int)(slab_capacity_elems / (size_t)slab_elems);
   if (splits < 1) return hipErrorNotSupported;
-  if (combos * splits < num_cu / 2) return hipErrorNotSupported;      // too little parallelism: wgrad_v2 fills the chip better
+  if (!force && combos * splits < (num_cu * 3) / 4) return hipErrorNotSupported;   // too little parallelism: wgrad_v2 / v1 fill the chip better
   const int tps = (ntiles + splits - 1) / splits;
   const int zs = (ntiles + tps - 1) / tps;
-  const size_t lds = 2 * (size_t)HW_STAGE;
+  const size_t lds = 2 * (size_t)(128 * BCO * 2 + HW_HPAD * BCI * 2);
+  auto kern = wgrad_halo_kernel<BCO, BCI>;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_halo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
   prof_begin(PROF_WGRAD, 2.0 * (double)g.M * 9.0 * (double)g.Clog * (double)co_rows, st);
-  hipLaunchKernelGGL(wgrad_halo_kernel, dim3(zs, combos), dim3(512), lds, st, g, (const bf16_t*)src, (const bf16_t*)dy, co_rows, ldy,
-                     slabs, nslices, tps, slab_elems);
+  hipLaunchKernelGGL(kern, dim3(zs, combos), dim3(512), lds, st, g, (const bf16_t*)src, (const bf16_t*)dy, co_rows, ldy, slabs,
+                     nslices, tps, slab_elems);
   prof_end(PROF_WGRAD, st);
   *nsplit_out = zs;
   return hipGetLastError();
+}
+
+// returns hipErrorNotSupported when the shape does not qualify (the caller falls through to wgrad_v2 / v1)
+hipError_t wgrad_halo(const GatherDesc& g, const void* src, const void* dy, int co_rows, int ldy, float* slabs,
+                      size_t slab_capacity_elems, int num_cu, int* nsplit_out, bool force, hipStream_t st) {
+  if (g.sh != 1 || g.sw != 1 || g.ys != 1 || g.xs != 1 || g.th != 3 || g.tw != 3) return hipErrorNotSupported;
+  if (g.Ho % HW_TH != 0 || g.Wo % HW_TW != 0 || co_rows < 48) return hipErrorNotSupported;
+  if ((long long)g.N * g.Hs * g.Ws * g.Cs >= (1ll << 31)) return hipErrorNotSupported;
+  if (co_rows <= 64) {
+    if (g.Cs % 128 != 0) return hipErrorNotSupported;
+    return launch_wgrad_halo<64, 128>(g, src, dy, co_rows, ldy, slabs, slab_capacity_elems, num_cu, nsplit_out, force, st);
+  }
+  if (g.Cs % 64 != 0 || co_rows < 96) return hipErrorNotSupported;
+  return launch_wgrad_halo<128, 64>(g, src, dy, co_rows, ldy, slabs, slab_capacity_elems, num_cu, nsplit_out, force, st);
 }
 
 }  // namespace dei2i

@@ -186,22 +186,35 @@ __global__ __launch_bounds__(512) void wgrad_v2_kernel(const GatherDesc g, const
 // dw_oihw[co][ci][t] = sum_s slab[s][co][t][ci]  (slab reduce fused with the un-pack to the reference's OIHW layout)
 __global__ void wgrad_reduce_unpack_kernel(const float* __restrict__ slabs, int nsplit, long long slab_elems,
                                            float* __restrict__ dw, int Cout, int Cin, int CinS, int taps) {
-  // walk the PACKED index (ci fastest) so the nsplit slab reads are coalesced; the single OIHW write is the strided one
-  const size_t total = (size_t)Cout * taps * CinS;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+  // walk the PACKED index four channels at a time (ci fastest: the nsplit slab reads are coalesced 16-byte loads, four
+  // slabs in flight per thread); the single OIHW write is the strided one
+  const size_t total4 = (size_t)Cout * taps * CinS / 4;
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += (size_t)gridDim.x * blockDim.x) {
+    const size_t i = q * 4;
     const int ci = (int)(i % CinS);
     if (ci >= Cin) continue;
     const size_t r = i / CinS;
     const int t = (int)(r % taps);
     const size_t co = r / taps;
-    float v = 0.f;
-    for (int s = 0; s < nsplit; ++s) v += slabs[(size_t)s * slab_elems + i];
-    dw[(co * Cin + ci) * taps + t] = v;
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0, v3 = v0;
+    const float* p = slabs + i;
+    int s = 0;
+    for (; s + 3 < nsplit; s += 4) {
+      v0 += *reinterpret_cast<const f32x4*>(p + (size_t)s * slab_elems);
+      v1 += *reinterpret_cast<const f32x4*>(p + (size_t)(s + 1) * slab_elems);
+      v2 += *reinterpret_cast<const f32x4*>(p + (size_t)(s + 2) * slab_elems);
+      v3 += *reinterpret_cast<const f32x4*>(p + (size_t)(s + 3) * slab_elems);
+    }
+    for (; s < nsplit; ++s) v0 += *reinterpret_cast<const f32x4*>(p + (size_t)s * slab_elems);
+    const f32x4 v = (v0 + v1) + (v2 + v3);
+    float* o = dw + (co * Cin + ci) * taps + t;
+    o[0] = v.x;
+    if (ci + 1 < Cin) o[taps] = v.y;
+    if (ci + 2 < Cin) o[2 * (size_t)taps] = v.z;
+    if (ci + 3 < Cin) o[3 * (size_t)taps] = v.w;
   }
 }
 
-// Returns hipErrorNotSupported when the shape does not qualify.  On success *nsplit_out slabs of co_rows*K floats hold
-// the partial sums (caller reduces with wgrad_reduce_unpack).
 hipError_t wgrad_v2(const GatherDesc& g, const void* src, const void* dy, int co_rows, int ldy, float* slabs,
                     size_t slab_capacity_elems, int num_cu, int* nsplit_out, hipStream_t st) {
   if (g.Cs % 128 != 0 || co_rows < 96 || g.M < 4096) return hipErrorNotSupported;
@@ -248,7 +261,7 @@ hipError_t wgrad_v2(const GatherDesc& g, const void* src, const void* dy, int co
 
 hipError_t wgrad_reduce_unpack(const float* slabs, int nsplit, long long slab_elems, float* dw, int Cout, int Cin, int CinS,
                                int taps, hipStream_t st) {
-  const size_t total = (size_t)Cout * CinS * taps;
+  const size_t total = (size_t)Cout * CinS * taps / 4;
   hipLaunchKernelGGL(wgrad_reduce_unpack_kernel, dim3(grid_for(total, 256, 256u * 8u)), dim3(256), 0, st, slabs, nsplit,
                      slab_elems, dw, Cout, Cin, CinS, taps);
   return hipGetLastError();

@@ -207,7 +207,8 @@ class _Conv2d(torch.autograd.Function):
                     "conv2d_dgrad_input")
         if ctx.needs_input_grad[1]:
             packed = lib.dei2i_packed_fwd_elems(byref(d))
-            scratch = _workspace(x.device, max(packed * 4, min(packed * 4 * 64, 512 << 20)), slot="wgrad")   # up to 64 partial slabs
+            # partial slabs: up to 64, or as many as fit 96 MB (a (co, ci, 9-tap) register block per CU is 256 x 295 KB)
+            scratch = _workspace(x.device, max(packed * 4, min(max(packed * 4 * 64, 96 << 20), 512 << 20)), slot="wgrad")
             dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
             L.check(lib.dei2i_conv2d_wgrad_oihw(byref(d), _p(x), _p(g), _p(scratch), scratch.numel(), _p(dw), st),
                     "conv2d_wgrad")

@@ -69,14 +69,21 @@ CONV_CASES = [
     # halo-resident wgrad (bf16, stride-1 3x3, Cout >= 96, H % 4 == 0, W % 32 == 0, combos x splits >= 128)
     (128, 256, 3, 1, 1, True, False, 16, 32, 16, False, "none"),   # 2 co tiles x 2 ci slices, 32 pixel splits of 2 half-tiles
     (64, 160, 3, 1, 1, True, True, 8, 16, 16, False, "none"),      # fused upsample, ragged Cout (160 = 128 + 32)
+    (128, 64, 3, 1, 1, True, False, 16, 32, 8, False, "none"),     # 64 co x 128 ci variant (forced: see FORCE_WGRAD_HALO)
+    (256, 48, 3, 1, 1, False, False, 8, 32, 4, False, "none"),     # the same with ragged Cout and zero padding
 ]
+FORCE_WGRAD_HALO = {(128, 64, 3, 1, 1, True, False, 16, 32, 8, False, "none"), (256, 48, 3, 1, 1, False, False, 8, 32, 4, False, "none")}
 
 
 @pytest.mark.parametrize("pname", ["f32", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv2d_fwd_bwd(ops, pname, case):
+def test_conv2d_fwd_bwd(ops, pname, case, request):
     cin, cout, k, s, pad, reflect, up, H, W, N, has_bias, act = case
     prec = ops.get_precision(pname)
+    if case in FORCE_WGRAD_HALO:         # small shapes normally stay on wgrad_v2 / v1 (too few workgroups): force the kernel
+        from de_i2i_gan_amd import _lib
+        _lib.load().dei2i_set_option(b"wgrad_halo", 2)
+        request.addfinalizer(lambda: _lib.load().dei2i_set_option(b"wgrad_halo", 1))
     torch.manual_seed(hash(case) % 1000)
     x = torch.randn(N, cin, H, W)
     w = torch.randn(cout, cin, k, k) * math.sqrt(2.0 / (cin * k * k))
