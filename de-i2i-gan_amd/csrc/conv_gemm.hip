@@ -517,6 +517,8 @@ static int g_use_v2 = 1;
 void set_use_v2(int on) { g_use_v2 = on; }
 static int g_use_halo = 1;
 void set_use_halo(int on) { g_use_halo = on; }
+static int g_use_thin = 1;
+void set_use_thin(int on) { g_use_thin = on; }
 
 template <typename T, int BM, int BN, int WM, int WN>
 static hipError_t launch_gg(const DescPack& pack, const void* src, const void* wgt, int wrows, const float* bias,
@@ -623,6 +625,10 @@ hipError_t gather_gemm_multi(int dtype, const GatherDesc* descs, const long long
   if (pack.n == 0) return hipSuccess;
   for (int i = pack.n; i < 4; ++i) { pack.d[i] = pack.d[0]; pack.woff[i] = 0; pack.fd_taps[i] = pack.fd_taps[0]; pack.m_base[i] = 0; }
   if (dtype == DT_BF16) {
+    if (g_use_thin && pack.n == 1) {      // 8-channel inputs (stem, D's first conv, heads dgrad): thin_conv.hip
+      hipError_t e = thin_cin_conv(pack.d[0], src, (const bf16_t*)wgt + pack.woff[0], wrows, bias, out, ldc, act, g_num_cu, st);
+      if (e != hipErrorNotSupported) return e;
+    }
     if (g_use_halo && pack.n == 1) {      // stride-1 3x3 layers: halo-resident kernel (conv_halo.hip)
       hipError_t e = halo_conv(pack.d[0], src, (const bf16_t*)wgt + pack.woff[0],
                                wrows, bias, out, ldc, act, g_num_cu, st);

@@ -40,9 +40,10 @@ def timeit(fn, iters=10):
 def main():
     prec = ops.get_precision(sys.argv[1] if len(sys.argv) > 1 else "bf16")
     only = sys.argv[2] if len(sys.argv) > 2 else None
-    if len(sys.argv) > 3:
+    for kv in sys.argv[3:]:                      # library options for same-box A/B runs: name=int
         from de_i2i_gan_amd import _lib
-        _lib.load().dei2i_set_option(b"v2_ablate", int(sys.argv[3]))
+        name, val = kv.split("=") if "=" in kv else ("v2_ablate", kv)
+        _lib.load().dei2i_set_option(name.encode(), int(val))
     for name, cin, cout, k, s, pad, refl, up, H, N in SHAPES:
         if only and only not in name:
             continue

@@ -72,6 +72,12 @@ CONV_CASES = [
     (128, 64, 3, 1, 1, True, False, 16, 32, 8, False, "none"),     # 64 co x 128 ci variant (forced: see FORCE_WGRAD_HALO)
     (256, 48, 3, 1, 1, False, False, 8, 32, 4, False, "none"),     # the same with ragged Cout and zero padding
 ]
+CONV_CASES += [
+    # thin-input kernel (bf16, 8-channel source vectors, <= 64 outputs, >= 256 tiles of 8x32 pixels)
+    (3, 64, 7, 1, 3, True, False, 128, 128, 4, False, "none"),          # generator stem
+    (3, 64, 4, 2, 1, True, False, 256, 128, 8, True, "leaky_relu"),     # discriminator's first conv: stride 2, bias, LReLU
+    (64, 4, 3, 1, 1, True, False, 128, 128, 4, False, "none"),          # heads: the interior dgrad (dY has 8 channels)
+]
 FORCE_WGRAD_HALO = {(128, 64, 3, 1, 1, True, False, 16, 32, 8, False, "none"), (256, 48, 3, 1, 1, False, False, 8, 32, 4, False, "none")}
 
 
