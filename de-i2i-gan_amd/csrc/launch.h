@@ -30,6 +30,8 @@ hipError_t gather_gemm_v2(const DescPack& pack, const void* src, const void* wgt
 int num_cu();
 void set_use_halo(int on);
 void set_use_thin(int on);
+hipError_t thin_cout_conv(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out, int ldc,
+                          int act, int num_cu, hipStream_t st);
 hipError_t thin_cin_conv(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out, int ldc,
                          int act, int num_cu, hipStream_t st);
 hipError_t halo_conv(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out, int ldc,

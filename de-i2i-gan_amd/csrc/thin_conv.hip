@@ -213,4 +213,157 @@ hipError_t thin_cin_conv(const GatherDesc& g, const void* src, const void* wgt, 
   return hipErrorNotSupported;
 }
 
+
+// =====================================================================================================================
+// Thin-OUTPUT convs (bf16, 64-channel source, <= 8 output channels): the generator heads (64 -> 4, 3x3) and the
+// interior dgrad of the stem (dY 64 channels -> dX 3(8), 7x7).  The work is the 134 MB input stream plus, for the 7x7,
+// 3 136 MACs per output value; on the gather GEMMs the 8-wide output wastes a 32-column tile and every 256-pixel tile
+// pays its own pipeline fill (measured 130 us / 570 us).  Persistent workgroups walk 8 x 32 pixel tiles, ONE barrier per
+// tile: the 64-channel input halo of tile t+1 ((8+th-1) x (32+tw-1) pixels x 128 B, double-buffered) arrives by LDS-DMA
+// while tile t computes; the 8 weight rows live in LDS.  The MFMA runs transposed (A = weights, rows >= 8 read a zero
+// row; B = pixels): D[channel][pixel] leaves each lane with 4 consecutive channels of its pixel in 4 registers, so the
+// result goes straight to memory as 8-byte stores -- a wave writes 32 pixels x 16 B = 512 contiguous bytes.
+// =====================================================================================================================
+constexpr int TO_MAXCO = 8;
+
+__global__ __launch_bounds__(512) void thin_cout_conv_kernel(const GatherDesc g, const bf16_t* __restrict__ src,
+                                                             const bf16_t* __restrict__ wgt, const int wrows,
+                                                             const float* __restrict__ bias, bf16_t* __restrict__ out,
+                                                             const int ldc, const int act, const int ntiles, const int halo_bytes,
+                                                             const int nbuf) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const halo = smem;                                  // [nbuf][halo_bytes], 128-byte pixel rows, XOR-swizzled
+  unsigned char* const wl = smem + nbuf * halo_bytes;                   // [9 rows][K*2 B]: 8 weight rows + one zero row
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // tile row of this wave
+  const int lr = lane & 31, lh = lane >> 5;
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_thin);
+  const int ntaps = g.th * g.tw;
+  const int wrow_bytes = g.K * 2;
+
+  for (int i = tid; i < (TO_MAXCO + 1) * (wrow_bytes >> 4); i += 512) {
+    const int row = i / (wrow_bytes >> 4), ch = i - row * (wrow_bytes >> 4);
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row < wrows) v = *reinterpret_cast<const u32x4*>(wgt + (size_t)row * g.K + ch * 8);
+    *reinterpret_cast<u32x4*>(wl + row * wrow_bytes + ch * 16) = v;
+  }
+
+  const int hwd = TC_TW + g.tw - 1, hht = TC_TH + g.th - 1;
+  const int npix = hwd * hht;
+  const int ngroups = (npix + 7) >> 3;                               // 8-pixel LDS-DMA groups
+  const int tiles_x = g.Wo / TC_TW, tiles_y = g.Ho / TC_TH;
+  const int tiles_img = tiles_x * tiles_y;
+
+  auto issue_halo = [&](int buf, int t) {
+    const int img = t / tiles_img;
+    const int rem = t - img * tiles_img;
+    const int ty = rem / tiles_x;
+    const int hy0 = ty * TC_TH + g.by0 + (g.ys < 0 ? -(g.th - 1) : 0);
+    const int hx0 = (rem - ty * tiles_x) * TC_TW + g.bx0 + (g.xs < 0 ? -(g.tw - 1) : 0);
+    for (int grp = wave; grp < ngroups; grp += 8) {                  // wave-uniform trip count
+      const int p = grp * 8 + (lane >> 3);
+      const bf16_t* ptr = zero;
+      if (p < npix) {
+        const int hy = p / hwd, hx = p - hy * hwd;
+        const int y = bound_coord(hy0 + hy, g.Hl, g.pad_mode);
+        const int x = bound_coord(hx0 + hx, g.Wl, g.pad_mode);
+        if ((y | x) >= 0)
+          ptr = src + ((size_t)((img * g.Hs + (y >> g.up)) * g.Ws + (x >> g.up))) * 64 + (((lane & 7) ^ ((p >> 1) & 7)) << 3);
+      }
+      glds16tc(ptr, halo + buf * halo_bytes + grp * 1024);
+    }
+  };
+
+  // weight fragment address of this lane: row lr (rows >= 8 -> the zero row), 8 channels at k = 16*kblock + 8*lh
+  const unsigned char* const wbase = wl + (lr < TO_MAXCO ? lr : TO_MAXCO) * wrow_bytes + lh * 16;
+  const int pix0 = (wave + (g.ys < 0 ? g.th - 1 : 0)) * hwd + lr + (g.xs < 0 ? g.tw - 1 : 0);
+  const int step_x = g.xs > 0 ? 1 : -1, step_y = g.ys > 0 ? hwd : -hwd;
+  float bv[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) bv[k] = (bias != nullptr && 4 * lh + k < wrows) ? bias[4 * lh + k] : 0.f;
+
+  int t = blockIdx.x;
+  if (t < ntiles && nbuf == 2) issue_halo(0, t);
+  for (int it = 0; t < ntiles; ++it) {
+    const int tn = t + gridDim.x;
+    const unsigned char* hb = halo;
+    if (nbuf == 2) {                                                 // halo of tile t+1 streams in under tile t
+      if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (one output store per tile stays in flight)
+      else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      __syncthreads();
+      if (tn < ntiles) issue_halo((it + 1) & 1, tn);
+      hb = halo + (it & 1) * halo_bytes;
+    } else {                                                         // 7x7: one 67 KB halo buffer next to 56 KB of weights
+      __syncthreads();                                               // everyone is done with the previous tile
+      issue_halo(0, t);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    int ty = 0, tx = 0;                                              // wave-uniform tap walk
+    for (int tap = 0; tap < ntaps; ++tap) {
+      const int pix = pix0 + ty * step_y + tx * step_x;
+      const unsigned char* pa = hb + pix * 128;
+      const int sw = (pix >> 1) & 7;
+      const unsigned char* wa = wbase + tap * 128;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const u32x4 w = *reinterpret_cast<const u32x4*>(wa + ks * 32);
+        const u32x4 a = *reinterpret_cast<const u32x4*>(pa + (((ks * 2 + lh) ^ sw) << 4));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
+      }
+      if (++tx == g.tw) { tx = 0; ++ty; }
+    }
+
+    // D row = channel (e&3) + 8(e>>2) + 4lh, col = pixel lr: registers 0..3 are channels 4lh .. 4lh+3 of pixel lr
+    {
+      const int img = t / tiles_img;
+      const int rem = t - img * tiles_img;
+      const int tyi = rem / tiles_x;
+      const size_t opix = (size_t)out_pixel(g, img, tyi * TC_TH + wave, (rem - tyi * tiles_x) * TC_TW + lr);
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = 4 * lh + k < wrows ? apply_act(acc[k] + bv[k], act) : 0.f;
+      u32x2 pk;
+      pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+      pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+      *reinterpret_cast<u32x2*>(out + opix * ldc + 4 * lh) = pk;
+    }
+    t = tn;
+  }
+}
+
+// returns hipErrorNotSupported when the shape does not qualify (the caller falls through to the gather GEMMs)
+hipError_t thin_cout_conv(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out, int ldc,
+                          int act, int num_cu, hipStream_t st) {
+  if (g.Cs != 64 || wrows > TO_MAXCO || ldc != 8) return hipErrorNotSupported;
+  if ((g.ys != 1 && g.ys != -1) || (g.xs != 1 && g.xs != -1) || g.sh != 1 || g.sw != 1) return hipErrorNotSupported;
+  if (g.Ho % TC_TH != 0 || g.Wo % TC_TW != 0 || g.M != g.N * g.Ho * g.Wo) return hipErrorNotSupported;
+  if ((long long)g.N * g.Hs * g.Ws * 64 >= (1ll << 31)) return hipErrorNotSupported;
+  const int ntiles = g.N * (g.Ho / TC_TH) * (g.Wo / TC_TW);
+  if (ntiles < num_cu) return hipErrorNotSupported;
+  const int hwd = TC_TW + g.tw - 1, hht = TC_TH + g.th - 1;
+  const int halo_bytes = ((hwd * hht + 7) / 8) * 1024;
+  const size_t wbytes = (size_t)(TO_MAXCO + 1) * g.K * 2;
+  int nbuf = 2;
+  if (2 * (size_t)halo_bytes + wbytes > 160 * 1024) nbuf = 1;
+  const size_t lds = nbuf * (size_t)halo_bytes + wbytes;
+  if (lds > 160 * 1024) return hipErrorNotSupported;
+  static size_t lds_set = 0;
+  if (lds > lds_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(thin_cout_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    lds_set = lds;
+  }
+  prof_begin(PROF_GATHER_GEMM, 2.0 * (double)g.M * (double)(g.th * g.tw) * (double)g.Clog * (double)wrows, st);
+  hipLaunchKernelGGL(thin_cout_conv_kernel, dim3(std::min(ntiles, num_cu)), dim3(512), lds, st, g, (const bf16_t*)src,
+                     (const bf16_t*)wgt, wrows, bias, (bf16_t*)out, ldc, act, ntiles, halo_bytes, nbuf);
+  prof_end(PROF_GATHER_GEMM, st);
+  return hipGetLastError();
+}
+
 }  // namespace dei2i
