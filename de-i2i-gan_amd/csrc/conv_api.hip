@@ -227,7 +227,11 @@ size_t dei2i_conv2d_workspace_bytes(const dei2i_conv* c) {
   dei2i_conv2d_out_shape(c, &Ho, &Wo);
   dei2i_conv2d_dgrad_shape(c, &OH, &OW);
   const size_t f = (size_t)c->N * Ho * Wo * c->CoutS, d = (size_t)c->N * OH * OW * c->CinS;
-  return (f > d ? f : d) * sizeof(float);
+  // split-K slices write one fp32 slab each: room for 16 slabs, but no more than 64 MB beyond a single slab (layers
+  // with large outputs have enough tiles to fill the chip without split-K)
+  const size_t one = (f > d ? f : d) * sizeof(float);
+  const size_t many = one * 16, cap = one > ((size_t)64 << 20) ? one : ((size_t)64 << 20);
+  return many < cap ? many : cap;
 }
 
 int dei2i_conv2d_fwd(const dei2i_conv* c, const void* x, const void* w_packed, const float* bias, int act, void* y, float* ws,

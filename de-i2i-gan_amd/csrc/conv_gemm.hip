@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const DescPack pack, c
                                                           const T* __restrict__ wgt_base, const int wrows,
                                                           const float* __restrict__ bias, T* __restrict__ out,
                                                           float* __restrict__ ws, const int ldc, const int act,
-                                                          const int tiles_n, const int ksteps_per_split) {
+                                                          const int tiles_n, const int ksteps_per_split, const int slab_rows) {
   constexpr int VEC = Elem<T>::VEC;
   constexpr int BKE = 128 / (int)sizeof(T);      // k elements per 128-byte LDS row
   constexpr int RA = BM / 32, RB = BN / 32;      // 16-byte vectors per thread per k-step
@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const DescPack pack, c
   const int nk_total = (g.K + BKE - 1) / BKE;
   const int kbeg = blockIdx.z * ksteps_per_split;
   const int kend = min(nk_total, kbeg + ksteps_per_split);
-  if (kbeg >= kend) return;
+  const bool empty = kbeg >= kend;        // a split-K slice past this class's K: it still owns (zero) slab rows
+  if (empty && ws == nullptr) return;
 
   // ---- per-thread load assignment ----
   const int kv = tid & 7;       // 16-byte chunk within the 128-byte k-row
@@ -208,25 +209,25 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const DescPack pack, c
   };
 
   // ---- main loop: register-staged, double-buffered LDS, one barrier per k-step ----
-  load_tile(kbeg);
-  bool live_cur = tap_live, any_live = false;
-  if (live_cur) store_tile(0);
-  __syncthreads();
-  int buf = 0;
-  for (int ks = kbeg; ks < kend; ++ks) {
-    const bool more = ks + 1 < kend;
-    if (more) load_tile(ks + 1);          // global loads in flight under the MFMAs
-    const bool live_next = more && tap_live;
-    any_live |= live_cur;
-    if (live_cur) compute_tile(buf);
-    if (live_next) store_tile(buf ^ 1);
+  if (!empty) {
+    load_tile(kbeg);
+    bool live_cur = tap_live;
+    if (live_cur) store_tile(0);
     __syncthreads();
-    buf ^= 1;
-    live_cur = live_next;
+    int buf = 0;
+    for (int ks = kbeg; ks < kend; ++ks) {
+      const bool more = ks + 1 < kend;
+      if (more) load_tile(ks + 1);          // global loads in flight under the MFMAs
+      const bool live_next = more && tap_live;
+      if (live_cur) compute_tile(buf);
+      if (live_next) store_tile(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+      live_cur = live_next;
+    }
   }
 
   // ---- epilogue: D[i][j], j = lane&31 (output channel), i = (e&3) + 8*(e>>2) + 4*(lane>>5) (pixel) ----
-  if (!any_live && ws != nullptr) return;       // a split-K slice of dead taps adds nothing
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -246,9 +247,12 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const DescPack pack, c
         const int n = n0 + wn * WTN + j * 32 + lr;
         if (n >= ldc) continue;
         float v = acc[i][j][e];
-        if (ws != nullptr) {
-          const size_t wpix = pack.ws_compact ? (size_t)(pack.m_base[blockIdx.y] + m) : opix;
-          if (n < wrows) atomicAdd(ws + wpix * ldc + n, v);
+        if (ws != nullptr) {       // split-K: this slice's fp32 slab, rows indexed by (class base + m); plain stores
+          const size_t wrow = (size_t)(pack.m_base[blockIdx.y] + m);
+          if (n < wrows) {
+            if (pack.ws_atomic) atomicAdd(ws + wrow * ldc + n, v);
+            else ws[((size_t)blockIdx.z * slab_rows + wrow) * ldc + n] = v;
+          }
         } else {
           if (n < wrows) {
             if (bias != nullptr) v += bias[n];
@@ -263,32 +267,15 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const DescPack pack, c
   }
 }
 
-// split-K finalize: out = act(ws + bias) over the whole (pixels, ldc) output, padded channels forced to 0
+// split-K finalize: out = act(sum over slices of slab[z] + bias).  Slab row r belongs to class k
+// (m_base[k] <= r < m_base[k+1]), local row m = r - m_base[k]; only the output pixels the classes cover are written
+// (all of them for a conv / dgrad frame; the reflect ring for a ring launch).  Padded channels are forced to 0.
 template <typename T>
-__global__ void splitk_finalize_kernel(const float* __restrict__ ws, const float* __restrict__ bias, T* __restrict__ out,
-                                       size_t total, int ldc, int co, int act) {
+__global__ void splitk_finalize_kernel(const DescPack pack, const float* __restrict__ ws, const int zs, const size_t slab_elems,
+                                       const float* __restrict__ bias, T* __restrict__ out, int ldc, int co, int act) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; i < total; i += stride) {
-    const int c = (int)(i % (size_t)ldc);
-    float v = 0.f;
-    if (c < co) {
-      v = ws[i];
-      if (bias != nullptr) v += bias[c];
-      v = apply_act(v, act);
-    }
-    Elem<T>::store(out + i, v);
-  }
-}
-
-// compact variant: ws row r belongs to class k (m_base[k] <= r < m_base[k+1]), local row m = r - m_base[k]; only the
-// output pixels the classes cover are written (the reflect ring of a dgrad frame)
-template <typename T>
-__global__ void splitk_finalize_compact_kernel(const DescPack pack, const float* __restrict__ ws, const float* __restrict__ bias,
-                                               T* __restrict__ out, size_t total, int ldc, int co, int act) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; i < total; i += stride) {
+  for (; i < slab_elems; i += stride) {
     const int c = (int)(i % (size_t)ldc);
     const int r = (int)(i / (size_t)ldc);
     int k = 0;
@@ -299,7 +286,7 @@ __global__ void splitk_finalize_compact_kernel(const DescPack pack, const float*
     const size_t opix = (size_t)out_pixel(g, n, oy, ox);
     float v = 0.f;
     if (c < co) {
-      v = ws[i];
+      for (int z = 0; z < zs; ++z) v += ws[(size_t)z * slab_elems + i];
       if (bias != nullptr) v += bias[c];
       v = apply_act(v, act);
     }
@@ -519,10 +506,12 @@ static int g_use_halo = 1;
 void set_use_halo(int on) { g_use_halo = on; }
 static int g_use_thin = 1;
 void set_use_thin(int on) { g_use_thin = on; }
+static int g_splitk_atomic = 0;
+void set_splitk_atomic(int on) { g_splitk_atomic = on; }
 
 template <typename T, int BM, int BN, int WM, int WN>
 static hipError_t launch_gg(const DescPack& pack, const void* src, const void* wgt, int wrows, const float* bias,
-                            void* out, float* ws, int ldc, int act, int splits, hipStream_t st) {
+                            void* out, float* ws, int ldc, int act, int splits, int slab_rows, int* zs_out, hipStream_t st) {
   constexpr int BKE = 128 / (int)sizeof(T);
   int tiles_m = 0, Kmax = 0;
   double flops = 0.0;
@@ -548,8 +537,9 @@ static hipError_t launch_gg(const DescPack& pack, const void* src, const void* w
   }
   prof_begin(PROF_GATHER_GEMM, flops, st);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, pack, (const T*)src, (const T*)wgt, wrows, bias, (T*)out,
-                     zs > 1 ? ws : (float*)nullptr, ldc, act, tiles_n, kps);
+                     zs > 1 ? ws : (float*)nullptr, ldc, act, tiles_n, kps, slab_rows);
   prof_end(PROF_GATHER_GEMM, st);
+  *zs_out = zs;
   return hipGetLastError();
 }
 
@@ -571,36 +561,43 @@ static hipError_t gather_gemm_t(const DescPack& pack, const void* src, const voi
   }
   if (!any) return hipSuccess;
   const GatherDesc& g0 = pack.d[0];
-  // split-K when the grid cannot fill the chip: aim for >= 2 workgroups per CU, keep >= 4 k-steps per split
+  // split-K when the grid cannot fill the chip: aim for >= 2 workgroups per CU, down to 2 k-steps per workgroup (small-M
+  // layers -- deep D convs, the 5x5 SPADE table convs, reflect rings -- are a serial chain of k-steps on a handful of
+  // CUs).  Every slice writes its own fp32 slab with plain stores (rows = class base + m) and the finalize kernel sums
+  // the slabs: no memset, no float atomics (chip-wide atomic rate ~1.3 TB/s against ~6 TB/s of plain stores), and the
+  // result does not depend on arrival order.
+  const int slab_rows = pack.m_base[pack.n - 1] + pack.d[pack.n - 1].M;
+  const size_t slab_elems = (size_t)slab_rows * ldc;
   int splits = 1;
-  size_t out_elems = (size_t)g0.N * g0.OH * g0.OW * ldc;
-  if (pack.ws_compact) out_elems = (size_t)(pack.m_base[pack.n - 1] + pack.d[pack.n - 1].M) * ldc;
-  if (tiles < g_num_cu && nk >= 4 && ws != nullptr && ws_bytes >= out_elems * sizeof(float)) {
-    // small-M layers (deep D convs, the 5x5 SPADE table convs) are a serial chain of k-steps on a handful of CUs:
-    // spread K over the idle CUs, down to 2 k-steps per workgroup
+  if (tiles < g_num_cu && nk >= 4 && ws != nullptr && ws_bytes >= 2 * slab_elems * sizeof(float)) {
     splits = (2 * g_num_cu + tiles - 1) / tiles;
     if (splits > nk / 2) splits = nk / 2;
+    const size_t fit = ws_bytes / (slab_elems * sizeof(float));
+    if ((size_t)splits > fit) splits = (int)fit;
     if (splits < 1) splits = 1;
   }
-  if (splits > 1) {
-    hipError_t e = hipMemsetAsync(ws, 0, out_elems * sizeof(float), st);
-    if (e != hipSuccess) return e;
+  if (splits > 1 && !pack.ws_compact && (long long)slab_rows < (long long)g0.N * g0.OH * g0.OW) {
+    // classes that do not cover the output frame (no such conv on the reference path): uncovered pixels read as zero
+    hipError_t e0 = hipMemsetAsync(out, 0, (size_t)g0.N * g0.OH * g0.OW * ldc * sizeof(T), st);
+    if (e0 != hipSuccess) return e0;
+  }
+  if (splits > 1 && pack.ws_atomic) {
+    hipError_t e0 = hipMemsetAsync(ws, 0, slab_elems * sizeof(float), st);
+    if (e0 != hipSuccess) return e0;
   }
   hipError_t e;
-  if (BN == 128) e = launch_gg<T, 128, 128, 2, 2>(pack, src, wgt, wrows, bias, out, ws, ldc, act, splits, st);
-  else if (BN == 64) e = launch_gg<T, 128, 64, 2, 2>(pack, src, wgt, wrows, bias, out, ws, ldc, act, splits, st);
-  else e = launch_gg<T, 128, 32, 4, 1>(pack, src, wgt, wrows, bias, out, ws, ldc, act, splits, st);
+  int zs = 1;
+  if (BN == 128) e = launch_gg<T, 128, 128, 2, 2>(pack, src, wgt, wrows, bias, out, ws, ldc, act, splits, slab_rows, &zs, st);
+  else if (BN == 64) e = launch_gg<T, 128, 64, 2, 2>(pack, src, wgt, wrows, bias, out, ws, ldc, act, splits, slab_rows, &zs, st);
+  else e = launch_gg<T, 128, 32, 4, 1>(pack, src, wgt, wrows, bias, out, ws, ldc, act, splits, slab_rows, &zs, st);
   if (e != hipSuccess) return e;
-  if (splits > 1) {
+  if (zs > 1) {
     const int threads = 256;
-    size_t blocks = (out_elems + threads - 1) / threads;
+    size_t blocks = (slab_elems + threads - 1) / threads;
     if (blocks > 4096) blocks = 4096;
-    if (pack.ws_compact)
-      hipLaunchKernelGGL(splitk_finalize_compact_kernel<T>, dim3((unsigned)blocks), dim3(threads), 0, st, pack, (const float*)ws,
-                         bias, (T*)out, out_elems, ldc, wrows, act);
-    else
-      hipLaunchKernelGGL(splitk_finalize_kernel<T>, dim3((unsigned)blocks), dim3(threads), 0, st, (const float*)ws, bias,
-                         (T*)out, out_elems, ldc, wrows, act);
+    hipLaunchKernelGGL(splitk_finalize_kernel<T>, dim3((unsigned)blocks), dim3(threads), 0, st, pack, (const float*)ws,
+                       pack.ws_atomic ? 1 : zs, slab_elems,
+                       bias, (T*)out, ldc, wrows, act);
     e = hipGetLastError();
   }
   return e;
@@ -613,6 +610,7 @@ hipError_t gather_gemm_multi(int dtype, const GatherDesc* descs, const long long
   DescPack pack;
   pack.n = 0;
   pack.ws_compact = compact_ws ? 1 : 0;
+  pack.ws_atomic = g_splitk_atomic;
   pack.skip_dead_taps = compact_ws ? 1 : 0;      // the reflect-ring launches are the compact ones
   for (int i = 0; i < n; ++i) {
     if (descs[i].M <= 0) continue;           // empty parity class

@@ -19,6 +19,7 @@ struct DescPack {
   FastDiv fd_taps[4];     // divide by th*tw (v2 k-step order)
   int n;
   int ws_compact;         // split-K partials indexed by (m_base[class] + m) instead of the output pixel
+  int ws_atomic;          // split-K slices accumulate into ONE slab with fp32 atomics (A/B option) instead of one slab each
   int skip_dead_taps;     // v1: skip the k-steps of a tap that contributes zero to every row of the tile (reflect ring)
   int m_base[4];
 };
@@ -30,6 +31,7 @@ hipError_t gather_gemm_v2(const DescPack& pack, const void* src, const void* wgt
 int num_cu();
 void set_use_halo(int on);
 void set_use_thin(int on);
+void set_splitk_atomic(int on);
 hipError_t thin_cout_conv(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out, int ldc,
                           int act, int num_cu, hipStream_t st);
 hipError_t thin_cin_conv(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out, int ldc,

@@ -76,6 +76,7 @@ int dei2i_set_option(const char* name, int value) {
   if (std::string(name) == "wgrad_v2") { g_use_wgrad_v2 = value; return 0; }
   if (std::string(name) == "halo_conv") { set_use_halo(value); return 0; }
   if (std::string(name) == "thin_conv") { set_use_thin(value); return 0; }
+  if (std::string(name) == "splitk_atomic") { set_splitk_atomic(value); return 0; }
   if (std::string(name) == "wgrad_halo") { g_use_wgrad_halo = value; return 0; }
   if (std::string(name) == "v2_ablate") { g_v2_ablate = value; return 0; }     // timing-only builds: 1 = no loads, 2 = no MFMA
   return DEI2I_ERR_BAD_ARG;
