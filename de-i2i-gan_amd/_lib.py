@@ -89,11 +89,12 @@ def load():
     # torch bundles its own libamdhip64.so.7; whichever copy is mapped first serves the whole process.  Import torch
     # first so this library shares torch's HIP runtime (streams, device pointers) instead of /opt/rocm's copy.
     import torch  # noqa: F401
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("DEI2I_LIB", LIB_PATH)     # a differently built copy of the SAME library, for same-box A/B timing
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"libdei2i_hip.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"libdei2i_hip.so not found at {path}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU / PyTorch fallback for the de-i2i-gan_amd ops.")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here == header/library drift
         fn.restype = res

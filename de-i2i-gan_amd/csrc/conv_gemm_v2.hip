@@ -181,8 +181,10 @@ __global__ __launch_bounds__(512) void gather_gemm_v2_kernel(const DescPack pack
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[ks & 1][i]),
-                                                               __builtin_bit_cast(bf16x8, bf[ks & 1][j]), acc[i][j], 0, 0, 0);
+          // transposed product (A = weights, B = pixels): D[channel][pixel] -- four consecutive channels of one pixel
+          // sit in consecutive registers, so the epilogue stages 8-byte packs instead of 2-byte scalars
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[ks & 1][j]),
+                                                               __builtin_bit_cast(bf16x8, af[ks & 1][i]), acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -208,48 +210,32 @@ __global__ __launch_bounds__(512) void gather_gemm_v2_kernel(const DescPack pack
   const unsigned long long t2 = ablate == 5 ? __builtin_amdgcn_s_memtime() : 0ull;
   if (ablate == 4) return;
   // ---- epilogue ----
-  // D layout: lane&31 = output channel, register e = pixel row.  Direct stores would be 2-byte stores (64 B per
-  // 32 lanes); instead the tile is staged through the (now idle) LDS ring as bf16 [row][BN] and written back with
-  // 16-byte stores, one 2*BN-byte row per BN/8 lanes.  Split-K partials (fp32 atomics) keep the direct path.
-  if (ws != nullptr) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        if (m >= g.M) continue;
-        size_t opix;
-        if (g.out_identity) {
-          opix = (size_t)m;
-        } else {
-          int n, oy, ox;
-          decode_m(g, m, n, oy, ox);
-          opix = (size_t)out_pixel(g, n, oy, ox);
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int n = n0 + wn * WTN + j * 32 + lr;
-          if (n < wrows) atomicAdd(ws + opix * ldc + n, acc[i][j][e]);
-        }
-      }
-    return;
-  }
+  // D row = channel (e&3) + 8(e>>2) + 4lh of its 32-block, col = pixel lr.  The tile is staged through the (now idle)
+  // LDS ring as bf16 [pixel][BN (+8 pad)] with 8-byte writes (row stride 16*odd bytes: 2-way instead of 32-way bank
+  // conflicts) and written back with 16-byte stores, one 2*BN-byte row per BN/8 lanes.
   __syncthreads();                       // every wave is done reading the ring
-  bf16_t* ctile = reinterpret_cast<bf16_t*>(smem);
+  constexpr int CROW = BN * 2 + 16;
+  unsigned char* ctile = smem;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = wn * WTN + j * 32 + lr;
-    const int n = n0 + col;
-    const float bv = (bias != nullptr && n < wrows) ? bias[n] : 0.f;
+  for (int j = 0; j < TN; ++j)
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int q = 0; q < 4; ++q) {
+      const int col0 = wn * WTN + j * 32 + 8 * q + 4 * lh;
+      float bq[4];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        const float v = n < wrows ? apply_act(acc[i][j][e] + bv, act) : 0.f;
-        ctile[row * BN + col] = f32_to_bf16(v);
+      for (int k = 0; k < 4; ++k) bq[k] = (bias != nullptr && n0 + col0 + k < wrows) ? bias[n0 + col0 + k] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * WTM + i * 32 + lr;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = n0 + col0 + k < wrows ? apply_act(acc[i][j][q * 4 + k] + bq[k], act) : 0.f;
+        u32x2 pk;
+        pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+        pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+        *reinterpret_cast<u32x2*>(ctile + row * CROW + col0 * 2) = pk;
       }
-  }
+    }
   __syncthreads();
   constexpr int CPR = BN / 8;             // 16-byte chunks per tile row
   constexpr int RPP = 512 / CPR;          // rows per pass
@@ -269,7 +255,7 @@ __global__ __launch_bounds__(512) void gather_gemm_v2_kernel(const DescPack pack
         decode_m(g, m, n, oy, ox);
         opix = (size_t)out_pixel(g, n, oy, ox);
       }
-      *reinterpret_cast<u32x4*>(out + opix * ldc + ncol) = *reinterpret_cast<const u32x4*>(ctile + row * BN + chunk * 8);
+      *reinterpret_cast<u32x4*>(out + opix * ldc + ncol) = *reinterpret_cast<const u32x4*>(ctile + row * CROW + chunk * 16);
     }
   }
   if (ablate == 5 && dbg != nullptr && tid == 0) {

@@ -63,6 +63,7 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, cons
   static_assert(TN >= 1 && STAGES >= 3, "tile shape");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned long long kt0 = ablate == 5 ? __builtin_amdgcn_s_memtime() : 0ull;
   unsigned char* const halo = smem;
   unsigned char* const ring = smem + 2 * HALO_BYTES;
   int* const htab = reinterpret_cast<int*>(ring + STAGES * B_STAGE);
@@ -208,8 +209,10 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, cons
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[ks][i]),
-                                                             __builtin_bit_cast(bf16x8, f.b[ks][j]), acc[i][j], 0, 0, 0);
+        // transposed product (A = weights, B = pixels): D[channel][pixel] leaves four consecutive channels of one pixel
+        // in consecutive registers, so the epilogue stages 8-byte packs instead of 2-byte scalars
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.b[ks][j]),
+                                                             __builtin_bit_cast(bf16x8, f.a[ks][i]), acc[i][j], 0, 0, 0);
   };
 
   // ---- main loop: two wave groups in anti-phase ("ping-pong") ----
@@ -323,23 +326,32 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, cons
     }
   }
 
-  // ---- epilogue: stage the tile through LDS as bf16 [row][BN], write back with 16-byte stores ----
+  // ---- epilogue: D row = channel (e&3) + 8(e>>2) + 4lh of the 32-block, col = pixel lr.  Stage the tile through LDS
+  //      as bf16 [pixel][BN (+8 pad)] with 8-byte writes (row stride 16*odd bytes: 2-way instead of 32-way conflicts),
+  //      write back with 16-byte stores ----
   __syncthreads();
-  bf16_t* ctile = reinterpret_cast<bf16_t*>(smem);
+  constexpr int CROW = BN * 2 + 16;       // staging row stride in bytes
+  unsigned char* ctile = smem;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = wn * WTN + j * 32 + lr;
-    const int n = n0 + col;
-    const float bv = (bias != nullptr && n < wrows) ? bias[n] : 0.f;
+  for (int j = 0; j < TN; ++j)
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int q = 0; q < 4; ++q) {
+      const int col0 = wn * WTN + j * 32 + 8 * q + 4 * lh;             // first of this lane's four channels
+      float bq[4];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = (wm * 2 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        const float v = n < wrows ? apply_act(acc[i][j][e] + bv, act) : 0.f;
-        ctile[row * BN + col] = f32_to_bf16(v);
+      for (int k = 0; k < 4; ++k) bq[k] = (bias != nullptr && n0 + col0 + k < wrows) ? bias[n0 + col0 + k] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = (wm * 2 + i) * 32 + lr;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = n0 + col0 + k < wrows ? apply_act(acc[i][j][q * 4 + k] + bq[k], act) : 0.f;
+        u32x2 pk;
+        pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+        pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+        *reinterpret_cast<u32x2*>(ctile + row * CROW + col0 * 2) = pk;
       }
-  }
+    }
   __syncthreads();
   constexpr int CPR = BN / 8;             // 16-byte chunks per tile row
   constexpr int RPP = 512 / CPR;          // rows per pass
@@ -350,8 +362,12 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, cons
     for (int p = 0; p < BM / RPP; ++p) {
       const int row = p * RPP + rsub;
       const size_t opix = (size_t)out_pixel(g, img, y0 + (row >> 5), x0 + (row & 31));
-      *reinterpret_cast<u32x4*>(out + opix * ldc + ncol) = *reinterpret_cast<const u32x4*>(ctile + row * BN + chunk * 8);
+      *reinterpret_cast<u32x4*>(out + opix * ldc + ncol) = *reinterpret_cast<const u32x4*>(ctile + row * CROW + chunk * 16);
     }
+  }
+  if (ablate == 5 && dbg != nullptr && lane == 0) {      // diagnostic: cycles from kernel entry to the last store issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    dbg[(size_t)gridDim.x * 8 * 4 + ((size_t)blockIdx.x * 8 + wave) * 6] = __builtin_amdgcn_s_memtime() - kt0;
   }
 }
 

@@ -39,3 +39,7 @@ print("waves", len(d), "k-steps", nk[0].item())
 print("loop cycles per wave: median %.0f  -> %.0f cycles per k-step" % (cyc.median().item(), (cyc / nk).median().item()))
 print("clock: median %.3f GHz" % ((cyc / real).median().item() * 0.1))
 print("loop wall per tile: %.1f us" % (real.median().item() / 100.0))
+if mode == 5:
+    tot = dbg[512 * 8 * 4:].view(-1, 6)[:, 0].cpu().double()
+    tot = tot[tot > 0]
+    print("whole kernel per tile: median %.0f cycles -> prologue + epilogue %.0f cycles" % (tot.median().item(), tot.median().item() - cyc.median().item()))
