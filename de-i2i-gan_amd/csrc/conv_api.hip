@@ -288,6 +288,14 @@ int dei2i_conv2d_dgrad_input(const dei2i_conv* c, const void* dy, const void* wd
     const int OH = c->H + 2 * p, OW = c->W + 2 * p;
     GatherDesc ring[4] = {sub_rect_desc(ring_frame, 0, p, 0, OW), sub_rect_desc(ring_frame, c->H + p, p, 0, OW),
                           sub_rect_desc(ring_frame, p, c->H, 0, p), sub_rect_desc(ring_frame, p, c->H, c->W + p, p)};
+    if (c->kh == 2 * p + 1 && c->kw == 2 * p + 1) {
+      // "same" convs: the top p frame rows only see tap rows 0..p-1 (the others read above dY), the bottom rows only
+      // tap rows kh-p..kh-1, likewise the side columns -- run each rectangle on its live taps (a third of K for 3x3)
+      ring[0] = sub_taps_desc(ring[0], 0, p, 0, c->kw);
+      ring[1] = sub_taps_desc(ring[1], c->kh - p, p, 0, c->kw);
+      ring[2] = sub_taps_desc(ring[2], 0, c->kh, 0, p);
+      ring[3] = sub_taps_desc(ring[3], 0, c->kh, c->kw - p, p);
+    }
     const long long woffs[4] = {0, 0, 0, 0};
     // ring launch: dead taps are skipped (2 of 3 tap rows / columns fall outside dY for a whole tile); split-K with a
     // compact workspace -- the partials are indexed by ring row, so memset / finalize touch ring rows only

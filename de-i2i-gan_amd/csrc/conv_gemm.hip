@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const DescPack pack, c
   }
 
   u32x4 areg[RA], breg[RB];
-  int cur_tap = -1;
+  int cur_tap = -1, b_woff = 0;
   int a_pix[RA];
 
   // Dead-tap skipping (reflect-ring launches: 2 of 3 tap rows / columns read outside dY for every row of a tile).
@@ -132,6 +132,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const DescPack pack, c
       const int ty = (int)fd_div((uint32_t)tap, g.fd_tw);
       const int tx = tap - ty * g.tw;
       const int dy = ty * g.ys, dx = tx * g.xs;
+      b_woff = weight_tap_offset(g, ty, tx);
       int any = 0;
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const DescPack pack, c
     }
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
-      breg[j] = (kval && b_row[j] >= 0) ? ld16(wgt + (size_t)b_row[j] * g.K + k) : zero16();
+      breg[j] = (kval && b_row[j] >= 0) ? ld16(wgt + (size_t)b_row[j] * g.wK + b_woff + ci) : zero16();
     }
   };
 

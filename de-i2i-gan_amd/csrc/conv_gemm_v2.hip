@@ -306,6 +306,7 @@ hipError_t gather_gemm_v2(const DescPack& pack, const void* src, const void* wgt
   for (int i = 0; i < pack.n; ++i) {
     const GatherDesc& g = pack.d[i];
     if (g.Cs % 64 != 0 || g.K % 64 != 0 || g.th * g.tw > 16) return hipErrorNotSupported;
+    if (g.wK != g.K || g.wtw != g.tw) return hipErrorNotSupported;        // sub-tap views: v1 only
     if ((long long)g.N * g.Hs * g.Ws * g.Cs >= (1ll << 31)) return hipErrorNotSupported;      // 32-bit offset table
     tiles256 += (g.M + 255) / 256;
     tiles192 += (g.M + 191) / 192;

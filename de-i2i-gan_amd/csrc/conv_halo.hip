@@ -394,7 +394,7 @@ static hipError_t launch_halo(const GatherDesc& g, const void* src, const void* 
 hipError_t halo_conv(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out, int ldc,
                      int act, int num_cu, hipStream_t st) {
   if (g.sh != 1 || g.sw != 1 || (g.ys != 1 && g.ys != -1) || (g.xs != 1 && g.xs != -1)) return hipErrorNotSupported;
-  if (g.th != 3 || g.tw != 3) return hipErrorNotSupported;       // tap count >= ring depth + 1 (halo issue at tap 1)
+  if (g.th != 3 || g.tw != 3 || g.wK != g.K || g.wtw != g.tw) return hipErrorNotSupported;       // tap count >= ring depth + 1 (halo issue at tap 1)
   if (g.Cs % 64 != 0 || g.Ho % HALO_TH != 0 || g.Wo % HALO_TW != 0 || g.M != g.N * g.Ho * g.Wo) return hipErrorNotSupported;
   if ((long long)g.N * g.Hs * g.Ws * g.Cs >= (1ll << 31)) return hipErrorNotSupported;   // 32-bit offset table
   if (ldc < 64 || ldc % 8 != 0) return hipErrorNotSupported;

@@ -27,6 +27,9 @@ struct GatherDesc {
   int th, tw, ys, xs;     // tap grid and per-tap step
   int pad_mode;           // PAD_ZERO / PAD_REFLECT
   int K;                  // th*tw*Cs
+  // weight addressing: row stride wK, and tap (ty, tx) of this descriptor is weight tap (wty0+ty)*wtw + (wtx0+tx) --
+  // a descriptor may cover a sub-rectangle of the packed tap grid (reflect-ring launches)
+  int wK, wtw, wty0, wtx0;
   int OH, OW, oys, oxs, oy0, ox0;   // output placement
   int out_identity;       // 1 when the output pixel index == m
   FastDiv fd_cs, fd_tw, fd_wo, fd_howo;
@@ -53,6 +56,9 @@ DEI2I_HD void decode_m(const GatherDesc& g, int m, int& n, int& oy, int& ox) {
   oy = (int)uy;
   ox = (int)(rem - uy * (uint32_t)g.Wo);
 }
+
+// element offset, within a packed weight row, of this descriptor's tap (ty, tx)
+DEI2I_HD int weight_tap_offset(const GatherDesc& g, int ty, int tx) { return ((g.wty0 + ty) * g.wtw + g.wtx0 + tx) * g.Cs; }
 
 DEI2I_HD void decode_k(const GatherDesc& g, int k, int& tap, int& ci) {
   uint32_t t = fd_div((uint32_t)k, g.fd_cs);
@@ -107,6 +113,7 @@ inline GatherDesc make_fwd_desc(const ConvShape& c, int Cs) {
   g.pad_mode = c.pad_mode;
   g.OH = g.Ho; g.OW = g.Wo; g.oys = g.oxs = 1; g.oy0 = g.ox0 = 0;
   finish_desc(g);
+  g.wK = g.K; g.wtw = g.tw; g.wty0 = g.wtx0 = 0;
   return g;
 }
 
@@ -152,6 +159,7 @@ inline GatherDesc make_dgrad_desc(const ConvShape& c, int CoutS, int ay, int ax)
   if (g.Ho == 0) g.Ho = 1;
   if (g.Wo == 0) g.Wo = 1;
   finish_desc(g);
+  g.wK = g.K; g.wtw = g.tw; g.wty0 = g.wtx0 = 0;
   if (Ho_keep == 0 || Wo_keep == 0) g.M = 0;
   return g;
 }
@@ -163,6 +171,18 @@ inline GatherDesc sub_rect_desc(const GatherDesc& g, int ry0, int rh, int rx0, i
   r.Ho = rh; r.Wo = rw;
   r.by0 = g.by0 + ry0 * g.sh; r.bx0 = g.bx0 + rx0 * g.sw;
   r.oy0 = g.oy0 + ry0 * g.oys; r.ox0 = g.ox0 + rx0 * g.oxs;
+  finish_desc(r);
+  return r;
+}
+
+// The same gather restricted to taps [ty0, ty0+nty) x [tx0, tx0+ntx) of g's tap grid (weights keep their packed layout:
+// the descriptor remembers where its taps sit in the full grid).  Reflect-ring rectangles read outside dY for every
+// other tap row / column, so their GEMMs run on the live third of K only.
+inline GatherDesc sub_taps_desc(const GatherDesc& g, int ty0, int nty, int tx0, int ntx) {
+  GatherDesc r = g;
+  r.th = nty; r.tw = ntx;
+  r.by0 = g.by0 + ty0 * g.ys; r.bx0 = g.bx0 + tx0 * g.xs;
+  r.wty0 = g.wty0 + ty0; r.wtx0 = g.wtx0 + tx0;
   finish_desc(r);
   return r;
 }

@@ -201,7 +201,7 @@ static hipError_t launch_thin(const GatherDesc& g, const void* src, const void* 
 // returns hipErrorNotSupported when the shape does not qualify (the caller falls through to the gather GEMMs)
 hipError_t thin_cin_conv(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out, int ldc,
                          int act, int num_cu, hipStream_t st) {
-  if (g.Cs != 8 || wrows > TC_N || ldc > TC_N || ldc % 8 != 0) return hipErrorNotSupported;
+  if (g.Cs != 8 || wrows > TC_N || ldc > TC_N || ldc % 8 != 0 || g.wK != g.K || g.wtw != g.tw) return hipErrorNotSupported;
   if ((g.ys != 1 && g.ys != -1) || (g.xs != 1 && g.xs != -1) || g.sh < 1 || g.sh > 2 || g.sw != g.sh) return hipErrorNotSupported;
   if (g.Ho % TC_TH != 0 || g.Wo % TC_TW != 0 || g.M != g.N * g.Ho * g.Wo) return hipErrorNotSupported;
   const int ntiles = g.N * (g.Ho / TC_TH) * (g.Wo / TC_TW);
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(512) void thin_cout_conv_kernel(const GatherDesc g,
 // returns hipErrorNotSupported when the shape does not qualify (the caller falls through to the gather GEMMs)
 hipError_t thin_cout_conv(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out, int ldc,
                           int act, int num_cu, hipStream_t st) {
-  if (g.Cs != 64 || wrows > TO_MAXCO || ldc != 8) return hipErrorNotSupported;
+  if (g.Cs != 64 || wrows > TO_MAXCO || ldc != 8 || g.wK != g.K || g.wtw != g.tw) return hipErrorNotSupported;
   if ((g.ys != 1 && g.ys != -1) || (g.xs != 1 && g.xs != -1) || g.sh != 1 || g.sw != 1) return hipErrorNotSupported;
   if (g.Ho % TC_TH != 0 || g.Wo % TC_TW != 0 || g.M != g.N * g.Ho * g.Wo) return hipErrorNotSupported;
   if ((long long)g.N * g.Hs * g.Ws * 64 >= (1ll << 31)) return hipErrorNotSupported;

@@ -26,7 +26,8 @@ static void run_gather_gemm(const GatherDesc& g, const float* src, const float* 
         int tap, ci;
         decode_k(g, k, tap, ci);
         const int pix = src_pixel(g, n, oy, ox, tap);
-        if (pix >= 0) acc += (double)src[(long long)pix * g.Cs + ci] * (double)wgt[(long long)r * g.K + k];
+        const int ty = tap / g.tw, tx = tap - ty * g.tw;
+        if (pix >= 0) acc += (double)src[(long long)pix * g.Cs + ci] * (double)wgt[(long long)r * g.wK + weight_tap_offset(g, ty, tx) + ci];
       }
       out[op * ldc + r] = (float)acc;
     }
@@ -136,8 +137,14 @@ long long hc_conv_dgrad_decomposed(const int* p, const float* dy, const float* w
   const GatherDesc interior = make_dgrad_desc(z, CoutS, 0, 0);
   run_gather_gemm(interior, dy, wd, CinS, dx, CinS);
   const int OH = s.H + 2 * pad, OW = s.W + 2 * pad;
-  const GatherDesc ring[4] = {sub_rect_desc(frame, 0, pad, 0, OW), sub_rect_desc(frame, s.H + pad, pad, 0, OW),
-                              sub_rect_desc(frame, pad, s.H, 0, pad), sub_rect_desc(frame, pad, s.H, s.W + pad, pad)};
+  GatherDesc ring[4] = {sub_rect_desc(frame, 0, pad, 0, OW), sub_rect_desc(frame, s.H + pad, pad, 0, OW),
+                        sub_rect_desc(frame, pad, s.H, 0, pad), sub_rect_desc(frame, pad, s.H, s.W + pad, pad)};
+  if (s.kh == 2 * pad + 1 && s.kw == 2 * pad + 1) {           // live taps only, as dei2i_conv2d_dgrad_input does
+    ring[0] = sub_taps_desc(ring[0], 0, pad, 0, s.kw);
+    ring[1] = sub_taps_desc(ring[1], s.kh - pad, pad, 0, s.kw);
+    ring[2] = sub_taps_desc(ring[2], 0, s.kh, 0, pad);
+    ring[3] = sub_taps_desc(ring[3], 0, s.kh, s.kw - pad, pad);
+  }
   long long written = 0;
   for (int k = 0; k < 4; ++k) {
     run_gather_gemm(ring[k], dy, wd, CinS, ext, CinS);
