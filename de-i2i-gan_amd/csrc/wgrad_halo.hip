@@ -47,8 +47,9 @@ template <int ROWB> DEI2I_D int hw_swz(int row) {
   else return ((row >> 1) & 1) << 6;
 }
 
-// BCO x BCI = 128 x 64 (Cout >= 96) or 64 x 128 (Cout <= 64): 8 waves = (BCO/32) x (BCI/32) blocks, 9 taps each
-template <int BCO, int BCI>
+// BCO x BCI = 128 x 64 (Cout >= 96) or 64 x 128 (Cout <= 64): 8 waves = (BCO/32) x (BCI/32) blocks, 9 taps each;
+// 64 x 64 with the taps split over NTG = 2 wave groups for 64-channel inputs (the 64 -> 4 heads: one live co block)
+template <int BCO, int BCI, int NTG>
 __global__ __launch_bounds__(512) void wgrad_halo_kernel(const GatherDesc g, const bf16_t* __restrict__ src,
                                                          const bf16_t* __restrict__ dy, const int co_rows, const int ldy,
                                                          float* __restrict__ slabs, const int nslices, const int tiles_per_split,
@@ -56,15 +57,18 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const GatherDesc g, con
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr int NIB = BCI / 32;
-  static_assert((BCO / 32) * NIB == 8, "8 waves");
+  constexpr int NIB = BCI / 32, NCB = BCO / 32;
+  constexpr int TPW = (9 + NTG - 1) / NTG;            // taps per wave
+  static_assert(NCB * NIB * NTG == 8, "8 waves");
   constexpr int ROWB_A = BCO * 2, ROWB_B = BCI * 2;
   constexpr int HW_A_BYTES = 128 * ROWB_A, HW_B_BYTES = HW_HPAD * ROWB_B, HW_STAGE = HW_A_BYTES + HW_B_BYTES;
   constexpr int RPI_A = 1024 / ROWB_A, SPR_A = ROWB_A / 16;      // dy rows per DMA instruction, 16-byte slots per row
   constexpr int RPI_B = 1024 / ROWB_B, SPR_B = ROWB_B / 16;
   constexpr int NA = 128 / RPI_A / 8, NB = (HW_HPAD / RPI_B + 7) / 8;   // DMA instructions per wave per half-tile
   constexpr int GROUPS_B = HW_HPAD / RPI_B;
-  const int cb = wave / NIB, ib = wave % NIB;         // 32-channel block of co / of ci
+  const int tg = wave / (NCB * NIB);                  // tap group
+  const int cb = (wave / NIB) % NCB, ib = wave % NIB; // 32-channel block of co / of ci
+  const int tap0 = NTG == 1 ? 0 : tg * TPW;           // compile-time 0 for the 9-taps-per-wave variants
 
   const int combo = blockIdx.y, split = blockIdx.x;
   const int tile_c = combo / nslices, slice = combo - tile_c * nslices;
@@ -114,9 +118,9 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const GatherDesc g, con
     }
   };
 
-  f32x16 acc[9];
+  f32x16 acc[TPW];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < TPW; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
@@ -144,8 +148,10 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const GatherDesc g, con
       const u32x4 af = tr_read(ab, ra * ROWB_A + (a_colb ^ hw_swz<ROWB_A>(ra)), (ra + 4) * ROWB_A + (a_colb ^ hw_swz<ROWB_A>(ra + 4)));
       const int py = kb >> 1, px0 = (kb & 1) * 16;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int ty = t / 3, tx = t - ty * 3;
+      for (int t = 0; t < TPW; ++t) {
+        const int tap = tap0 + t;                                         // wave-uniform
+        if (NTG > 1 && tap >= 9) break;
+        const int ty = tap / 3, tx = tap - ty * 3;
         const int rb = (py + ty) * HW_HWD + px0 + tx + 8 * lh + tr_q;     // halo pixels rb, rb+4
         const u32x4 bf = tr_read(bb, rb * ROWB_B + (b_colb ^ hw_swz<ROWB_B>(rb)), (rb + 4) * ROWB_B + (b_colb ^ hw_swz<ROWB_B>(rb + 4)));
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf), acc[t], 0, 0, 0);
@@ -168,15 +174,16 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const GatherDesc g, con
   // ---- partial block -> this split's slab [Cout][9][Cs] (lanes run along ci: 128-byte segments) ----
   float* slab = slabs + (size_t)split * slab_elems;
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < TPW; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int co = c0 + cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-      if (co < co_rows) slab[(size_t)co * g.K + t * g.Cs + ci0 + ib * 32 + lr] = acc[t][e];
+      const int tap = tap0 + t;
+      if (co < co_rows && tap < 9) slab[(size_t)co * g.K + tap * g.Cs + ci0 + ib * 32 + lr] = acc[t][e];
     }
 }
 
-template <int BCO, int BCI>
+template <int BCO, int BCI, int NTG>
 static hipError_t launch_wgrad_halo(const GatherDesc& g, const void* src, const void* dy, int co_rows, int ldy, float* slabs,
                                     size_t slab_capacity_elems, int num_cu, int* nsplit_out, bool force, hipStream_t st) {
   const int nslices = g.Cs / BCI, tiles_c = (co_rows + BCO - 1) / BCO;
@@ -192,7 +199,7 @@ static hipError_t launch_wgrad_halo(const GatherDesc& g, const void* src, const 
   const int tps = (ntiles + splits - 1) / splits;
   const int zs = (ntiles + tps - 1) / tps;
   const size_t lds = 2 * (size_t)(128 * BCO * 2 + HW_HPAD * BCI * 2);
-  auto kern = wgrad_halo_kernel<BCO, BCI>;
+  auto kern = wgrad_halo_kernel<BCO, BCI, NTG>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -211,14 +218,17 @@ static hipError_t launch_wgrad_halo(const GatherDesc& g, const void* src, const 
 hipError_t wgrad_halo(const GatherDesc& g, const void* src, const void* dy, int co_rows, int ldy, float* slabs,
                       size_t slab_capacity_elems, int num_cu, int* nsplit_out, bool force, hipStream_t st) {
   if (g.sh != 1 || g.sw != 1 || g.ys != 1 || g.xs != 1 || g.th != 3 || g.tw != 3) return hipErrorNotSupported;
-  if (g.Ho % HW_TH != 0 || g.Wo % HW_TW != 0 || co_rows < 48) return hipErrorNotSupported;
+  if (g.Ho % HW_TH != 0 || g.Wo % HW_TW != 0) return hipErrorNotSupported;
   if ((long long)g.N * g.Hs * g.Ws * g.Cs >= (1ll << 31)) return hipErrorNotSupported;
   if (co_rows <= 64) {
-    if (g.Cs % 128 != 0) return hipErrorNotSupported;
-    return launch_wgrad_halo<64, 128>(g, src, dy, co_rows, ldy, slabs, slab_capacity_elems, num_cu, nsplit_out, force, st);
+    if (g.Cs % 128 == 0 && co_rows >= 48)
+      return launch_wgrad_halo<64, 128, 1>(g, src, dy, co_rows, ldy, slabs, slab_capacity_elems, num_cu, nsplit_out, force, st);
+    if (g.Cs % 64 == 0 && co_rows <= 32)        // thin heads: the work is the input stream; taps split over two wave groups
+      return launch_wgrad_halo<64, 64, 2>(g, src, dy, co_rows, ldy, slabs, slab_capacity_elems, num_cu, nsplit_out, force, st);
+    return hipErrorNotSupported;
   }
   if (g.Cs % 64 != 0 || co_rows < 96) return hipErrorNotSupported;
-  return launch_wgrad_halo<128, 64>(g, src, dy, co_rows, ldy, slabs, slab_capacity_elems, num_cu, nsplit_out, force, st);
+  return launch_wgrad_halo<128, 64, 1>(g, src, dy, co_rows, ldy, slabs, slab_capacity_elems, num_cu, nsplit_out, force, st);
 }
 
 }  // namespace dei2i

@@ -77,8 +77,10 @@ CONV_CASES += [
     (3, 64, 7, 1, 3, True, False, 128, 128, 4, False, "none"),          # generator stem
     (3, 64, 4, 2, 1, True, False, 256, 128, 8, True, "leaky_relu"),     # discriminator's first conv: stride 2, bias, LReLU
     (64, 4, 3, 1, 1, True, False, 128, 128, 4, False, "none"),          # heads: the interior dgrad (dY has 8 channels)
+    (64, 4, 3, 1, 1, True, False, 16, 32, 4, False, "none"),            # heads wgrad: 64 x 64 block, taps split over two wave groups (forced)
 ]
-FORCE_WGRAD_HALO = {(128, 64, 3, 1, 1, True, False, 16, 32, 8, False, "none"), (256, 48, 3, 1, 1, False, False, 8, 32, 4, False, "none")}
+FORCE_WGRAD_HALO = {(128, 64, 3, 1, 1, True, False, 16, 32, 8, False, "none"), (256, 48, 3, 1, 1, False, False, 8, 32, 4, False, "none"),
+                    (64, 4, 3, 1, 1, True, False, 16, 32, 4, False, "none")}
 
 
 @pytest.mark.parametrize("pname", ["f32", "bf16"])
