@@ -589,10 +589,10 @@ static inline size_t combine_lds(int dtype, int nv) { return (size_t)nv * (dtype
 
 extern "C" {
 
-int dei2i_moments_chunks(int HW) {            // per image: >= 64 rows per workgroup, up to 256 workgroups
+int dei2i_moments_chunks(int HW) {            // per image: >= 64 rows per workgroup, up to 64 workgroups (x N images)
   int c = HW / 64;
   if (c < 1) c = 1;
-  if (c > 256) c = 256;
+  if (c > 64) c = 64;
   return c;
 }
 
