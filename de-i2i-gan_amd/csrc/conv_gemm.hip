@@ -274,9 +274,12 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const DescPack pack, c
 template <typename T>
 __global__ void splitk_finalize_kernel(const DescPack pack, const float* __restrict__ ws, const int zs, const size_t slab_elems,
                                        const float* __restrict__ bias, T* __restrict__ out, int ldc, int co, int act) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // four channels per thread (ldc is a multiple of the 16-byte vector: 8 bf16 / 4 f32), two slabs in flight
+  size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; i < slab_elems; i += stride) {
+  const size_t total4 = slab_elems >> 2;
+  for (; q < total4; q += stride) {
+    const size_t i = q << 2;
     const int c = (int)(i % (size_t)ldc);
     const int r = (int)(i / (size_t)ldc);
     int k = 0;
@@ -285,13 +288,27 @@ __global__ void splitk_finalize_kernel(const DescPack pack, const float* __restr
     int n, oy, ox;
     decode_m(g, r - pack.m_base[k], n, oy, ox);
     const size_t opix = (size_t)out_pixel(g, n, oy, ox);
-    float v = 0.f;
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
     if (c < co) {
-      for (int z = 0; z < zs; ++z) v += ws[(size_t)z * slab_elems + i];
-      if (bias != nullptr) v += bias[c];
-      v = apply_act(v, act);
+      int z = 0;
+      for (; z + 1 < zs; z += 2) {
+        v0 += *reinterpret_cast<const f32x4*>(ws + (size_t)z * slab_elems + i);
+        v1 += *reinterpret_cast<const f32x4*>(ws + (size_t)(z + 1) * slab_elems + i);
+      }
+      if (z < zs) v0 += *reinterpret_cast<const f32x4*>(ws + (size_t)z * slab_elems + i);
     }
-    Elem<T>::store(out + opix * ldc + c, v);
+    const f32x4 v = v0 + v1;
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float o = 0.f;
+      if (c + e < co) {
+        o = vv[e];
+        if (bias != nullptr) o += bias[c + e];
+        o = apply_act(o, act);
+      }
+      Elem<T>::store(out + opix * ldc + c + e, o);
+    }
   }
 }
 
@@ -594,7 +611,7 @@ static hipError_t gather_gemm_t(const DescPack& pack, const void* src, const voi
   if (e != hipSuccess) return e;
   if (zs > 1) {
     const int threads = 256;
-    size_t blocks = (slab_elems + threads - 1) / threads;
+    size_t blocks = ((slab_elems >> 2) + threads - 1) / threads;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(splitk_finalize_kernel<T>, dim3((unsigned)blocks), dim3(threads), 0, st, pack, (const float*)ws,
                        pack.ws_atomic ? 1 : zs, slab_elems,
