@@ -28,6 +28,7 @@ namespace dei2i {
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page_halo[256];
 extern int g_v2_ablate;
 extern unsigned long long* g_v2_dbg;
+int g_halo_mfma32 = 0;
 
 typedef __attribute__((address_space(3))) void lds_void_h;
 typedef __attribute__((address_space(1))) const void gbl_void_h;
@@ -49,7 +50,7 @@ constexpr int HALO_HL = 6;                            // halo LDS-DMA instructio
 
 template <int N> DEI2I_D void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BN, int STAGES, bool DIAG>
+template <int BN, int STAGES, bool DIAG, bool M16>
 __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, const bf16_t* __restrict__ src,
                                                         const bf16_t* __restrict__ wgt, const int wrows,
                                                         const float* __restrict__ bias, bf16_t* __restrict__ out,
@@ -145,42 +146,51 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, cons
     if (++is_tap == ntaps) { is_tap = 0; ++is_slice; }
   };
 
-  f32x16 acc[TM][TN];
+  // MFMA shape: 32x32x16 (M16 = false) or 16x16x32 (M16 = true; same cycles per FLOP, but the chip holds a higher clock
+  // under it -- mfma_peak.hip: 2.26 vs 1.94 PF, 2.2 vs 1.9 GHz).  Both run the transposed product (A = weights,
+  // B = pixels): D[channel][pixel] leaves four consecutive channels of one pixel in consecutive registers.
+  constexpr int PB = M16 ? TM * 2 : TM;              // pixel blocks per wave (16 or 32 pixels each)
+  constexpr int CB = M16 ? WTN / 16 : TN;            // channel blocks per wave
+  constexpr int NKS = M16 ? 2 : 4;                   // MFMA k-blocks per 64-channel k-step
+  typedef __attribute__((ext_vector_type(M16 ? 4 : 16))) float acc_t;
+  acc_t acc[PB][CB];
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < PB; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < CB; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int e = 0; e < (M16 ? 4 : 16); ++e) acc[i][j][e] = 0.f;
 
-  const int lr = lane & 31, lh = lane >> 5;
+  const int lr = lane & 31, lh = lane >> 5;          // 32x32x16 lane roles: row / k-half
+  const int l16 = lane & 15, kg = lane >> 4;         // 16x16x32 lane roles: row / k-group (8 channels each)
 
-  // ---- fragment reads: ALL four 16-wide k-substeps of a k-step live in registers (Frags); the reads of k-step it+1
-  //      are issued between the MFMA groups of k-step it, so LDS latency never sits between a barrier and an MFMA ----
-  struct Frags { u32x4 a[4][TM]; u32x4 b[4][TN]; };
-  int a_pix0[TM];                                    // halo pixel of this lane's row for tap offset 0
+  // ---- fragment reads: ALL k-blocks of a k-step live in registers (Frags); the reads of k-step j are issued in this
+  //      wave's M phase, its MFMAs in the C phase ----
+  struct Frags { u32x4 a[NKS][PB]; u32x4 b[NKS][CB]; };
+  int a_pix0[PB];                                    // halo pixel of this lane's pixel row for tap offset 0
 #pragma unroll
-  for (int i = 0; i < TM; ++i) a_pix0[i] = (wm * 2 + i) * hwd + lr;
-  int b_lane[TN], b_rsw[TN];
+  for (int i = 0; i < PB; ++i)
+    a_pix0[i] = M16 ? (wm * TM + (i >> 1)) * hwd + (i & 1) * 16 + l16 : (wm * TM + i) * hwd + lr;
+  int b_lane[CB], b_rsw[CB];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int row = wn * WTN + j * 32 + lr;
+  for (int j = 0; j < CB; ++j) {
+    const int row = M16 ? wn * WTN + j * 16 + l16 : wn * WTN + j * 32 + lr;
     b_lane[j] = row * 128;
     b_rsw[j] = (row >> 1) & 7;
   }
-  // state of the k-step whose fragments are being LOADED (one ahead of the one being computed)
+  // state of the k-step whose fragments are being LOADED
   int ld_tx = 0, ld_ty = 0, ld_slice = 0, ld_stage = 0;
   const int step_x = g.xs > 0 ? 1 : -1, step_y = g.ys > 0 ? hwd : -hwd;
   int ld_toff = (g.ys > 0 ? 0 : (g.th - 1) * hwd) + (g.xs > 0 ? 0 : g.tw - 1);     // halo pixel offset of tap (0,0)
   const int toff_row_wrap = step_y - (g.tw - 1) * step_x;                            // (ty,tw-1) -> (ty+1,0)
   const int toff_origin = ld_toff;
-  const unsigned char* la_base[TM];
-  int la_swz[TM];
+  const unsigned char* la_base[PB];
+  int la_swz[PB];
   const unsigned char* lb_base;
   auto prep_load = [&]() {                            // addresses for the k-step (ld_tap, ld_slice, ld_stage)
     const unsigned char* hb = halo + (ld_slice & 1) * HALO_BYTES;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < PB; ++i) {
       const int pix = a_pix0[i] + ld_toff;
       la_base[i] = hb + pix * 128;
       la_swz[i] = (pix >> 1) & 7;
@@ -198,21 +208,24 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, cons
     if (++ld_stage == STAGES) ld_stage = 0;
   };
   auto read_frags = [&](Frags& f, int ks) {
-    const int chunk = ks * 2 + lh;
+    const int chunk = M16 ? ks * 4 + kg : ks * 2 + lh;          // this lane's 16-byte chunk of the 128-byte k-row
 #pragma unroll
-    for (int i = 0; i < TM; ++i) f.a[ks][i] = *reinterpret_cast<const u32x4*>(la_base[i] + ((chunk ^ la_swz[i]) << 4));
+    for (int i = 0; i < PB; ++i) f.a[ks][i] = *reinterpret_cast<const u32x4*>(la_base[i] + ((chunk ^ la_swz[i]) << 4));
 #pragma unroll
-    for (int j = 0; j < TN; ++j) f.b[ks][j] = *reinterpret_cast<const u32x4*>(lb_base + b_lane[j] + ((chunk ^ b_rsw[j]) << 4));
+    for (int j = 0; j < CB; ++j) f.b[ks][j] = *reinterpret_cast<const u32x4*>(lb_base + b_lane[j] + ((chunk ^ b_rsw[j]) << 4));
   };
   auto mfma_group = [&](const Frags& f, int ks) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < PB; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        // transposed product (A = weights, B = pixels): D[channel][pixel] leaves four consecutive channels of one pixel
-        // in consecutive registers, so the epilogue stages 8-byte packs instead of 2-byte scalars
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.b[ks][j]),
-                                                             __builtin_bit_cast(bf16x8, f.a[ks][i]), acc[i][j], 0, 0, 0);
+      for (int j = 0; j < CB; ++j) {
+        if constexpr (M16)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.b[ks][j]),
+                                                               __builtin_bit_cast(bf16x8, f.a[ks][i]), acc[i][j], 0, 0, 0);
+        else
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.b[ks][j]),
+                                                               __builtin_bit_cast(bf16x8, f.a[ks][i]), acc[i][j], 0, 0, 0);
+      }
   };
 
   // ---- main loop: two wave groups in anti-phase ("ping-pong") ----
@@ -250,7 +263,7 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, cons
     const unsigned long long q0 = now();
     prep_load();
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) read_frags(f, ks);
+    for (int ks = 0; ks < NKS; ++ks) read_frags(f, ks);
     advance_load();
     __builtin_amdgcn_sched_barrier(0);
     const unsigned long long q2 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -278,12 +291,10 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, cons
     __builtin_amdgcn_sched_barrier(0);
     if (j - 1 + STAGES < nk) issue_b((j + STAGES - 1) % STAGES);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_group(f, 1);
-    __builtin_amdgcn_sched_barrier(0);
     if (tap == 1 && slice + 1 < nslices) issue_halo(slice + 1);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_group(f, 2);
-    mfma_group(f, 3);
+#pragma unroll
+    for (int ks = 1; ks < NKS; ++ks) mfma_group(f, ks);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     if (DIAG) dg[5] += now() - q0;
@@ -332,26 +343,48 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, cons
   __syncthreads();
   constexpr int CROW = BN * 2 + 16;       // staging row stride in bytes
   unsigned char* ctile = smem;
+  if constexpr (M16) {
+    // D row = channel 4*kg + e of its 16-block, col = pixel l16
 #pragma unroll
-  for (int j = 0; j < TN; ++j)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int col0 = wn * WTN + j * 32 + 8 * q + 4 * lh;             // first of this lane's four channels
+    for (int j = 0; j < CB; ++j) {
+      const int col0 = wn * WTN + j * 16 + 4 * kg;
       float bq[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) bq[k] = (bias != nullptr && n0 + col0 + k < wrows) ? bias[n0 + col0 + k] : 0.f;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = (wm * 2 + i) * 32 + lr;
+      for (int i = 0; i < PB; ++i) {
+        const int row = (wm * TM + (i >> 1)) * 32 + (i & 1) * 16 + l16;
         float v[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = n0 + col0 + k < wrows ? apply_act(acc[i][j][q * 4 + k] + bq[k], act) : 0.f;
+        for (int k = 0; k < 4; ++k) v[k] = n0 + col0 + k < wrows ? apply_act(acc[i][j][k] + bq[k], act) : 0.f;
         u32x2 pk;
         pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
         pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
         *reinterpret_cast<u32x2*>(ctile + row * CROW + col0 * 2) = pk;
       }
     }
+  } else {
+#pragma unroll
+    for (int j = 0; j < CB; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col0 = wn * WTN + j * 32 + 8 * q + 4 * lh;             // first of this lane's four channels
+        float bq[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bq[k] = (bias != nullptr && n0 + col0 + k < wrows) ? bias[n0 + col0 + k] : 0.f;
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+          const int row = (wm * TM + i) * 32 + lr;
+          float v[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = n0 + col0 + k < wrows ? apply_act(acc[i][j][q * 4 + k] + bq[k], act) : 0.f;
+          u32x2 pk;
+          pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+          pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+          *reinterpret_cast<u32x2*>(ctile + row * CROW + col0 * 2) = pk;
+        }
+      }
+  }
   __syncthreads();
   constexpr int CPR = BN / 8;             // 16-byte chunks per tile row
   constexpr int RPP = 512 / CPR;          // rows per pass
@@ -377,8 +410,9 @@ static hipError_t launch_halo(const GatherDesc& g, const void* src, const void* 
   const int tiles_m = g.N * (g.Ho / HALO_TH) * (g.Wo / HALO_TW);
   const int tiles_n = (ldc + BN - 1) / BN;
   const size_t lds = 2 * (size_t)HALO_BYTES + (size_t)STAGES * BN * 128 + HALO_GROUPS * 8 * sizeof(int);
-  auto kern = halo_conv_kernel<BN, STAGES, false>;
-  if (g_v2_ablate == 6) kern = halo_conv_kernel<BN, STAGES, true>;        // diagnostic build: per-phase cycle stamps
+  auto kern = halo_conv_kernel<BN, STAGES, false, true>;
+  if (g_halo_mfma32) kern = halo_conv_kernel<BN, STAGES, false, false>;     // A/B option: 32x32x16 MFMAs
+  if (g_v2_ablate == 6) kern = halo_conv_kernel<BN, STAGES, true, true>;   // diagnostic build: per-phase cycle stamps
   {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
