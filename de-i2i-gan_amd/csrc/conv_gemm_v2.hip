@@ -142,48 +142,50 @@ __global__ __launch_bounds__(512) void gather_gemm_v2_kernel(const DescPack pack
     }
   };
 
-  f32x16 acc[TM][TN];
+  // 16x16x32 MFMAs (same cycles per FLOP as 32x32x16; the chip holds a higher clock under them -- mfma_peak.hip), in the
+  // transposed product (A = weights, B = pixels): D[channel][pixel], four consecutive channels of one pixel in the
+  // four registers of a 16x16 block, so the epilogue stages 8-byte packs.
+  constexpr int PB = WTM / 16, CB = WTN / 16;       // 16-pixel / 16-channel blocks per wave
+  f32x4 acc[PB][CB];
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < PB; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < CB; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
-  const int lr = lane & 31, lh = lane >> 5;
+  const int l16 = lane & 15, kg = lane >> 4;        // lane roles: row of the block / 8-channel k-group
 
-  // Fragment reads are software-pipelined against the MFMAs through two register sets: the ds_reads of k-substep
+  // Fragment reads are software-pipelined against the MFMAs through two register sets: the ds_reads of k-block
   // ks+1 are issued BEFORE the MFMAs of ks.  (With one set, a ds_read that overwrites the source registers of a
   // queued MFMA cannot issue until that MFMA has read them, so LDS latency and MFMA time add up instead of overlapping.)
   auto compute = [&](int stage) {
     const unsigned char* ab = smem + stage * STAGE_BYTES;
     const unsigned char* bb = ab + BM * 128;
-    u32x4 af[2][TM], bf[2][TN];
-    auto load_frags = [&](int ks, u32x4 (&a)[TM], u32x4 (&b)[TN]) {
-      const int chunk = ks * 2 + lh;
+    u32x4 af[2][PB], bf[2][CB];
+    auto load_frags = [&](int ks, u32x4 (&a)[PB], u32x4 (&b)[CB]) {
+      const int chunk = ks * 4 + kg;                 // this lane's 16-byte chunk of the 128-byte k-row
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = wm * WTM + i * 32 + lr;
+      for (int i = 0; i < PB; ++i) {
+        const int row = wm * WTM + i * 16 + l16;
         a[i] = *reinterpret_cast<const u32x4*>(ab + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int row = wn * WTN + j * 32 + lr;
+      for (int j = 0; j < CB; ++j) {
+        const int row = wn * WTN + j * 16 + l16;
         b[j] = *reinterpret_cast<const u32x4*>(bb + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
       }
     };
     load_frags(0, af[0], bf[0]);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      if (ks + 1 < 4) load_frags(ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);   // in flight under the MFMAs of ks
+    for (int ks = 0; ks < 2; ++ks) {
+      if (ks + 1 < 2) load_frags(ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);   // in flight under the MFMAs of ks
       __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMAs (else the two register sets are merged)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < PB; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          // transposed product (A = weights, B = pixels): D[channel][pixel] -- four consecutive channels of one pixel
-          // sit in consecutive registers, so the epilogue stages 8-byte packs instead of 2-byte scalars
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[ks & 1][j]),
+        for (int j = 0; j < CB; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf[ks & 1][j]),
                                                                __builtin_bit_cast(bf16x8, af[ks & 1][i]), acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -210,32 +212,30 @@ __global__ __launch_bounds__(512) void gather_gemm_v2_kernel(const DescPack pack
   const unsigned long long t2 = ablate == 5 ? __builtin_amdgcn_s_memtime() : 0ull;
   if (ablate == 4) return;
   // ---- epilogue ----
-  // D row = channel (e&3) + 8(e>>2) + 4lh of its 32-block, col = pixel lr.  The tile is staged through the (now idle)
+  // D row = channel 4*kg + e of its 16-block, col = pixel l16.  The tile is staged through the (now idle)
   // LDS ring as bf16 [pixel][BN (+8 pad)] with 8-byte writes (row stride 16*odd bytes: 2-way instead of 32-way bank
   // conflicts) and written back with 16-byte stores, one 2*BN-byte row per BN/8 lanes.
   __syncthreads();                       // every wave is done reading the ring
   constexpr int CROW = BN * 2 + 16;
   unsigned char* ctile = smem;
 #pragma unroll
-  for (int j = 0; j < TN; ++j)
+  for (int j = 0; j < CB; ++j) {
+    const int col0 = wn * WTN + j * 16 + 4 * kg;                       // first of this lane's four channels
+    float bq[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int col0 = wn * WTN + j * 32 + 8 * q + 4 * lh;
-      float bq[4];
+    for (int k = 0; k < 4; ++k) bq[k] = (bias != nullptr && n0 + col0 + k < wrows) ? bias[n0 + col0 + k] : 0.f;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) bq[k] = (bias != nullptr && n0 + col0 + k < wrows) ? bias[n0 + col0 + k] : 0.f;
+    for (int i = 0; i < PB; ++i) {
+      const int row = wm * WTM + i * 16 + l16;
+      float v[4];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = wm * WTM + i * 32 + lr;
-        float v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = n0 + col0 + k < wrows ? apply_act(acc[i][j][q * 4 + k] + bq[k], act) : 0.f;
-        u32x2 pk;
-        pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-        pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-        *reinterpret_cast<u32x2*>(ctile + row * CROW + col0 * 2) = pk;
-      }
+      for (int k = 0; k < 4; ++k) v[k] = n0 + col0 + k < wrows ? apply_act(acc[i][j][k] + bq[k], act) : 0.f;
+      u32x2 pk;
+      pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+      pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+      *reinterpret_cast<u32x2*>(ctile + row * CROW + col0 * 2) = pk;
     }
+  }
   __syncthreads();
   constexpr int CPR = BN / 8;             // 16-byte chunks per tile row
   constexpr int RPP = 512 / CPR;          // rows per pass
