@@ -1,4 +1,6 @@
 """DefectGanModel (models/defectgan_model.py:18-104,173-314): the loss graphs of the D step and the G step."""
+import os
+
 import torch
 
 from ..networks.discriminator import DefectGanDiscriminator
@@ -47,6 +49,17 @@ class DefectGanModel(BaseModel):
     def _mean(terms):
         return torch.stack(terms).mean()
 
+    def _netD_batched(self, *images):
+        """netD(x) for several image batches in ONE pass over their concatenation.  The discriminator has no batch
+        statistics (PatchGAN convs + LeakyReLU only, discriminator.py:60-90), so this is the same function as the
+        reference's one call per batch -- with 2-4x fewer, 2-4x larger kernels on its small-M deep layers and one weight
+        gradient per layer instead of one per call."""
+        if os.environ.get("DEI2I_SPLIT_D"):               # A/B switch: the reference's call-per-batch structure
+            return [self.netD(t) for t in images]
+        sizes = [t.shape[0] for t in images]
+        src, cls = self.netD(torch.cat(images, 0))
+        return list(zip(src.split(sizes), cls.split(sizes)))
+
     def _compute_generator_loss(self, bg_data, df_labels, df_data):
         """defectgan_model.py:173-249"""
         nm_labels, df_labels = self._get_labels(df_labels)
@@ -62,8 +75,8 @@ class DefectGanModel(BaseModel):
         for p in d_params:
             p.requires_grad_(False)
         try:
-            fake_defects_src, fake_defects_cls = self.netD(fake_defects)
-            fake_normals_src, fake_normals_cls = self.netD(fake_normals)
+            (fake_defects_src, fake_defects_cls), (fake_normals_src, fake_normals_cls) = \
+                self._netD_batched(fake_defects, fake_normals)
         finally:
             for p in d_params:
                 p.requires_grad_(True)
@@ -85,10 +98,8 @@ class DefectGanModel(BaseModel):
         with torch.no_grad():
             fake_defects, _ = self.netG(bg_data, df_labels)
             fake_normals, _ = self.netG(df_data, nm_labels)
-        fake_defects_src, _ = self.netD(fake_defects.detach())
-        fake_normals_src, _ = self.netD(fake_normals.detach())
-        real_defects_src, real_defects_cls = self.netD(df_data)
-        real_normals_src, real_normals_cls = self.netD(bg_data)
+        (fake_defects_src, _), (fake_normals_src, _), (real_defects_src, real_defects_cls), \
+            (real_normals_src, real_normals_cls) = self._netD_batched(fake_defects.detach(), fake_normals.detach(), df_data, bg_data)
         gan_loss = [self._cal_loss(fake_defects_src, 0.0, "bce"), self._cal_loss(fake_normals_src, 0.0, "bce"),
                     self._cal_loss(real_defects_src, 1.0, "bce"), self._cal_loss(real_normals_src, 1.0, "bce")]
         clf_loss = [self._cal_loss(real_defects_cls, df_labels.view_as(real_defects_cls), self.clf_loss_type),

@@ -55,7 +55,7 @@ class record_kinks:
         kind_of = {L.ACT_RELU: "relu", L.ACT_LRELU: "leaky"}
 
         def conv(a, out):                # (x, weight, bias, cache, sources, geom, act); the SPADE label-path ReLU is exact
-            return (kind_of[a[6]], out) if a[6] == L.ACT_LRELU else None
+            return (kind_of[a[6]], out, "conv") if a[6] == L.ACT_LRELU else None
 
         def bn(a, out):                  # (..., act)
             return (kind_of[a[-1]], out) if a[-1] != L.ACT_NONE else None
@@ -74,7 +74,7 @@ class record_kinks:
                 if out.requires_grad:
                     r = _pick(a, out)
                     if r is not None:
-                        self.tape.append((r[0], r[1].detach().double().cpu()))
+                        self.tape.append((r[0], r[1].detach().double().cpu()) + tuple(r[2:]))
                 return out
             cls.apply = apply
             self._patched.append(cls)
@@ -84,3 +84,22 @@ class record_kinks:
         for cls in self._patched:
             del cls.apply                # fall back to torch.autograd.Function.apply
         return False
+
+
+def unbatch_discriminator(tape, ncalls, n):
+    """The product runs the discriminator ONCE on the concatenation of `ncalls` image batches of `n` (it has no batch
+    statistics); the oracle follows the reference and calls it once per batch.  Re-order the discriminator's records
+    (the fused conv+LeakyReLU sites, one run of them per D pass) into per-call order and drop the source tag."""
+    out, i = [], 0
+    while i < len(tape):
+        if len(tape[i]) > 2 and tape[i][2] == "conv" and tape[i][1].shape[0] == ncalls * n:
+            j = i
+            while j < len(tape) and len(tape[j]) > 2 and tape[j][2] == "conv" and tape[j][1].shape[0] == ncalls * n:
+                j += 1
+            for c in range(ncalls):
+                out.extend((k, t[c * n:(c + 1) * n]) for k, t, *_ in tape[i:j])
+            i = j
+        else:
+            out.append(tuple(tape[i][:2]))
+            i += 1
+    return out

@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import record_kinks, formula_fill, load_golden, make_opt
+from helpers import record_kinks, unbatch_discriminator, formula_fill, load_golden, make_opt
 from oracle import defectgan_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -112,6 +112,8 @@ def test_step_gradients_match_oracle_fp64(name, c):
         assert tape.worst < 2e-3, (tape.flips, tape.worst)      # replayed branches differ only within noise of a kink
         return out
 
+    d_tape = unbatch_discriminator(d_tape, 4, c["batch"])        # product: one D pass over 4 batches; oracle: 4 passes
+    g_tape = unbatch_discriminator(g_tape, 2, c["batch"])
     d_gan, d_clf, gD = oracle(O.train_discriminator_once, d_tape, SG, SD, None, bg.double(), labels.double(), df.double(), cfg)
     g_losses, gG = oracle(O.train_generator_once, g_tape, {k: v.clone() for k, v in SG.items()},
                           {k: v.detach() for k, v in SD.items()}, None, bg.double(), labels.double(), df.double(), cfg)
