@@ -96,8 +96,14 @@ class DefectGanModel(BaseModel):
         nm_labels, df_labels = self._get_labels(df_labels)
         self.netG.clear_spade_cache()
         with torch.no_grad():
-            fake_defects, _ = self.netG(bg_data, df_labels)
-            fake_normals, _ = self.netG(df_data, nm_labels)
+            if self.netG.training or os.environ.get("DEI2I_SPLIT_D"):
+                fake_defects, _ = self.netG(bg_data, df_labels)
+                fake_normals, _ = self.netG(df_data, nm_labels)
+            else:
+                # netG is in eval mode here (defectgan_model.py:87-90): BatchNorm uses running statistics and SPADE's
+                # InstanceNorm is per sample, so one pass over both batches is the same function as two passes
+                fakes, _ = self.netG(torch.cat([bg_data, df_data], 0), torch.cat([df_labels, nm_labels], 0))
+                fake_defects, fake_normals = fakes.split([bg_data.shape[0], df_data.shape[0]])
         (fake_defects_src, _), (fake_normals_src, _), (real_defects_src, real_defects_cls), \
             (real_normals_src, real_normals_cls) = self._netD_batched(fake_defects.detach(), fake_normals.detach(), df_data, bg_data)
         gan_loss = [self._cal_loss(fake_defects_src, 0.0, "bce"), self._cal_loss(fake_normals_src, 0.0, "bce"),
