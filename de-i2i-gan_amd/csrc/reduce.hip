@@ -289,16 +289,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 
 DEI2I_D int border_class(int i, int extent) { return i < 2 ? i : (i >= extent - 2 ? 4 - (extent - 1 - i) : 2); }
 
-// ---- SPADE backward, pass 1 ----
+// ---- SPADE backward ----
+// z = relu(v), v = xhat*(1+gamma) + beta, xhat = (x - mean)*rstd.  With g = dz*[v > 0]:
+//   dgamma = g*xhat, dbeta = g, dxhat = g*(1+gamma), dx = rstd*(sum_cell dxhat - cnt*mean(dxhat) - cnt*xhat*mean(dxhat*xhat)).
+// Both passes RECOMPUTE v from x and the gamma/beta table instead of reading the saved output z and a stored dxhat
+// tensor: pass 1 reads dz + x (2 tensors, no activation-sized write), pass 2 reads dz + x and writes dx -- 5 tensor
+// transfers instead of 7, and the op no longer keeps its output alive for backward.
 // partial[((n*chunks + chunk)*4 + q)*C + c], q: 0 sum dxhat, 1 sum dxhat*xhat, 2 sum dgamma (interior class), 3 sum dbeta (interior)
 template <typename T>
-__global__ __launch_bounds__(256) void spade_bwd_partial_kernel(const T* __restrict__ dz, const T* __restrict__ z,
-                                                                const T* __restrict__ x, const float* __restrict__ mean,
-                                                                const float* __restrict__ rstd, const T* __restrict__ gb,
-                                                                int gb_mode, T* __restrict__ dgb_dense,
-                                                                float* __restrict__ dgb_cls, T* __restrict__ dxhat,
-                                                                float* __restrict__ partial, int H, int W, int C, int up,
-                                                                int chunks) {
+__global__ __launch_bounds__(256) void spade_bwd_partial_kernel(const T* __restrict__ dz, const T* __restrict__ x,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const T* __restrict__ gb, int gb_mode,
+                                                                T* __restrict__ dgb_dense, float* __restrict__ partial, int H,
+                                                                int W, int C, int up, int chunks) {
   constexpr int VEC = Elem<T>::VEC;
   extern __shared__ float smem[];
   const int cv = C / VEC, rpp = 256 / cv;
@@ -317,13 +320,12 @@ __global__ __launch_bounds__(256) void spade_bwd_partial_kernel(const T* __restr
     float mv[VEC], rv[VEC];
     ldcoef<VEC>(mean + (size_t)n * C + c, mv);
     ldcoef<VEC>(rstd + (size_t)n * C + c, rv);
-    struct Row { u32x4 d, z, x, gm; size_t opix; bool interior; };
+    struct Row { u32x4 d, x, gm, bt; size_t opix; bool interior; };
     auto load = [&](int r) {
       Row q;
       const int h = r / W, w = r - h * W;
       q.opix = (size_t)n * HW + r;
       q.d = *reinterpret_cast<const u32x4*>(dz + q.opix * C + c);
-      q.z = *reinterpret_cast<const u32x4*>(z + q.opix * C + c);
       q.x = *reinterpret_cast<const u32x4*>(x + (((size_t)n * Hs + (h >> up)) * Ws + (w >> up)) * C + c);
       size_t gpix = q.opix;
       q.interior = true;
@@ -333,22 +335,22 @@ __global__ __launch_bounds__(256) void spade_bwd_partial_kernel(const T* __restr
         q.interior = cy == 2 && cx == 2;
       }
       q.gm = *reinterpret_cast<const u32x4*>(gb + gpix * 2 * C + c);
+      q.bt = *reinterpret_cast<const u32x4*>(gb + gpix * 2 * C + C + c);
       return q;
     };
     auto use = [&](const Row& q) {
-      float d[VEC], zz[VEC], xv[VEC], gm[VEC], dg[VEC], db[VEC], dxh[VEC];
-      Elem<T>::unpack(q.d, d); Elem<T>::unpack(q.z, zz); Elem<T>::unpack(q.x, xv); Elem<T>::unpack(q.gm, gm);
+      float d[VEC], xv[VEC], gm[VEC], bt[VEC], dg[VEC], db[VEC];
+      Elem<T>::unpack(q.d, d); Elem<T>::unpack(q.x, xv); Elem<T>::unpack(q.gm, gm); Elem<T>::unpack(q.bt, bt);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        const float g = zz[e] > 0.f ? d[e] : 0.f;
         const float xh = (xv[e] - mv[e]) * rv[e];
+        const float g = fmaf(xh, 1.f + gm[e], bt[e]) > 0.f ? d[e] : 0.f;
+        const float dxh = g * (1.f + gm[e]);
         dg[e] = g * xh;
         db[e] = g;
-        dxh[e] = g * (1.f + gm[e]);
-        v[0][e] += dxh[e];
-        v[1][e] = fmaf(dxh[e], xh, v[1][e]);
+        v[0][e] += dxh;
+        v[1][e] = fmaf(dxh, xh, v[1][e]);
       }
-      *reinterpret_cast<u32x4*>(dxhat + q.opix * C + c) = Elem<T>::pack(dxh);
       if (gb_mode == 0) {
         *reinterpret_cast<u32x4*>(dgb_dense + q.opix * 2 * C + c) = Elem<T>::pack(dg);
         *reinterpret_cast<u32x4*>(dgb_dense + q.opix * 2 * C + C + c) = Elem<T>::pack(db);
@@ -377,10 +379,10 @@ __global__ __launch_bounds__(256) void spade_bwd_partial_kernel(const T* __restr
 // class-mode gamma/beta gradients of the 24 border classes: one workgroup per (class, image) walks that class's
 // O(perimeter) pixel list and reduces dgamma = g*xhat, dbeta = g with plain stores (deterministic, no atomics).
 template <typename T>
-__global__ __launch_bounds__(256) void spade_bwd_border_kernel(const T* __restrict__ dz, const T* __restrict__ z,
-                                                               const T* __restrict__ x, const float* __restrict__ mean,
-                                                               const float* __restrict__ rstd, float* __restrict__ dgb_cls,
-                                                               int H, int W, int C, int up) {
+__global__ __launch_bounds__(256) void spade_bwd_border_kernel(const T* __restrict__ dz, const T* __restrict__ x,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               const T* __restrict__ gb, float* __restrict__ dgb_cls, int H,
+                                                               int W, int C, int up) {
   constexpr int VEC = Elem<T>::VEC;
   extern __shared__ float smem[];
   const int cls = blockIdx.x, n = blockIdx.y;
@@ -398,20 +400,23 @@ __global__ __launch_bounds__(256) void spade_bwd_border_kernel(const T* __restri
   for (int e = 0; e < VEC; ++e) v[0][e] = v[1][e] = 0.f;
   if (prow < rpp) {
     const int c = vcol * VEC;
-    float mv[VEC], rv[VEC];
+    float mv[VEC], rv[VEC], gm[VEC], bt[VEC];
     ldcoef<VEC>(mean + (size_t)n * C + c, mv);
     ldcoef<VEC>(rstd + (size_t)n * C + c, rv);
+    const size_t gpix = ((size_t)n * 5 + cy) * 5 + cx;
+    Elem<T>::unpack(*reinterpret_cast<const u32x4*>(gb + gpix * 2 * C + c), gm);
+    Elem<T>::unpack(*reinterpret_cast<const u32x4*>(gb + gpix * 2 * C + C + c), bt);
     for (int i = prow; i < count; i += rpp) {
       const int h = y0 + i / nx, w = x0 + i % nx;
       const size_t opix = ((size_t)n * H + h) * W + w;
-      float d[VEC], zz[VEC], xv[VEC];
+      float d[VEC], xv[VEC];
       Elem<T>::unpack(*reinterpret_cast<const u32x4*>(dz + opix * C + c), d);
-      Elem<T>::unpack(*reinterpret_cast<const u32x4*>(z + opix * C + c), zz);
       Elem<T>::unpack(*reinterpret_cast<const u32x4*>(x + (((size_t)n * Hs + (h >> up)) * Ws + (w >> up)) * C + c), xv);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        const float g = zz[e] > 0.f ? d[e] : 0.f;
-        v[0][e] = fmaf(g, (xv[e] - mv[e]) * rv[e], v[0][e]);
+        const float xh = (xv[e] - mv[e]) * rv[e];
+        const float g = fmaf(xh, 1.f + gm[e], bt[e]) > 0.f ? d[e] : 0.f;
+        v[0][e] = fmaf(g, xh, v[0][e]);
         v[1][e] += g;
       }
     }
@@ -441,11 +446,12 @@ __global__ __launch_bounds__(256) void spade_bwd_finalize_kernel(const float* __
   }
 }
 
-// dx (source resolution) = rstd * ( sum_cell dxhat - cnt*c1 - cnt*xhat*c2 ) (+ addend)
+// dx (source resolution) = rstd * ( sum_cell dxhat - cnt*c1 - cnt*xhat*c2 ) (+ addend); dxhat recomputed from dz, x, gamma/beta
 template <typename T>
-__global__ void spade_bwd_apply_kernel(const T* __restrict__ dxhat, const T* __restrict__ x, const float* __restrict__ mean,
-                                       const float* __restrict__ rstd, const float* __restrict__ coef,
-                                       const T* __restrict__ addend, T* __restrict__ dx, int N, int H, int W, int C, int up) {
+__global__ void spade_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ x, const float* __restrict__ mean,
+                                       const float* __restrict__ rstd, const T* __restrict__ gb, int gb_mode,
+                                       const float* __restrict__ coef, const T* __restrict__ addend, T* __restrict__ dx, int N,
+                                       int H, int W, int C, int up) {
   constexpr int VEC = Elem<T>::VEC;
   const int cv = C / VEC;
   const int Hs = H >> up, Ws = W >> up;
@@ -457,29 +463,34 @@ __global__ void spade_bwd_apply_kernel(const T* __restrict__ dxhat, const T* __r
     const int ws = (int)(r % Ws); r /= Ws;
     const int hs = (int)(r % Hs);
     const int n = (int)(r / Hs);
-    float acc[VEC], xv[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
-    for (int a = 0; a < (1 << up); ++a)
-      for (int b = 0; b < (1 << up); ++b) {
-        float t[VEC];
-        Elem<T>::unpack(*reinterpret_cast<const u32x4*>(
-                            dxhat + (((size_t)n * H + ((hs << up) + a)) * W + ((ws << up) + b)) * C + c), t);
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) acc[e] += t[e];
-      }
-    Elem<T>::unpack(*reinterpret_cast<const u32x4*>(x + i * VEC), xv);
-    float ad[VEC];
-    if (addend != nullptr) Elem<T>::unpack(*reinterpret_cast<const u32x4*>(addend + i * VEC), ad);
-    float mv[VEC], rv[VEC], k1[VEC], k2[VEC];
+    float acc[VEC], xv[VEC], xh[VEC], mv[VEC], rv[VEC], k1[VEC], k2[VEC];
     ldcoef<VEC>(mean + (size_t)n * C + c, mv);
     ldcoef<VEC>(rstd + (size_t)n * C + c, rv);
+    Elem<T>::unpack(*reinterpret_cast<const u32x4*>(x + i * VEC), xv);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { acc[e] = 0.f; xh[e] = (xv[e] - mv[e]) * rv[e]; }
+    for (int a = 0; a < (1 << up); ++a)
+      for (int b = 0; b < (1 << up); ++b) {
+        const int h = (hs << up) + a, w = (ws << up) + b;
+        const size_t opix = ((size_t)n * H + h) * W + w;
+        const size_t gpix = gb_mode == 0 ? opix : ((size_t)n * 5 + border_class(h, H)) * 5 + border_class(w, W);
+        float d[VEC], gm[VEC], bt[VEC];
+        Elem<T>::unpack(*reinterpret_cast<const u32x4*>(dz + opix * C + c), d);
+        Elem<T>::unpack(*reinterpret_cast<const u32x4*>(gb + gpix * 2 * C + c), gm);
+        Elem<T>::unpack(*reinterpret_cast<const u32x4*>(gb + gpix * 2 * C + C + c), bt);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float g = fmaf(xh[e], 1.f + gm[e], bt[e]) > 0.f ? d[e] : 0.f;
+          acc[e] = fmaf(g, 1.f + gm[e], acc[e]);
+        }
+      }
+    float ad[VEC];
+    if (addend != nullptr) Elem<T>::unpack(*reinterpret_cast<const u32x4*>(addend + i * VEC), ad);
     ldcoef<VEC>(coef + ((size_t)n * 2) * C + c, k1);
     ldcoef<VEC>(coef + ((size_t)n * 2 + 1) * C + c, k2);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      const float xh = (xv[e] - mv[e]) * rv[e];
-      float v = rv[e] * (acc[e] - cnt * k1[e] - cnt * xh * k2[e]);
+      float v = rv[e] * (acc[e] - cnt * k1[e] - cnt * xh[e] * k2[e]);
       if (addend != nullptr) v += ad[e];
       acc[e] = v;
     }
@@ -691,11 +702,9 @@ int dei2i_bn_bwd_apply(int dtype, size_t pixels, int C, const void* dz, const vo
   return (int)hipGetLastError();
 }
 
-int dei2i_spade_bwd_partial(int dtype, int N, int H, int W, int C, int up, const void* dz, const void* z, const void* x,
-                            const float* mean, const float* rstd, const void* gb, int gb_mode, void* dgb, void* dxhat,
-                            float* partial, dei2i_stream s) {
-  if (N <= 0 || H <= 0 || W <= 0 || !cv_ok(dtype, C) || up < 0 || up > 1 || !dz || !z || !x || !mean || !rstd || !gb || !dgb ||
-      !dxhat || !partial)
+int dei2i_spade_bwd_partial(int dtype, int N, int H, int W, int C, int up, const void* dz, const void* x, const float* mean,
+                            const float* rstd, const void* gb, int gb_mode, void* dgb, float* partial, dei2i_stream s) {
+  if (N <= 0 || H <= 0 || W <= 0 || !cv_ok(dtype, C) || up < 0 || up > 1 || !dz || !x || !mean || !rstd || !gb || !dgb || !partial)
     return DEI2I_ERR_BAD_ARG;
   if (gb_mode == 1 && (H < 4 || W < 4)) return DEI2I_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)s;
@@ -706,30 +715,28 @@ int dei2i_spade_bwd_partial(int dtype, int N, int H, int W, int C, int up, const
   }
   if (dtype == DT_BF16)
     hipLaunchKernelGGL(spade_bwd_partial_kernel<bf16_t>, dim3(chunks, N), dim3(256), combine_lds(dtype, 4), st,
-                       (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)x, mean, rstd, (const bf16_t*)gb, gb_mode,
-                       gb_mode == 0 ? (bf16_t*)dgb : (bf16_t*)nullptr, gb_mode == 1 ? (float*)dgb : (float*)nullptr,
-                       (bf16_t*)dxhat, partial, H, W, C, up, chunks);
+                       (const bf16_t*)dz, (const bf16_t*)x, mean, rstd, (const bf16_t*)gb, gb_mode,
+                       gb_mode == 0 ? (bf16_t*)dgb : (bf16_t*)nullptr, partial, H, W, C, up, chunks);
   else
     hipLaunchKernelGGL(spade_bwd_partial_kernel<float>, dim3(chunks, N), dim3(256), combine_lds(dtype, 4), st,
-                       (const float*)dz, (const float*)z, (const float*)x, mean, rstd, (const float*)gb, gb_mode,
-                       gb_mode == 0 ? (float*)dgb : (float*)nullptr, gb_mode == 1 ? (float*)dgb : (float*)nullptr,
-                       (float*)dxhat, partial, H, W, C, up, chunks);
+                       (const float*)dz, (const float*)x, mean, rstd, (const float*)gb, gb_mode,
+                       gb_mode == 0 ? (float*)dgb : (float*)nullptr, partial, H, W, C, up, chunks);
   if (gb_mode == 1) {
     if (dtype == DT_BF16)
       hipLaunchKernelGGL(spade_bwd_border_kernel<bf16_t>, dim3(25, N), dim3(256), combine_lds(dtype, 2), st, (const bf16_t*)dz,
-                         (const bf16_t*)z, (const bf16_t*)x, mean, rstd, (float*)dgb, H, W, C, up);
+                         (const bf16_t*)x, mean, rstd, (const bf16_t*)gb, (float*)dgb, H, W, C, up);
     else
       hipLaunchKernelGGL(spade_bwd_border_kernel<float>, dim3(25, N), dim3(256), combine_lds(dtype, 2), st, (const float*)dz,
-                         (const float*)z, (const float*)x, mean, rstd, (float*)dgb, H, W, C, up);
+                         (const float*)x, mean, rstd, (const float*)gb, (float*)dgb, H, W, C, up);
   }
   return (int)hipGetLastError();
 }
 
-int dei2i_spade_bwd_apply(int dtype, int N, int H, int W, int C, int up, const void* dxhat, const void* x, const float* mean,
-                          const float* rstd, const float* partial, int chunks, float* dgb_cls, float* coef,
-                          const void* addend, void* dx, dei2i_stream s) {
+int dei2i_spade_bwd_apply(int dtype, int N, int H, int W, int C, int up, const void* dz, const void* x, const float* mean,
+                          const float* rstd, const void* gb, int gb_mode, const float* partial, int chunks, float* dgb_cls,
+                          float* coef, const void* addend, void* dx, dei2i_stream s) {
   const int vec = dtype == DT_BF16 ? 8 : 4;
-  if (N <= 0 || H <= 0 || W <= 0 || !cv_ok(dtype, C) || up < 0 || up > 1 || !dxhat || !x || !mean || !rstd || !partial ||
+  if (N <= 0 || H <= 0 || W <= 0 || !cv_ok(dtype, C) || up < 0 || up > 1 || !dz || !x || !mean || !rstd || !gb || !partial ||
       !coef || !dx)
     return DEI2I_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)s;
@@ -738,11 +745,11 @@ int dei2i_spade_bwd_apply(int dtype, int N, int H, int W, int C, int up, const v
   const size_t total = (size_t)N * (H >> up) * (W >> up) * (C / vec);
   const unsigned grid = grid_for(total, 256, 256u * 16u);
   if (dtype == DT_BF16)
-    hipLaunchKernelGGL(spade_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dxhat, (const bf16_t*)x, mean,
-                       rstd, (const float*)coef, (const bf16_t*)addend, (bf16_t*)dx, N, H, W, C, up);
+    hipLaunchKernelGGL(spade_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)x, mean,
+                       rstd, (const bf16_t*)gb, gb_mode, (const float*)coef, (const bf16_t*)addend, (bf16_t*)dx, N, H, W, C, up);
   else
-    hipLaunchKernelGGL(spade_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dxhat, (const float*)x, mean,
-                       rstd, (const float*)coef, (const float*)addend, (float*)dx, N, H, W, C, up);
+    hipLaunchKernelGGL(spade_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dz, (const float*)x, mean,
+                       rstd, (const float*)gb, gb_mode, (const float*)coef, (const float*)addend, (float*)dx, N, H, W, C, up);
   return (int)hipGetLastError();
 }
 

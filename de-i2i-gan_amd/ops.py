@@ -397,31 +397,31 @@ class _SpadeRelu(torch.autograd.Function):
         L.check(lib.dei2i_spade_act_fwd(prec.code, n, h, w, c, 1 if up else 0, _p(x), _p(mean), _p(rstd), _p(gb), gb_mode,
                                         _p(out), st), "spade_act_fwd")
         ctx.prec, ctx.up, ctx.gb_mode = prec, up, gb_mode
-        ctx.save_for_backward(x, gb, mean, rstd, out)
+        ctx.out_shape = (n, h, w, c)
+        ctx.save_for_backward(x, gb, mean, rstd)        # backward recomputes the ReLU mask; the output is not kept
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, gb, mean, rstd, out = ctx.saved_tensors
+        x, gb, mean, rstd = ctx.saved_tensors
         prec, up, gb_mode = ctx.prec, ctx.up, ctx.gb_mode
         lib = _lib_for(x)
         st = _stream()
         dev = x.device
         dout = dout.contiguous()
-        n, h, w, c = out.shape
+        n, h, w, c = ctx.out_shape
         chunks = lib.dei2i_moments_chunks(h * w)
         partial = torch.empty((n, chunks, 4, c), dtype=torch.float32, device=dev)
-        dxhat = torch.empty_like(out)
         if gb_mode == 0:
             dgb = torch.empty_like(gb)
         else:
             dgb = torch.empty((n, 5, 5, 2 * c), dtype=torch.float32, device=dev)
-        L.check(lib.dei2i_spade_bwd_partial(prec.code, n, h, w, c, 1 if up else 0, _p(dout), _p(out), _p(x), _p(mean), _p(rstd),
-                                            _p(gb), gb_mode, _p(dgb), _p(dxhat), _p(partial), st), "spade_bwd_partial")
+        L.check(lib.dei2i_spade_bwd_partial(prec.code, n, h, w, c, 1 if up else 0, _p(dout), _p(x), _p(mean), _p(rstd),
+                                            _p(gb), gb_mode, _p(dgb), _p(partial), st), "spade_bwd_partial")
         coef = torch.empty((n, 2, c), dtype=torch.float32, device=dev)
         dx = torch.empty_like(x)
-        L.check(lib.dei2i_spade_bwd_apply(prec.code, n, h, w, c, 1 if up else 0, _p(dxhat), _p(x), _p(mean), _p(rstd), _p(partial),
-                                          chunks, _p(dgb) if gb_mode == 1 else None, _p(coef), None, _p(dx), st),
+        L.check(lib.dei2i_spade_bwd_apply(prec.code, n, h, w, c, 1 if up else 0, _p(dout), _p(x), _p(mean), _p(rstd), _p(gb), gb_mode,
+                                          _p(partial), chunks, _p(dgb) if gb_mode == 1 else None, _p(coef), None, _p(dx), st),
                 "spade_bwd_apply")
         if gb_mode == 1 and prec.dtype != torch.float32:
             dgb_t = torch.empty(dgb.shape, dtype=prec.dtype, device=dev)

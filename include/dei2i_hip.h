@@ -136,18 +136,16 @@ int dei2i_bn_bwd_partial(int dtype, size_t pixels, int C, const void* dz, const 
 int dei2i_bn_bwd_apply(int dtype, size_t pixels, int C, const void* dz, const void* y, const float* a, const float* b,
                        const float* mean, const float* rstd, int act, int train, const float* partial, int chunks,
                        float* dweight, float* dbias, void* dy, dei2i_stream s);
-/* SPADE backward, pass 1: g = dz*[z>0]; dgamma = g*xhat, dbeta = g -> dgb (dense T tensor, or fp32 (N,5,5,2C)
- * in class mode; zeroed by the call); dxhat = g*(1+gamma) written to `dxhat`; per-(n,c) partial sums of dxhat,
- * dxhat*xhat and the interior-class dgamma/dbeta -> partial (N, chunks, 4, C).
- * chunks = dei2i_moments_chunks(H*W of the OUTPUT). */
-int dei2i_spade_bwd_partial(int dtype, int N, int H, int W, int C, int up, const void* dz, const void* z, const void* x,
-                            const float* mean, const float* rstd, const void* gb, int gb_mode, void* dgb,
-                            void* dxhat, float* partial, dei2i_stream s);
-/* pass 2 (finalize + apply).  coef: fp32 scratch (N,2,C).  dgb_cls: the class-mode fp32 (N,5,5,2C) buffer of pass 1
- * (interior-class sums are added here) or NULL in dense mode.
- * dx[n,hs,ws,c] = rstd * ( sum_cell dxhat - cnt*(s1/M) - xhat*cnt*(s2/M) ) (+ addend) at source resolution */
-int dei2i_spade_bwd_apply(int dtype, int N, int H, int W, int C, int up, const void* dxhat, const void* x,
-                          const float* mean, const float* rstd, const float* partial, int chunks, float* dgb_cls,
+/* SPADE backward.  z = relu(v), v = xhat*(1+gamma)+beta is RECOMPUTED from x and the gamma/beta table in both passes (the
+ * op keeps neither its output nor a dxhat tensor): g = dz*[v>0]; dgamma = g*xhat, dbeta = g -> dgb (dense T tensor, or
+ * fp32 (N,5,5,2C) border-class table); partial (N, chunks, 4, C) fp32 sums of dxhat = g*(1+gamma), dxhat*xhat and the
+ * interior-class dgamma / dbeta.  chunks = dei2i_moments_chunks(H*W of the OUTPUT). */
+int dei2i_spade_bwd_partial(int dtype, int N, int H, int W, int C, int up, const void* dz, const void* x, const float* mean,
+                            const float* rstd, const void* gb, int gb_mode, void* dgb, float* partial, dei2i_stream s);
+/* pass 2 (finalize + apply): dx = rstd*(sum_cell dxhat - cnt*mean(dxhat) - cnt*xhat*mean(dxhat*xhat)) (+ addend).
+ * coef: fp32 scratch (N,2,C).  dgb_cls: the class-mode fp32 (N,5,5,2C) buffer of pass 1 (interior sums are added), or NULL. */
+int dei2i_spade_bwd_apply(int dtype, int N, int H, int W, int C, int up, const void* dz, const void* x, const float* mean,
+                          const float* rstd, const void* gb, int gb_mode, const float* partial, int chunks, float* dgb_cls,
                           float* coef, const void* addend, void* dx, dei2i_stream s);
 
 /* ---- generator heads + compose (generator.py:266-275) ----

@@ -67,8 +67,8 @@ for (H, W, C) in ((256, 256, 64), (128, 128, 128), (64, 64, 256)):
     dgb = torch.empty(N, 5, 5, 2 * C, device=DEV)
     coef = torch.empty(N, 2, C, device=DEV)
     z = torch.relu(torch.randn(N, H, W, C, device=DEV)).bfloat16()
-    timeit(tag + " spade_bwd_partial", lambda: lib.dei2i_spade_bwd_partial(BF, N, H, W, C, 0, p(dz), p(z), p(x), p(mean_n), p(rstd_n), p(gb), 1, p(dgb), p(out2), p(partial), st), 4 * T)
-    timeit(tag + " spade_bwd_apply", lambda: lib.dei2i_spade_bwd_apply(BF, N, H, W, C, 0, p(out2), p(x), p(mean_n), p(rstd_n), p(partial), chunks, p(dgb), p(coef), None, p(out), st), 3 * T)
+    timeit(tag + " spade_bwd_partial", lambda: lib.dei2i_spade_bwd_partial(BF, N, H, W, C, 0, p(dz), p(x), p(mean_n), p(rstd_n), p(gb), 1, p(dgb), p(partial), st), 2 * T)
+    timeit(tag + " spade_bwd_apply", lambda: lib.dei2i_spade_bwd_apply(BF, N, H, W, C, 0, p(dz), p(x), p(mean_n), p(rstd_n), p(gb), 1, p(partial), chunks, p(dgb), p(coef), None, p(out), st), 3 * T)
     timeit(tag + " colsum", lambda: lib.dei2i_colsum(BF, pix, C, p(dz), p(dwt), st), T)
     timeit(tag + " torch add (reference point)", lambda: torch.add(x, y, out=out), 3 * T)
     del x, y, dz, out, out2, ext, z
