@@ -323,7 +323,7 @@ int dei2i_conv2d_wgrad(const dei2i_conv* c, const void* x, const void* dy, float
   if (!valid_conv(c) || !x || !dy || !dw_packed) return DEI2I_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)s;
   GatherDesc g = make_fwd_desc(to_shape(c), c->CinS);
-  return (int)wgrad_gemm(c->dtype, g, x, dy, c->Cout, c->CoutS, dw_packed, st);
+  return (int)wgrad_gemm(c->dtype, g, x, dy, c->Cout, c->CoutS, dw_packed, 0, nullptr, st);
 }
 
 /* wgrad straight to the OIHW fp32 gradient: the bf16 hot shapes take the LDS-DMA slab kernel + fused reduce/un-pack
@@ -350,9 +350,10 @@ int dei2i_conv2d_wgrad_oihw(const dei2i_conv* c, const void* x, const void* dy, 
       return (int)wgrad_reduce_unpack(scratch, nsplit, (long long)packed, dw_oihw, c->Cout, c->Cin, c->CinS, c->kh * c->kw, st);
     if (e != hipErrorNotSupported) return (int)e;
   }
-  hipError_t e = wgrad_gemm(c->dtype, g, x, dy, c->Cout, c->CoutS, scratch, st);
+  int nsplit = 0;
+  hipError_t e = wgrad_gemm(c->dtype, g, x, dy, c->Cout, c->CoutS, scratch, scratch_elems, &nsplit, st);
   if (e != hipSuccess) return (int)e;
-  return dei2i_unpack_wgrad(c, scratch, dw_oihw, 0.f, s);
+  return (int)wgrad_reduce_unpack(scratch, nsplit, (long long)packed, dw_oihw, c->Cout, c->Cin, c->CinS, c->kh * c->kw, st);
 }
 
 int dei2i_fold_pad(int dtype, int N, int H, int W, int C, int pad, int pad_mode, int up, const void* dx_ext,

@@ -320,15 +320,20 @@ template <int ROWB> DEI2I_D int tr_swz(int row) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// wgrad:  dw[co][k] += sum_m dy[m][co] * gather(src)[m][k]         (fp32 atomics into a zeroed buffer)
+// wgrad:  dw[co][k] = sum_m dy[m][co] * gather(src)[m][k]
+// The pixel range is split over gridDim.z; split z stores its partial to slab z (dw + z*slab_elems, plain stores) and
+// wgrad_reduce_unpack sums the slabs in a fixed order -- deterministic, no atomics.  slab_elems == 0 with direct == 0
+// is the legacy accumulate-with-atomics mode kept for callers that hand in a bare packed buffer (dei2i_conv2d_wgrad).
 // ------------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN>
 __global__ __launch_bounds__(256) void wgrad_kernel(const GatherDesc g, const T* __restrict__ src,
                                                     const T* __restrict__ dy, const int co_rows, const int ldy,
-                                                    float* __restrict__ dw, const int tiles_k,
-                                                    const int chunks_per_split, const int direct) {
+                                                    float* __restrict__ dw_base, const int tiles_k,
+                                                    const int chunks_per_split, const int direct,
+                                                    const long long slab_elems) {
   constexpr int VEC = Elem<T>::VEC;
   constexpr bool IS_BF16 = sizeof(T) == 2;
+  float* __restrict__ dw = dw_base + (size_t)blockIdx.z * (size_t)slab_elems;
   constexpr int BR = 128 / (int)sizeof(T);           // pixels per reduction chunk (64 bf16 / 32 f32)
   constexpr int VPR_A = BM / VEC, VPR_B = BN / VEC;  // 16-byte vectors per LDS row
   constexpr int RPP_A = 256 / VPR_A, RPP_B = 256 / VPR_B;   // rows covered per pass
@@ -669,14 +674,17 @@ hipError_t gather_gemm(int dtype, const GatherDesc& g, const void* src, const vo
 
 template <typename T, int BM, int BN>
 static hipError_t launch_wg(const GatherDesc& g, const void* src, const void* dy, int co_rows, int ldy, float* dw,
-                            hipStream_t st) {
+                            size_t capacity_elems, int* nsplit_out, hipStream_t st) {
   constexpr int BR = 128 / (int)sizeof(T);
   const int tiles_c = (co_rows + BM - 1) / BM;
   const int tiles_k = (g.K + BN - 1) / BN;
   const int nchunks = (g.M + BR - 1) / BR;
   const int tiles = tiles_c * tiles_k;
-  int splits = (4 * g_num_cu + tiles - 1) / tiles;
+  const bool slabs = nsplit_out != nullptr;            // deterministic mode: one slab per split, reduced by the caller
+  int splits = ((slabs ? 2 : 4) * g_num_cu + tiles - 1) / tiles;     // every split costs a slab write + read
   if (splits > nchunks / 2) splits = nchunks / 2;
+  const long long slab_elems = (long long)co_rows * g.K;
+  if (slabs && (size_t)slab_elems * (size_t)splits > capacity_elems) splits = (int)(capacity_elems / (size_t)slab_elems);
   if (splits < 1) splits = 1;
   const int cps = (nchunks + splits - 1) / splits;
   const int zs = (nchunks + cps - 1) / cps;
@@ -688,26 +696,30 @@ static hipError_t launch_wg(const GatherDesc& g, const void* src, const void* dy
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  if (zs > 1) {        // accumulate with fp32 atomics into a zeroed buffer; a single split stores directly
+  if (zs > 1 && !slabs) {        // legacy: accumulate with fp32 atomics into a zeroed buffer
     hipError_t e = hipMemsetAsync(dw, 0, (size_t)co_rows * g.K * sizeof(float), st);
     if (e != hipSuccess) return e;
   }
+  if (slabs) *nsplit_out = zs;
   prof_begin(PROF_WGRAD, 2.0 * (double)g.M * (double)(g.th * g.tw) * (double)g.Clog * (double)co_rows, st);
   hipLaunchKernelGGL(kern, dim3(tiles, 1, zs), dim3(256), lds, st, g, (const T*)src, (const T*)dy, co_rows, ldy, dw,
-                     tiles_k, cps, zs == 1 ? 1 : 0);
+                     tiles_k, cps, (zs == 1 || slabs) ? 1 : 0, slabs ? slab_elems : 0ll);
   prof_end(PROF_WGRAD, st);
   return hipGetLastError();
 }
 
 hipError_t wgrad_gemm(int dtype, const GatherDesc& g, const void* src, const void* dy, int co_rows, int ldy, float* dw,
-                      hipStream_t st) {
-  if (g.M <= 0) return hipSuccess;
-  if (dtype == DT_BF16) {
-    if (co_rows > 64) return launch_wg<bf16_t, 128, 128>(g, src, dy, co_rows, ldy, dw, st);
-    return launch_wg<bf16_t, 64, 128>(g, src, dy, co_rows, ldy, dw, st);
+                      size_t capacity_elems, int* nsplit_out, hipStream_t st) {
+  if (g.M <= 0) {
+    if (nsplit_out) *nsplit_out = 0;      // empty sum: the reduce kernel writes zeros
+    return hipSuccess;
   }
-  if (co_rows > 64) return launch_wg<float, 128, 128>(g, src, dy, co_rows, ldy, dw, st);
-  return launch_wg<float, 64, 128>(g, src, dy, co_rows, ldy, dw, st);
+  if (dtype == DT_BF16) {
+    if (co_rows > 64) return launch_wg<bf16_t, 128, 128>(g, src, dy, co_rows, ldy, dw, capacity_elems, nsplit_out, st);
+    return launch_wg<bf16_t, 64, 128>(g, src, dy, co_rows, ldy, dw, capacity_elems, nsplit_out, st);
+  }
+  if (co_rows > 64) return launch_wg<float, 128, 128>(g, src, dy, co_rows, ldy, dw, capacity_elems, nsplit_out, st);
+  return launch_wg<float, 64, 128>(g, src, dy, co_rows, ldy, dw, capacity_elems, nsplit_out, st);
 }
 
 void set_num_cu(int n) { g_num_cu = n > 0 ? n : 256; }

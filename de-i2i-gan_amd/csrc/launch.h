@@ -44,14 +44,16 @@ hipError_t gather_gemm(int dtype, const GatherDesc& g, const void* src, const vo
 hipError_t gather_gemm_multi(int dtype, const GatherDesc* descs, const long long* woffs, int n, const void* src,
                              const void* wgt, int wrows, const float* bias, void* out, float* ws, size_t ws_bytes, int ldc,
                              int act, hipStream_t st, bool compact_ws = false);
+// nsplit_out != nullptr: dw holds up to capacity_elems floats; split z writes slab z, *nsplit_out slabs to be summed
+// by wgrad_reduce_unpack (deterministic).  nsplit_out == nullptr: dw is one packed buffer, splits accumulate with atomics.
 hipError_t wgrad_gemm(int dtype, const GatherDesc& g, const void* src, const void* dy, int co_rows, int ldy, float* dw,
-                      hipStream_t st);
+                      size_t capacity_elems, int* nsplit_out, hipStream_t st);
 
 hipError_t wgrad_v2(const GatherDesc& g, const void* src, const void* dy, int co_rows, int ldy, float* slabs,
                     size_t slab_capacity_elems, int num_cu, int* nsplit_out, hipStream_t st);
 hipError_t wgrad_halo(const GatherDesc& g, const void* src, const void* dy, int co_rows, int ldy, float* slabs,
                       size_t slab_capacity_elems, int num_cu, int* nsplit_out, bool force, hipStream_t st);
-hipError_t wgrad_reduce_unpack(const float* slabs, int nsplit, long long slab_elems, float* dw, int Cout, int Cin, int CinS,
+hipError_t wgrad_reduce_unpack(float* slabs, int nsplit, long long slab_elems, float* dw, int Cout, int Cin, int CinS,
                                int taps, hipStream_t st);
 
 inline unsigned grid_for(size_t work_items, int threads, unsigned cap = 256u * 8u) {

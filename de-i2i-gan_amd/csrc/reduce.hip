@@ -500,7 +500,7 @@ __global__ void spade_bwd_apply_kernel(const T* __restrict__ dz, const T* __rest
 
 // ---- column sums (bias gradient) ----
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, float* __restrict__ out, size_t rows, int C) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, float* __restrict__ partial, size_t rows, int C) {
   constexpr int VEC = Elem<T>::VEC;
   extern __shared__ float smem[];
   const int cv = C / VEC, rpp = 256 / cv;
@@ -531,8 +531,29 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, fl
   }
   block_combine<1, VEC>(v, cv, rpp, smem);
   if (prow == 0 && prow < rpp) {
+    float* dst = partial + (size_t)blockIdx.x * C + (size_t)vcol * VEC;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) atomicAdd(out + vcol * VEC + e, v[0][e]);
+    for (int e = 0; e < VEC; ++e) dst[e] = v[0][e];
+  }
+}
+
+// out[c] = sum over blocks of partial[block][c] in a fixed order (deterministic; replaces a memset + fp32 atomics).
+// One workgroup per 16 channels: thread (slice, c) sums blocks slice, slice+16, ...; the 16 slices are then added in order.
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int blocks, int C,
+                                                              float* __restrict__ out) {
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, slice = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float s = 0.f;
+  if (c < C)
+    for (int b = slice; b < blocks; b += 16) s += partial[(size_t)b * C + c];
+  red[slice][cl] = s;
+  __syncthreads();
+  if (slice == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][cl];
+    out[c] = t;
   }
 }
 
@@ -644,18 +665,22 @@ int dei2i_in_finalize(int N, int HW, int C, const float* partial, float eps, flo
   return (int)hipGetLastError();
 }
 
-int dei2i_colsum(int dtype, size_t rows, int C, const void* g, float* out, dei2i_stream s) {
-  if (rows == 0 || !cv_ok(dtype, C) || !g || !out) return DEI2I_ERR_BAD_ARG;
-  hipStream_t st = (hipStream_t)s;
-  hipError_t e = hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st);
-  if (e != hipSuccess) return (int)e;
-  size_t blocks = rows / 256;       // every workgroup ends in C same-address atomics: keep the count low, the loads deep
+int dei2i_colsum_blocks(size_t rows) {      // >= 256 rows per workgroup, one workgroup per CU at most
+  size_t blocks = rows / 256;
   if (blocks < 1) blocks = 1;
   if (blocks > 256) blocks = 256;
+  return (int)blocks;
+}
+
+int dei2i_colsum(int dtype, size_t rows, int C, const void* g, float* partial, float* out, dei2i_stream s) {
+  if (rows == 0 || !cv_ok(dtype, C) || !g || !partial || !out) return DEI2I_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)s;
+  const int blocks = dei2i_colsum_blocks(rows);
   if (dtype == DT_BF16)
-    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), combine_lds(dtype, 1), st, (const bf16_t*)g, out, rows, C);
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), combine_lds(dtype, 1), st, (const bf16_t*)g, partial, rows, C);
   else
-    hipLaunchKernelGGL(colsum_kernel<float>, dim3((unsigned)blocks), dim3(256), combine_lds(dtype, 1), st, (const float*)g, out, rows, C);
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3((unsigned)blocks), dim3(256), combine_lds(dtype, 1), st, (const float*)g, partial, rows, C);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const float*)partial, blocks, C, out);
   return (int)hipGetLastError();
 }
 

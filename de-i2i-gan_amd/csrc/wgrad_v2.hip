@@ -184,34 +184,38 @@ __global__ __launch_bounds__(512) void wgrad_v2_kernel(const GatherDesc g, const
 }
 
 // dw_oihw[co][ci][t] = sum_s slab[s][co][t][ci]  (slab reduce fused with the un-pack to the reference's OIHW layout)
-__global__ void wgrad_reduce_unpack_kernel(const float* __restrict__ slabs, int nsplit, long long slab_elems,
-                                           float* __restrict__ dw, int Cout, int Cin, int CinS, int taps) {
-  // walk the PACKED index four channels at a time (ci fastest: the nsplit slab reads are coalesced 16-byte loads, four
-  // slabs in flight per thread); the single OIHW write is the strided one
-  const size_t total4 = (size_t)Cout * taps * CinS / 4;
-  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += (size_t)gridDim.x * blockDim.x) {
-    const size_t i = q * 4;
-    const int ci = (int)(i % CinS);
-    if (ci >= Cin) continue;
-    const size_t r = i / CinS;
-    const int t = (int)(r % taps);
-    const size_t co = r / taps;
-    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0, v3 = v0;
-    const float* p = slabs + i;
+// One workgroup per (co, 64-channel block): the taps x 64 block is read tap-major (ci fastest: every slab read is a
+// coalesced 256-byte row, four slabs in flight), transposed through LDS and written ci-major -- the (ci0.., all taps)
+// range of one co is CONTIGUOUS in OIHW, so the writes are coalesced too.  Slabs are added in index order: deterministic.
+constexpr int RU_CB = 64;            // channels per block
+constexpr int RU_MAX_TAPS = 64;      // 8x8 (cls_clf at 512x512) is the largest kernel of the path
+__global__ __launch_bounds__(256) void wgrad_reduce_unpack_kernel(const float* __restrict__ slabs, int nsplit, long long slab_elems,
+                                                                  float* __restrict__ dw, int Cout, int Cin, int CinS, int taps) {
+  extern __shared__ float ru_lds[];                 // [taps][RU_CB + 1]
+  const int co = blockIdx.x, ci0 = blockIdx.y * RU_CB;
+  const int cb = min(RU_CB, CinS - ci0);
+  const float* base = slabs + ((size_t)co * taps) * CinS + ci0;
+  for (int i = threadIdx.x; i < taps * RU_CB; i += 256) {
+    const int t = i / RU_CB, cl = i - t * RU_CB;
+    if (cl >= cb) continue;
+    const float* p = base + (size_t)t * CinS + cl;
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = 0.f;
     int s = 0;
-    for (; s + 3 < nsplit; s += 4) {
-      v0 += *reinterpret_cast<const f32x4*>(p + (size_t)s * slab_elems);
-      v1 += *reinterpret_cast<const f32x4*>(p + (size_t)(s + 1) * slab_elems);
-      v2 += *reinterpret_cast<const f32x4*>(p + (size_t)(s + 2) * slab_elems);
-      v3 += *reinterpret_cast<const f32x4*>(p + (size_t)(s + 3) * slab_elems);
+    for (; s + 7 < nsplit; s += 8) {                // eight slab reads in flight
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] += p[(size_t)(s + u) * slab_elems];
     }
-    for (; s < nsplit; ++s) v0 += *reinterpret_cast<const f32x4*>(p + (size_t)s * slab_elems);
-    const f32x4 v = (v0 + v1) + (v2 + v3);
-    float* o = dw + (co * Cin + ci) * taps + t;
-    o[0] = v.x;
-    if (ci + 1 < Cin) o[taps] = v.y;
-    if (ci + 2 < Cin) o[2 * (size_t)taps] = v.z;
-    if (ci + 3 < Cin) o[3 * (size_t)taps] = v.w;
+    for (; s < nsplit; ++s) v[s & 7] += p[(size_t)s * slab_elems];
+    ru_lds[t * (RU_CB + 1) + cl] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  }
+  __syncthreads();
+  const int live = min(cb, Cin - ci0);              // padded channels (ci >= Cin) are not part of the OIHW tensor
+  float* o = dw + ((size_t)co * Cin + ci0) * taps;
+  for (int j = threadIdx.x; j < live * taps; j += 256) {
+    const int cl = j / taps, t = j - cl * taps;
+    o[j] = ru_lds[t * (RU_CB + 1) + cl];
   }
 }
 
@@ -259,11 +263,44 @@ hipError_t wgrad_v2(const GatherDesc& g, const void* src, const void* dy, int co
   return hipGetLastError();
 }
 
-hipError_t wgrad_reduce_unpack(const float* slabs, int nsplit, long long slab_elems, float* dw, int Cout, int Cin, int CinS,
+// first level of a two-level slab sum, used when the (co, channel-block) grid alone cannot fill the chip (thin layers
+// with many slabs): slab z*k += slabs z*k+1 .. z*k+k-1, elementwise and in place, in index order
+__global__ void slab_group_sum_kernel(float* __restrict__ slabs, int nsplit, long long slab_elems, int k, int groups) {
+  const size_t n4 = (size_t)slab_elems / 4;
+  const size_t total = n4 * groups;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int z = (int)(i / n4);
+    const size_t e = (i - (size_t)z * n4) * 4;
+    const int s0 = z * k, s1 = min(nsplit, s0 + k);
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0, v3 = v0;
+    int sidx = s0;
+    for (; sidx + 3 < s1; sidx += 4) {
+      v0 += *reinterpret_cast<const f32x4*>(slabs + (size_t)sidx * slab_elems + e);
+      v1 += *reinterpret_cast<const f32x4*>(slabs + (size_t)(sidx + 1) * slab_elems + e);
+      v2 += *reinterpret_cast<const f32x4*>(slabs + (size_t)(sidx + 2) * slab_elems + e);
+      v3 += *reinterpret_cast<const f32x4*>(slabs + (size_t)(sidx + 3) * slab_elems + e);
+    }
+    for (; sidx < s1; ++sidx) v0 += *reinterpret_cast<const f32x4*>(slabs + (size_t)sidx * slab_elems + e);
+    *reinterpret_cast<f32x4*>(slabs + (size_t)s0 * slab_elems + e) = (v0 + v1) + (v2 + v3);
+  }
+}
+
+hipError_t wgrad_reduce_unpack(float* slabs, int nsplit, long long slab_elems, float* dw, int Cout, int Cin, int CinS,
                                int taps, hipStream_t st) {
-  const size_t total = (size_t)Cout * CinS * taps / 4;
-  hipLaunchKernelGGL(wgrad_reduce_unpack_kernel, dim3(grid_for(total, 256, 256u * 8u)), dim3(256), 0, st, slabs, nsplit,
-                     slab_elems, dw, Cout, Cin, CinS, taps);
+  if (taps > RU_MAX_TAPS || Cout <= 0 || CinS <= 0) return hipErrorInvalidValue;
+  const int cblocks = (CinS + RU_CB - 1) / RU_CB;
+  long long stride = slab_elems;
+  if (Cout * cblocks < 512 && nsplit > 8 && slab_elems % 4 == 0) {
+    const int k = (nsplit + 7) / 8, groups = (nsplit + k - 1) / k;
+    const size_t total = (size_t)slab_elems / 4 * groups;
+    hipLaunchKernelGGL(slab_group_sum_kernel, dim3(grid_for(total, 256, 256u * 8u)), dim3(256), 0, st, slabs, nsplit, slab_elems,
+                       k, groups);
+    nsplit = groups;
+    stride = slab_elems * k;
+  }
+  const size_t lds = (size_t)taps * (RU_CB + 1) * sizeof(float);
+  hipLaunchKernelGGL(wgrad_reduce_unpack_kernel, dim3(Cout, cblocks), dim3(256), lds, st, (const float*)slabs, nsplit, stride, dw,
+                     Cout, Cin, CinS, taps);
   return hipGetLastError();
 }
 

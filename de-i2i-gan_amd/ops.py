@@ -214,7 +214,9 @@ class _Conv2d(torch.autograd.Function):
                     "conv2d_wgrad")
         if ctx.has_bias and ctx.needs_input_grad[2]:
             dbf = torch.empty(couts, dtype=torch.float32, device=x.device)
-            L.check(lib.dei2i_colsum(prec.code, g.numel() // couts, couts, _p(g), _p(dbf), st), "colsum")
+            rows = g.numel() // couts
+            part = torch.empty(lib.dei2i_colsum_blocks(rows) * couts, dtype=torch.float32, device=x.device)
+            L.check(lib.dei2i_colsum(prec.code, rows, couts, _p(g), _p(part), _p(dbf), st), "colsum")
             db = dbf[:geom.cout].clone()
         return dx, dw, db, None, None, None, None
 

@@ -125,8 +125,10 @@ int dei2i_spade_act_fwd(int dtype, int N, int H, int W, int C, int up, const voi
 /* ---- backward of the above ---- */
 /* g = dz * act'(z) (LeakyReLU / ReLU expressed through the saved output z) */
 int dei2i_act_bwd(int dtype, size_t n, const void* dz, const void* z, int act, void* g, dei2i_stream s);
-/* column sums: out[c] = sum over rows of g[row][c]   (conv bias gradient) */
-int dei2i_colsum(int dtype, size_t rows, int C, const void* g, float* out, dei2i_stream s);
+/* column sums: out[c] = sum over rows of g[row][c]   (conv bias gradient).  Two deterministic stages (no atomics):
+ * partial is fp32 scratch of dei2i_colsum_blocks(rows) * C floats. */
+int dei2i_colsum_blocks(size_t rows);
+int dei2i_colsum(int dtype, size_t rows, int C, const void* g, float* partial, float* out, dei2i_stream s);
 /* BatchNorm backward (train): z = act(a*y+b); g = dz*act'(z); needs sum(g), sum(g*xhat) per channel.
  * bn_bwd_partial writes (chunks, 2, C) partial sums over `pixels` rows; bn_bwd_apply finishes:
  *   dy = a * (g - sum_g/M - xhat * sum_gx/M),  dweight = sum_gx, dbias = sum_g.   train = 0 -> dy = a*g. */

@@ -55,6 +55,7 @@ for (H, W, C) in ((256, 256, 64), (128, 128, 128), (64, 64, 256)):
     bchunks = lib.dei2i_bn_bwd_chunks(pix)
     bpart = torch.empty(bchunks, 2, C, device=DEV)
     dwt, dbs = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    csp = torch.empty(lib.dei2i_colsum_blocks(pix) * C, device=DEV)
     timeit(tag + " bn_bwd_partial", lambda: lib.dei2i_bn_bwd_partial(BF, pix, C, p(dz), p(y), p(a), p(b), p(mean), p(rstd), L.ACT_LRELU, p(bpart), st), 2 * T)
     timeit(tag + " bn_bwd_apply", lambda: lib.dei2i_bn_bwd_apply(BF, pix, C, p(dz), p(y), p(a), p(b), p(mean), p(rstd), L.ACT_LRELU, 1, p(bpart), bchunks, p(dwt), p(dbs), p(out), st), 3 * T)
     ext = torch.randn(N, H + 2, W + 2, C, device=DEV).bfloat16()
@@ -69,6 +70,6 @@ for (H, W, C) in ((256, 256, 64), (128, 128, 128), (64, 64, 256)):
     z = torch.relu(torch.randn(N, H, W, C, device=DEV)).bfloat16()
     timeit(tag + " spade_bwd_partial", lambda: lib.dei2i_spade_bwd_partial(BF, N, H, W, C, 0, p(dz), p(x), p(mean_n), p(rstd_n), p(gb), 1, p(dgb), p(partial), st), 2 * T)
     timeit(tag + " spade_bwd_apply", lambda: lib.dei2i_spade_bwd_apply(BF, N, H, W, C, 0, p(dz), p(x), p(mean_n), p(rstd_n), p(gb), 1, p(partial), chunks, p(dgb), p(coef), None, p(out), st), 3 * T)
-    timeit(tag + " colsum", lambda: lib.dei2i_colsum(BF, pix, C, p(dz), p(dwt), st), T)
+    timeit(tag + " colsum", lambda: lib.dei2i_colsum(BF, pix, C, p(dz), p(csp), p(dwt), st), T)
     timeit(tag + " torch add (reference point)", lambda: torch.add(x, y, out=out), 3 * T)
     del x, y, dz, out, out2, ext, z

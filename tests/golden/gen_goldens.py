@@ -51,13 +51,20 @@ CONFIGS = {
     # in run_config(); measured oracle-vs-reference (both fp32, same maths): 2e-4 on t0, 4e-2 on t1.
     "t0_img32_b2": dict(image_size=32, batch=2, num_layers=3, ngf=8, ndf=8, hidden_nc=16, tol_step2=1e-3),
     "t1_img64_b4": dict(image_size=64, batch=4, num_layers=4, ngf=16, ndf=16, hidden_nc=32, tol_step2=8e-2),
+    # the deeper encoder/decoder of the 512x512 configuration (num_scales=3: three stride-2 stages, three SPADE
+    # up-blocks), shrunk to 64x64 so the reference finishes in seconds.  tol_gradnorm: the 8x8 bottleneck (128 pixels
+    # per channel) makes every fp32 ReLU/L1 branch flip weigh more: the reference's fp32 G grad norms sit up to 16 %
+    # from the oracle's fp32 ones, while an fp64 run of both agrees to 1e-9 on every key (checked when this config
+    # was added: reference modules .double(), same losses to 1e-15).
+    "t2_img64_s3_b2": dict(image_size=64, batch=2, num_layers=4, ngf=8, ndf=8, hidden_nc=16, num_scales=3,
+                           tol_step2=8e-2, tol_gradnorm=0.3, tol_post=5e-2, tol_running=0.2),
 }
 
 
 def make_opt(c):
     return SimpleNamespace(
         model="defectgan", num_res=6, cycle_gan=False, label_nc=6, skip_conn=False, ngf=c["ngf"], ndf=c["ndf"],
-        input_nc=3, use_spectral=False, num_scales=2, style_norm_block_type="spade", hidden_nc=c["hidden_nc"],
+        input_nc=3, use_spectral=False, num_scales=c.get("num_scales", 2), style_norm_block_type="spade", hidden_nc=c["hidden_nc"],
         style_distill=False, embed_nc=768, add_noise=False, num_layers=c["num_layers"],
         image_size=c["image_size"], batch_size=c["batch"], device=torch.device("cpu"), is_train=True,
         clf_loss_type="bce", continue_training=False, load_model_name=None, init_type="normal",
@@ -112,13 +119,15 @@ def rel_dev(a, b, what, tol, floor=1e-4):
     assert ((a < 0) == (b < 0)).all(), f"{what}: grad-is-None pattern differs"
     m = b > floor
     dev = float(np.max(np.abs(a[m] - b[m]) / b[m]))
+    if dev > tol:
+        print(what, "per-key rel dev:", np.round(np.abs(a[m] - b[m]) / b[m], 3).tolist(), "ref norms:", b[m].tolist())
     assert dev <= tol, f"oracle != reference for {what}: max rel dev {dev:.3e} > {tol}"
     return dev
 
 
 def run_config(name, c):
     cfg = O.Cfg(image_size=c["image_size"], ngf=c["ngf"], ndf=c["ndf"], num_layers=c["num_layers"],
-                hidden_nc=c["hidden_nc"])
+                hidden_nc=c["hidden_nc"], num_scales=c.get("num_scales", 2))
     opt = make_opt(c)
     tr = DefectGanTrainer(opt)
     G, D = tr.model.netG, tr.model.netD
@@ -198,7 +207,7 @@ def run_config(name, c):
             # per-key grad-norm pin is loose by necessity (documented in DESIGN.md); tight backward checks live in
             # the op-level tests.
             on = np.array([float(gG[k].double().norm()) if gG[k] is not None else -1.0 for k in meta["G_grad_keys"]])
-            errs["G_grad_norm_rel"] = rel_dev(on, arrays["G_grad_norms_step1"], "G grad norms", 8e-2)
+            errs["G_grad_norm_rel"] = rel_dev(on, arrays["G_grad_norms_step1"], "G grad norms", c.get("tol_gradnorm", 8e-2))
             on = np.array([float(gD[k].double().norm()) if gD[k] is not None else -1.0 for k in meta["D_grad_keys"]])
             errs["D_grad_norm_rel"] = rel_dev(on, arrays["D_grad_norms_step1"], "D grad norms", 2e-3)
     # step 1 is a pure forward/backward comparison; step 2 sits behind one Adam update whose first step is
@@ -211,13 +220,13 @@ def run_config(name, c):
         keys, s, n = checks(net.state_dict())
         okeys, os_, on_ = checks({k: v.detach() for k, v in S.items()})
         assert keys == okeys
-        errs[f"{tag}_post_norm"] = assert_close(on_, n, f"{tag} post-step norms", rtol=1e-2)
+        errs[f"{tag}_post_norm"] = assert_close(on_, n, f"{tag} post-step norms", rtol=c.get("tol_post", 1e-2))
         meta[f"{tag}_check_keys"] = keys
         arrays[f"{tag}_post_sum"], arrays[f"{tag}_post_norm"] = s, n
     for k, v in G.state_dict().items():
         if "running_" in k:
             arrays["bn::" + k] = v.numpy().copy()
-            assert_close(SG[k], v, "running stat " + k, rtol=5e-2)
+            assert_close(SG[k], v, "running stat " + k, rtol=c.get("tol_running", 5e-2))
     # a few complete post-step tensors (small ones) for element-wise checks
     for k in ("stem.conv_block.0.weight", "dec_blk.1.conv.weight", "foreground_head.de_conv_block.0.weight"):
         arrays["Gp::" + k] = G.state_dict()[k].numpy().copy()
@@ -277,4 +286,5 @@ def run_config(name, c):
 
 if __name__ == "__main__":
     for n, c in CONFIGS.items():
-        run_config(n, c)
+        if len(sys.argv) == 1 or n in sys.argv[1:]:
+            run_config(n, c)

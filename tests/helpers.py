@@ -16,7 +16,8 @@ def load_golden(name):
     meta = json.loads((GOLD / f"{name}.json").read_text())
     arr = np.load(GOLD / f"{name}.npz")
     c = meta["config"]
-    cfg = O.Cfg(image_size=c["image_size"], ngf=c["ngf"], ndf=c["ndf"], num_layers=c["num_layers"], hidden_nc=c["hidden_nc"])
+    cfg = O.Cfg(image_size=c["image_size"], ngf=c["ngf"], ndf=c["ndf"], num_layers=c["num_layers"], hidden_nc=c["hidden_nc"],
+                num_scales=c.get("num_scales", 2))
     return meta, arr, c, cfg
 
 

@@ -12,6 +12,8 @@ Tolerances
   in addition the t0 golden's G step sits behind a D update that leaves a LeakyReLU pre-activation of the 2x2 final D
   feature map within fp32 rounding of 0 for `fake_defects`, so the golden G grad norms are only matched to 15%
   (diagnosed with tests/diag_gstep.py: with identical D inputs the HIP gradient equals the fp64 oracle to 3e-6)."""
+import functools
+
 import numpy as np
 import pytest
 import torch
@@ -35,11 +37,11 @@ def rmsrel(a, b):
     return ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-12)).item()
 
 
-def check_fwd(got, ref, pname):
+def check_fwd(got, ref, pname, bf16_rms=0.12):
     if pname == "f32":
         assert maxrel(got, ref) < 1e-3
     else:
-        assert rmsrel(got, ref) < 0.12 and maxrel(got, ref) < 0.5
+        assert rmsrel(got, ref) < bf16_rms and maxrel(got, ref) < 4.2 * bf16_rms
 
 
 def build(c, pname, **over):
@@ -51,13 +53,20 @@ def build(c, pname, **over):
 
 
 @pytest.mark.parametrize("pname", ["f32", "bf16"])
-@pytest.mark.parametrize("name", ["t0_img32_b2", "t1_img64_b4"])
+@pytest.mark.parametrize("name", ["t0_img32_b2", "t1_img64_b4", "t2_img64_s3_b2"])
 def test_forward_matches_reference_goldens(name, pname):
     meta, arr, c, cfg = load_golden(name)
     tr = build(c, pname)
     G, D = tr.model.netG, tr.model.netD
     bg, labels, df = O.synthetic_batch(c["batch"], c["image_size"])
     bg_d, lab_d = bg.to(DEV), labels.to(DEV)
+    # bf16 on the formula-filled nets: the three-scale t2 net normalises over an 8x8 bottleneck (64 pixels per
+    # instance-norm channel), which amplifies the 2^-9 activation rounding further than t0/t1 (measured 0.18 RMS)
+    check = functools.partial(check_fwd, bf16_rms=0.3 if c.get("num_scales", 2) == 3 else 0.12)
+    _forward_checks(G, D, tr, arr, c, bg, bg_d, lab_d, pname, check)
+
+
+def _forward_checks(G, D, tr, arr, c, bg, bg_d, lab_d, pname, check_fwd):
     with torch.no_grad():
         G.eval()
         out, prob = G(bg_d, lab_d.reshape(c["batch"], 6, 1, 1))
@@ -80,16 +89,22 @@ def test_forward_matches_reference_goldens(name, pname):
         G.load_state_dict(saved)
 
 
-@pytest.mark.parametrize("name,c", [
-    ("tiny16", dict(image_size=16, batch=1, num_layers=1, ngf=8, ndf=8, hidden_nc=8)),
-    ("t0", dict(image_size=32, batch=2, num_layers=3, ngf=8, ndf=8, hidden_nc=16)),
+@pytest.mark.parametrize("name,c,gtol", [
+    ("tiny16", dict(image_size=16, batch=1, num_layers=1, ngf=8, ndf=8, hidden_nc=8), 1e-3),
+    ("t0", dict(image_size=32, batch=2, num_layers=3, ngf=8, ndf=8, hidden_nc=16), 1e-3),
+    # three scales: the backward chain is two blocks longer and crosses batch / instance norms over 8x8 maps, whose
+    # backward amplifies fp32 rounding.  Branches are replayed, so what is left is linear rounding: the fp32 CPU
+    # restatement itself, replayed the same way, sits up to 1.1e-2 from its fp64 run on this config (3e-4 on t0);
+    # the HIP f32 path measures 3.4e-3
+    ("t2_scales3", dict(image_size=64, batch=2, num_layers=4, ngf=8, ndf=8, hidden_nc=16, num_scales=3), 1.5e-2),
 ])
-def test_step_gradients_match_oracle_fp64(name, c):
+def test_step_gradients_match_oracle_fp64(name, c, gtol):
     """Every live parameter gradient of the D loss graph and of the G loss graph (4 chained G passes + 2 D passes),
     f32 HIP path vs the oracle evaluated in fp64 on the same weights and the same piecewise-linear branches: the
     branch the HIP path took at every ReLU / LeakyReLU / |a-b| is recorded and replayed by the oracle (KinkTape), and
     the elements where that differs from the oracle's own branch must all sit within fp32 noise of the kink."""
-    cfg = O.Cfg(image_size=c["image_size"], ngf=c["ngf"], ndf=c["ndf"], num_layers=c["num_layers"], hidden_nc=c["hidden_nc"])
+    cfg = O.Cfg(image_size=c["image_size"], ngf=c["ngf"], ndf=c["ndf"], num_layers=c["num_layers"], hidden_nc=c["hidden_nc"],
+                num_scales=c.get("num_scales", 2))
     bg, labels, df = O.synthetic_batch(c["batch"], c["image_size"])
     SG = {k: (v.double() if v.is_floating_point() else v) for k, v in O.make_state(O.generator_state_shapes(cfg)).items()}
     SD = {k: v.double() for k, v in O.make_state(O.discriminator_state_shapes(cfg)).items()}
@@ -131,23 +146,25 @@ def test_step_gradients_match_oracle_fp64(name, c):
         if float(ref.norm()) < 1e-7 * scale:              # gradients that are zero by construction (bias before IN)
             assert float(p.grad.double().norm()) < 1e-4 * scale, k
             continue
-        assert ((p.grad.double().cpu() - ref).norm() / ref.norm()).item() < 1e-3, k
+        assert ((p.grad.double().cpu() - ref).norm() / ref.norm()).item() < gtol, k
 
 
 @pytest.mark.parametrize("pname", ["f32", "bf16"])
-@pytest.mark.parametrize("name", ["t0_img32_b2", "t1_img64_b4"])
+@pytest.mark.parametrize("name", ["t0_img32_b2", "t1_img64_b4", "t2_img64_s3_b2"])
 def test_two_train_steps_match_reference_goldens(name, pname):
     meta, arr, c, cfg = load_golden(name)
     tr = build(c, pname)
     G, D = tr.model.netG, tr.model.netD
     bg, labels, df = O.synthetic_batch(c["batch"], c["image_size"])
-    ltol = {"f32": 1e-4, "bf16": 2e-2}[pname]
+    ltol = {"f32": 1e-4, "bf16": 6e-2 if c.get("num_scales", 2) == 3 else 2e-2}[pname]     # t2 bf16: measured 4e-2
     for it in range(2):
         tr._train_discriminator_once(bg, labels, df)            # CPU tensors in, like the reference's loaders
         if it == 0:
             dn = np.array([float(p.grad.double().norm()) for _, p in D.named_parameters()])
             assert [k for k, _ in D.named_parameters()] == meta["D_grad_keys"]
-            assert np.max(np.abs(dn - arr["D_grad_norms_step1"]) / arr["D_grad_norms_step1"]) < (2e-3 if pname == "f32" else 0.15)
+            # bf16: D sees G's fake images, i.e. the bf16 forward noise of the formula-filled G (0.12 RMS, 0.3 on t2)
+            dtol = 2e-3 if pname == "f32" else (0.3 if c.get("num_scales", 2) == 3 else 0.15)
+            assert np.max(np.abs(dn - arr["D_grad_norms_step1"]) / arr["D_grad_norms_step1"]) < dtol
         tr._train_generator_once(bg, labels, df)
         if it == 0:
             ref = arr["G_grad_norms_step1"]
@@ -156,7 +173,7 @@ def test_two_train_steps_match_reference_goldens(name, pname):
             assert ((gn < 0) == (ref < 0)).all(), "grad-is-None pattern (never-executed norm_s / conv_s)"
             if pname == "f32":
                 m = ref > 1e-4
-                assert np.max(np.abs(gn[m] - ref[m]) / ref[m]) < 0.15          # see module docstring
+                assert np.max(np.abs(gn[m] - ref[m]) / ref[m]) < max(0.15, c.get("tol_gradnorm", 0))   # see module docstring
             else:
                 assert np.isfinite(gn).all()
         L = tr.losses
@@ -177,8 +194,8 @@ def test_two_train_steps_match_reference_goldens(name, pname):
     for k in meta["G_keys"]:
         if "running_" in k:
             if pname == "f32":
-                assert maxrel(sdg[k], arr["bn::" + k]) < 5e-2, k
-            elif k.startswith(("stem.", "enc_blk.")):
+                assert maxrel(sdg[k], arr["bn::" + k]) < c.get("tol_running", 5e-2), k
+            elif k.startswith(("stem.", "enc_blk.0.", "enc_blk.1.")):
                 # bf16: the formula-filled nets are chaotic -- a one-ulp difference grows ~4x per res-block layer
                 # (tests/diag_first_use.py t1 bf16: 1e-4 -> 3e-2 over five layers, run to run) -- so the 2^-9 activation
                 # rounding swamps the deep res-block statistics; only the first three BatchNorms are comparable
