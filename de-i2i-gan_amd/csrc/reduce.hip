@@ -15,29 +15,31 @@ namespace dei2i {
 
 static inline int vec_of(int dtype) { return dtype == DT_BF16 ? 8 : 4; }
 
-// Combine per-thread partials: vals[NV][VEC] of the threads sharing a channel vector; result valid where prow == 0.
+// Combine per-thread partials vals[NV][VEC] of the threads sharing a channel vector and store the sums:
+//   dst[q * C + vcol * VEC + e] = sum over prow (in order) of vals[q][e]      (dst: this workgroup's record)
+// The sum runs as a ROLLED loop over (quantity, element, channel-vector) outputs on all 256 threads -- a few hundred
+// bytes of code instead of NV*VEC unrolled serial LDS sums on cv threads (a dispatch walks its code cold: code size
+// is launch latency for these short kernels).
 template <int NV, int VEC>
-DEI2I_D void block_combine(float (&vals)[NV][VEC], int cv, int rpp, float* smem) {
+DEI2I_D void block_combine_store(const float (&vals)[NV][VEC], int cv, int rpp, float* smem, float* __restrict__ dst, int C) {
   const int tid = threadIdx.x;
   const int vcol = tid % cv, prow = tid / cv;
-  const bool active = prow < rpp;
   __syncthreads();
-  if (active) {
+  if (prow < rpp) {
 #pragma unroll
     for (int q = 0; q < NV; ++q)
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) smem[((size_t)(q * VEC + e) * rpp + prow) * cv + vcol] = vals[q][e];
+      for (int e = 0; e < VEC; ++e) smem[((q * VEC + e) * rpp + prow) * cv + vcol] = vals[q][e];
   }
   __syncthreads();
-  if (active && prow == 0) {
-#pragma unroll
-    for (int q = 0; q < NV; ++q)
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        float s = 0.f;
-        for (int r = 0; r < rpp; ++r) s += smem[((size_t)(q * VEC + e) * rpp + r) * cv + vcol];
-        vals[q][e] = s;
-      }
+#pragma unroll 1
+  for (int o = tid; o < NV * VEC * cv; o += 256) {
+    const int qe = o / cv, vc = o - qe * cv;
+    const float* src = smem + (size_t)qe * rpp * cv + vc;
+    float sum = 0.f;
+    for (int r = 0; r < rpp; ++r) sum += src[r * cv];
+    const int q = qe / VEC, e = qe - q * VEC;
+    dst[(size_t)q * C + vc * VEC + e] = sum;
   }
 }
 
@@ -73,12 +75,7 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const T* __restric
     }
     for (; r < rend; r += rpp) acc(*reinterpret_cast<const u32x4*>(base + (size_t)r * C));
   }
-  block_combine<2, VEC>(v, cv, rpp, smem);
-  if (prow == 0 && prow < rpp) {
-    float* dst = partial + ((size_t)n * chunks + chunk) * 2 * C + (size_t)vcol * VEC;
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) { dst[e] = v[0][e]; dst[C + e] = v[1][e]; }
-  }
+  block_combine_store<2, VEC>(v, cv, rpp, smem, partial + ((size_t)n * chunks + chunk) * 2 * C, C);
 }
 
 // Cross-workgroup combine of the partial records, in fp64 (deterministic, no atomics).  One workgroup per channel
@@ -210,12 +207,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
     }
     if (r < rend) acc(*reinterpret_cast<const u32x4*>(dzb + r * C), *reinterpret_cast<const u32x4*>(yb + r * C));
   }
-  block_combine<2, VEC>(v, cv, rpp, smem);
-  if (prow == 0 && prow < rpp) {
-    float* dst = partial + (size_t)chunk * 2 * C + (size_t)vcol * VEC;
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) { dst[e] = v[0][e]; dst[C + e] = v[1][e]; }
-  }
+  block_combine_store<2, VEC>(v, cv, rpp, smem, partial + (size_t)chunk * 2 * C, C);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int C,
@@ -366,14 +358,7 @@ __global__ __launch_bounds__(256) void spade_bwd_partial_kernel(const T* __restr
     }
     if (r < rend) use(load(r));
   }
-  block_combine<4, VEC>(v, cv, rpp, smem);
-  if (prow == 0 && prow < rpp) {
-    float* dst = partial + ((size_t)n * chunks + chunk) * 4 * C + (size_t)vcol * VEC;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) dst[(size_t)q * C + e] = v[q][e];
-  }
+  block_combine_store<4, VEC>(v, cv, rpp, smem, partial + ((size_t)n * chunks + chunk) * 4 * C, C);
 }
 
 // class-mode gamma/beta gradients of the 24 border classes: one workgroup per (class, image) walks that class's
@@ -421,12 +406,7 @@ __global__ __launch_bounds__(256) void spade_bwd_border_kernel(const T* __restri
       }
     }
   }
-  block_combine<2, VEC>(v, cv, rpp, smem);
-  if (prow == 0 && prow < rpp) {
-    float* dst = dgb_cls + (((size_t)n * 5 + cy) * 5 + cx) * 2 * C + (size_t)vcol * VEC;
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) { dst[e] = v[0][e]; dst[C + e] = v[1][e]; }
-  }
+  block_combine_store<2, VEC>(v, cv, rpp, smem, dgb_cls + (((size_t)n * 5 + cy) * 5 + cx) * 2 * C, C);
 }
 
 // coef[(n*2 + {0,1})*C + c] = s1/M, s2/M ; interior-class gamma/beta sums added into dgb_cls[n,2,2,:]
@@ -529,12 +509,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, fl
     }
     for (; r < rend; r += rpp) acc(*reinterpret_cast<const u32x4*>(base + r * C));
   }
-  block_combine<1, VEC>(v, cv, rpp, smem);
-  if (prow == 0 && prow < rpp) {
-    float* dst = partial + (size_t)blockIdx.x * C + (size_t)vcol * VEC;
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) dst[e] = v[0][e];
-  }
+  block_combine_store<1, VEC>(v, cv, rpp, smem, partial + (size_t)blockIdx.x * C, C);
 }
 
 // out[c] = sum over blocks of partial[block][c] in a fixed order (deterministic; replaces a memset + fp32 atomics).
