@@ -313,16 +313,15 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, cons
   }
   __builtin_amdgcn_s_barrier();                          // halo 0 and weights(0) complete for every wave
   if (grp == 1) __builtin_amdgcn_s_barrier();            // group 1 starts one phase late
-  int j = 0;
-  for (; j + 1 < nk; j += 2) {
+  // two k-steps per trip (two fragment register sets); an odd last k-step leaves through the break, so the phase code
+  // exists twice, not three times (a dispatch walks its code cold: code size is start-up latency)
+#pragma unroll 1
+  for (int j = 0; j < nk; j += 2) {
     phase_m(f0, j);
     phase_c(f0, j);
+    if (j + 1 >= nk) break;
     phase_m(f1, j + 1);
     phase_c(f1, j + 1);
-  }
-  if (j < nk) {
-    phase_m(f0, j);
-    phase_c(f0, j);
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();            // pairs with group 1's last phase
   if (ablate == 5 && dbg != nullptr && lane == 0) {      // diagnostic: loop cycles and the clock held
@@ -343,24 +342,42 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, cons
   __syncthreads();
   constexpr int CROW = BN * 2 + 16;       // staging row stride in bytes
   unsigned char* ctile = smem;
+  // Branch-free and small: act(v) = max(v,0) + slope*min(v,0) (slope 0 / 0.2 / 1 for ReLU / LeakyReLU / none -- exact for
+  // all three), padded output channels (n >= wrows) cleared with a bit mask on the packed pair.  The unrolled
+  // per-element `act` switch this replaces was 60 % of the kernel's code, and a dispatch walks its code cold.
+  const float slope = act == ACT_RELU ? 0.f : (act == ACT_LRELU ? 0.2f : 1.f);
+  auto finish4 = [&](const float (&a4)[4], const float (&bq)[4], uint32_t m01, uint32_t m23) -> u32x2 {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float t = a4[k] + bq[k];
+      v[k] = fmaf(slope, fminf(t, 0.f), fmaxf(t, 0.f));
+    }
+    u32x2 pk;
+    pk.x = ((uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16)) & m01;
+    pk.y = ((uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16)) & m23;
+    return pk;
+  };
+  auto col_consts = [&](int col0, float (&bq)[4], uint32_t& m01, uint32_t& m23) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bq[k] = (bias != nullptr && n0 + col0 + k < wrows) ? bias[n0 + col0 + k] : 0.f;
+    const int live = wrows - (n0 + col0);             // channels of this group of four that exist
+    m01 = live >= 2 ? 0xffffffffu : (live == 1 ? 0x0000ffffu : 0u);
+    m23 = live >= 4 ? 0xffffffffu : (live == 3 ? 0x0000ffffu : 0u);
+  };
   if constexpr (M16) {
     // D row = channel 4*kg + e of its 16-block, col = pixel l16
 #pragma unroll
     for (int j = 0; j < CB; ++j) {
       const int col0 = wn * WTN + j * 16 + 4 * kg;
       float bq[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) bq[k] = (bias != nullptr && n0 + col0 + k < wrows) ? bias[n0 + col0 + k] : 0.f;
+      uint32_t m01, m23;
+      col_consts(col0, bq, m01, m23);
 #pragma unroll
       for (int i = 0; i < PB; ++i) {
         const int row = (wm * TM + (i >> 1)) * 32 + (i & 1) * 16 + l16;
-        float v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = n0 + col0 + k < wrows ? apply_act(acc[i][j][k] + bq[k], act) : 0.f;
-        u32x2 pk;
-        pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-        pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-        *reinterpret_cast<u32x2*>(ctile + row * CROW + col0 * 2) = pk;
+        const float a4[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        *reinterpret_cast<u32x2*>(ctile + row * CROW + col0 * 2) = finish4(a4, bq, m01, m23);
       }
     }
   } else {
@@ -370,18 +387,13 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, cons
       for (int q = 0; q < 4; ++q) {
         const int col0 = wn * WTN + j * 32 + 8 * q + 4 * lh;             // first of this lane's four channels
         float bq[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) bq[k] = (bias != nullptr && n0 + col0 + k < wrows) ? bias[n0 + col0 + k] : 0.f;
+        uint32_t m01, m23;
+        col_consts(col0, bq, m01, m23);
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
           const int row = (wm * TM + i) * 32 + lr;
-          float v[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = n0 + col0 + k < wrows ? apply_act(acc[i][j][q * 4 + k] + bq[k], act) : 0.f;
-          u32x2 pk;
-          pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-          pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-          *reinterpret_cast<u32x2*>(ctile + row * CROW + col0 * 2) = pk;
+          const float a4[4] = {acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+          *reinterpret_cast<u32x2*>(ctile + row * CROW + col0 * 2) = finish4(a4, bq, m01, m23);
         }
       }
   }
