@@ -35,6 +35,7 @@ SIGNATURES = {
     "dei2i_set_option": (c_int, [c_char_p, c_int]),
     "dei2i_set_debug_buffer": (c_int, [c_void_p]),
     "dei2i_packed_fwd_elems": (c_size_t, [_CD]),
+    "dei2i_wgrad_slab_elems": (c_size_t, [_CD]),
     "dei2i_packed_dgrad_elems": (c_size_t, [_CD]),
     "dei2i_pack_weight_fwd": (c_int, [_CD, _P, _P, _P]),
     "dei2i_pack_weight_dgrad": (c_int, [_CD, _P, _P, _P]),

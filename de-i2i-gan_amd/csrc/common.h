@@ -99,6 +99,33 @@ DEI2I_D float apply_act(float v, int act) {
   if (act == ACT_LRELU) return v >= 0.f ? v : 0.2f * v;
   return v;
 }
+// Branch-free epilogue helpers of the MFMA kernels (the unrolled per-element `act` switch was most of their code, and
+// a dispatch walks its code cold).  act(v) = max(v,0) + slope*min(v,0) with slope 0 / 0.2 / 1 for ReLU / LeakyReLU /
+// none -- exact for all three.
+DEI2I_D float act_slope(int act) { return act == ACT_RELU ? 0.f : (act == ACT_LRELU ? 0.2f : 1.f); }
+// bias of four consecutive output channels n .. n+3 (0 beyond wrows) and the bit masks that clear the packed bf16
+// pairs of channels beyond wrows
+DEI2I_D void epi_col_consts(const float* __restrict__ bias, int n, int wrows, float (&bq)[4], uint32_t& m01, uint32_t& m23) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) bq[k] = (bias != nullptr && n + k < wrows) ? bias[n + k] : 0.f;
+  const int live = wrows - n;
+  m01 = live >= 2 ? 0xffffffffu : (live == 1 ? 0x0000ffffu : 0u);
+  m23 = live >= 4 ? 0xffffffffu : (live == 3 ? 0x0000ffffu : 0u);
+}
+DEI2I_D u32x2 epi_finish4(float a0, float a1, float a2, float a3, const float (&bq)[4], float slope, uint32_t m01, uint32_t m23) {
+  const float a4[4] = {a0, a1, a2, a3};
+  float v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float t = a4[k] + bq[k];
+    v[k] = fmaf(slope, fminf(t, 0.f), fmaxf(t, 0.f));
+  }
+  u32x2 pk;
+  pk.x = ((uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16)) & m01;
+  pk.y = ((uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16)) & m23;
+  return pk;
+}
+
 // derivative of the activation expressed through its OUTPUT z (valid for relu / lrelu(0.2): sign(z) == sign(pre))
 DEI2I_D float act_grad_from_out(float z, int act) {
   if (act == ACT_RELU) return z > 0.f ? 1.f : 0.f;

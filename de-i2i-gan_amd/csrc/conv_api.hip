@@ -159,6 +159,7 @@ using namespace dei2i;
 extern "C" {
 
 size_t dei2i_packed_fwd_elems(const dei2i_conv* c) { return (size_t)c->Cout * c->kh * c->kw * c->CinS; }
+size_t dei2i_wgrad_slab_elems(const dei2i_conv* c) { return (size_t)wgrad_slab_elems(c->Cout, c->kh * c->kw * c->CinS); }
 
 size_t dei2i_packed_dgrad_elems(const dei2i_conv* c) {
   size_t n = 0;
@@ -327,15 +328,15 @@ int dei2i_conv2d_wgrad(const dei2i_conv* c, const void* x, const void* dy, float
 }
 
 /* wgrad straight to the OIHW fp32 gradient: the bf16 hot shapes take the LDS-DMA slab kernel + fused reduce/un-pack
- * (scratch >= Cout*kh*kw*CinS floats; more lets it split the pixel range further); other shapes take the v1 kernel
+ * (scratch >= dei2i_wgrad_slab_elems floats; more lets it split the pixel range further); other shapes take the v1 kernel
  * into scratch[0 : packed elems] and the un-pack kernel. */
 int dei2i_conv2d_wgrad_oihw(const dei2i_conv* c, const void* x, const void* dy, float* scratch, size_t scratch_elems,
                             float* dw_oihw, dei2i_stream s) {
   if (!valid_conv(c) || !x || !dy || !scratch || !dw_oihw) return DEI2I_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)s;
-  const size_t packed = dei2i_packed_fwd_elems(c);
-  if (scratch_elems < packed) return DEI2I_ERR_WORKSPACE;
   GatherDesc g = make_fwd_desc(to_shape(c), c->CinS);
+  const size_t packed = (size_t)wgrad_slab_elems(c->Cout, g.K);      // slab stride: Cout rounded up to 8 rows
+  if (scratch_elems < packed) return DEI2I_ERR_WORKSPACE;
   if (c->dtype == DT_BF16 && g_use_wgrad_halo) {       // stride-1 3x3: (co, ci, 9 taps) block resident in registers
     int nsplit = 0;
     hipError_t e = wgrad_halo(g, x, dy, c->Cout, c->CoutS, scratch, scratch_elems, num_cu(), &nsplit, g_use_wgrad_halo == 2, st);

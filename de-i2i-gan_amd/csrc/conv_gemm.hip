@@ -347,15 +347,14 @@ template <int ROWB> DEI2I_D int tr_swz(int row) {
 // ------------------------------------------------------------------------------------------------
 // wgrad:  dw[co][k] = sum_m dy[m][co] * gather(src)[m][k]
 // The pixel range is split over gridDim.z; split z stores its partial to slab z (dw + z*slab_elems, plain stores) and
-// wgrad_reduce_unpack sums the slabs in a fixed order -- deterministic, no atomics.  slab_elems == 0 with direct == 0
-// is the legacy accumulate-with-atomics mode kept for callers that hand in a bare packed buffer (dei2i_conv2d_wgrad).
+// wgrad_reduce_unpack sums the slabs in a fixed order -- deterministic, no atomics.  Callers that hand in a bare packed
+// buffer (dei2i_conv2d_wgrad) get a single split.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN>
 __global__ __launch_bounds__(256) void wgrad_kernel(const GatherDesc g, const T* __restrict__ src,
                                                     const T* __restrict__ dy, const int co_rows, const int ldy,
                                                     float* __restrict__ dw_base, const int tiles_k,
-                                                    const int chunks_per_split, const int direct,
-                                                    const long long slab_elems) {
+                                                    const int chunks_per_split, const long long slab_elems) {
   constexpr int VEC = Elem<T>::VEC;
   constexpr bool IS_BF16 = sizeof(T) == 2;
   float* __restrict__ dw = dw_base + (size_t)blockIdx.z * (size_t)slab_elems;
@@ -513,32 +512,35 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GatherDesc g, const T*
     }
   };
 
-  load_chunk(cbeg);
-  store_chunk(0);
-  __syncthreads();
-  int buf = 0;
-  for (int c = cbeg; c < cend; ++c) {
-    const bool more = c + 1 < cend;
-    if (more) load_chunk(c + 1);
-    compute_chunk(buf);
-    if (more) store_chunk(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
+  // rotated so that load / compute / store each appear once in the instruction stream (cold-start code walk)
+  {
+    int buf = 1;
+#pragma unroll 1
+    for (int c = cbeg; c <= cend; ++c) {
+      const bool more = c < cend;
+      if (more) load_chunk(c);
+      if (c > cbeg) compute_chunk(buf);
+      if (more) store_chunk(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
   }
 
-  // D[i = co][j = k column]; lanes run along k (contiguous in dw) -> 128-byte atomic segments
+  // D[i = co][j = k column]; lanes run along k (contiguous in dw) -> 128-byte store segments.  co_rows is a multiple of
+  // 4 (padded channel count): rows 8q .. 8q+3 (+4 lh) share one guard.
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int co = c0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+    for (int q = 0; q < 4; ++q) {
+      const int co = c0 + wm * WTM + i * 32 + 8 * q + 4 * lh;
       if (co >= co_rows) continue;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int k = k0 + wn * WTN + j * 32 + lr;
         if (k < g.K) {
-          if (direct) dw[(size_t)co * g.K + k] = acc[i][j][e];
-          else atomicAdd(dw + (size_t)co * g.K + k, acc[i][j][e]);
+          float* p = dw + (size_t)co * g.K + k;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) p[(size_t)r * g.K] = acc[i][j][q * 4 + r];
         }
       }
     }
@@ -706,11 +708,11 @@ static hipError_t launch_wg(const GatherDesc& g, const void* src, const void* dy
   const int nchunks = (g.M + BR - 1) / BR;
   const int tiles = tiles_c * tiles_k;
   const bool slabs = nsplit_out != nullptr;            // deterministic mode: one slab per split, reduced by the caller
-  int splits = ((slabs ? 2 : 4) * g_num_cu + tiles - 1) / tiles;     // every split costs a slab write + read
+  int splits = (2 * g_num_cu + tiles - 1) / tiles;     // every split costs a slab write + read
   if (splits > nchunks / 2) splits = nchunks / 2;
-  const long long slab_elems = (long long)co_rows * g.K;
+  const long long slab_elems = wgrad_slab_elems(co_rows, g.K);
   if (slabs && (size_t)slab_elems * (size_t)splits > capacity_elems) splits = (int)(capacity_elems / (size_t)slab_elems);
-  if (splits < 1) splits = 1;
+  if (splits < 1 || !slabs) splits = 1;                // a bare packed buffer: one split, plain stores
   const int cps = (nchunks + splits - 1) / splits;
   const int zs = (nchunks + cps - 1) / cps;
   const size_t lds = 2 * (size_t)BR * (BM + BN) * sizeof(T);
@@ -721,14 +723,10 @@ static hipError_t launch_wg(const GatherDesc& g, const void* src, const void* dy
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  if (zs > 1 && !slabs) {        // legacy: accumulate with fp32 atomics into a zeroed buffer
-    hipError_t e = hipMemsetAsync(dw, 0, (size_t)co_rows * g.K * sizeof(float), st);
-    if (e != hipSuccess) return e;
-  }
   if (slabs) *nsplit_out = zs;
   prof_begin(PROF_WGRAD, 2.0 * (double)g.M * (double)(g.th * g.tw) * (double)g.Clog * (double)co_rows, st);
   hipLaunchKernelGGL(kern, dim3(tiles, 1, zs), dim3(256), lds, st, g, (const T*)src, (const T*)dy, co_rows, ldy, dw,
-                     tiles_k, cps, (zs == 1 || slabs) ? 1 : 0, slabs ? slab_elems : 0ll);
+                     tiles_k, cps, slabs ? slab_elems : 0ll);
   prof_end(PROF_WGRAD, st);
   return hipGetLastError();
 }

@@ -218,22 +218,18 @@ __global__ __launch_bounds__(512) void gather_gemm_v2_kernel(const DescPack pack
   __syncthreads();                       // every wave is done reading the ring
   constexpr int CROW = BN * 2 + 16;
   unsigned char* ctile = smem;
+  const float slope = act_slope(act);      // branch-free activation + padded-channel bit masks: see common.h
 #pragma unroll
   for (int j = 0; j < CB; ++j) {
     const int col0 = wn * WTN + j * 16 + 4 * kg;                       // first of this lane's four channels
     float bq[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) bq[k] = (bias != nullptr && n0 + col0 + k < wrows) ? bias[n0 + col0 + k] : 0.f;
+    uint32_t m01, m23;
+    epi_col_consts(bias, n0 + col0, wrows, bq, m01, m23);
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
       const int row = wm * WTM + i * 16 + l16;
-      float v[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = n0 + col0 + k < wrows ? apply_act(acc[i][j][k] + bq[k], act) : 0.f;
-      u32x2 pk;
-      pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-      pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-      *reinterpret_cast<u32x2*>(ctile + row * CROW + col0 * 2) = pk;
+      *reinterpret_cast<u32x2*>(ctile + row * CROW + col0 * 2) =
+          epi_finish4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3], bq, slope, m01, m23);
     }
   }
   __syncthreads();

@@ -345,26 +345,7 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, cons
   // Branch-free and small: act(v) = max(v,0) + slope*min(v,0) (slope 0 / 0.2 / 1 for ReLU / LeakyReLU / none -- exact for
   // all three), padded output channels (n >= wrows) cleared with a bit mask on the packed pair.  The unrolled
   // per-element `act` switch this replaces was 60 % of the kernel's code, and a dispatch walks its code cold.
-  const float slope = act == ACT_RELU ? 0.f : (act == ACT_LRELU ? 0.2f : 1.f);
-  auto finish4 = [&](const float (&a4)[4], const float (&bq)[4], uint32_t m01, uint32_t m23) -> u32x2 {
-    float v[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float t = a4[k] + bq[k];
-      v[k] = fmaf(slope, fminf(t, 0.f), fmaxf(t, 0.f));
-    }
-    u32x2 pk;
-    pk.x = ((uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16)) & m01;
-    pk.y = ((uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16)) & m23;
-    return pk;
-  };
-  auto col_consts = [&](int col0, float (&bq)[4], uint32_t& m01, uint32_t& m23) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) bq[k] = (bias != nullptr && n0 + col0 + k < wrows) ? bias[n0 + col0 + k] : 0.f;
-    const int live = wrows - (n0 + col0);             // channels of this group of four that exist
-    m01 = live >= 2 ? 0xffffffffu : (live == 1 ? 0x0000ffffu : 0u);
-    m23 = live >= 4 ? 0xffffffffu : (live == 3 ? 0x0000ffffu : 0u);
-  };
+  const float slope = act_slope(act);
   if constexpr (M16) {
     // D row = channel 4*kg + e of its 16-block, col = pixel l16
 #pragma unroll
@@ -372,12 +353,12 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, cons
       const int col0 = wn * WTN + j * 16 + 4 * kg;
       float bq[4];
       uint32_t m01, m23;
-      col_consts(col0, bq, m01, m23);
+      epi_col_consts(bias, n0 + col0, wrows, bq, m01, m23);
 #pragma unroll
       for (int i = 0; i < PB; ++i) {
         const int row = (wm * TM + (i >> 1)) * 32 + (i & 1) * 16 + l16;
-        const float a4[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-        *reinterpret_cast<u32x2*>(ctile + row * CROW + col0 * 2) = finish4(a4, bq, m01, m23);
+        *reinterpret_cast<u32x2*>(ctile + row * CROW + col0 * 2) =
+            epi_finish4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3], bq, slope, m01, m23);
       }
     }
   } else {
@@ -388,12 +369,12 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, cons
         const int col0 = wn * WTN + j * 32 + 8 * q + 4 * lh;             // first of this lane's four channels
         float bq[4];
         uint32_t m01, m23;
-        col_consts(col0, bq, m01, m23);
+        epi_col_consts(bias, n0 + col0, wrows, bq, m01, m23);
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
           const int row = (wm * TM + i) * 32 + lr;
-          const float a4[4] = {acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
-          *reinterpret_cast<u32x2*>(ctile + row * CROW + col0 * 2) = finish4(a4, bq, m01, m23);
+          *reinterpret_cast<u32x2*>(ctile + row * CROW + col0 * 2) =
+              epi_finish4(acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3], bq, slope, m01, m23);
         }
       }
   }

@@ -44,8 +44,11 @@ hipError_t gather_gemm(int dtype, const GatherDesc& g, const void* src, const vo
 hipError_t gather_gemm_multi(int dtype, const GatherDesc* descs, const long long* woffs, int n, const void* src,
                              const void* wgt, int wrows, const float* bias, void* out, float* ws, size_t ws_bytes, int ldc,
                              int act, hipStream_t st, bool compact_ws = false);
+// One wgrad slab: the packed [Cout][K] gradient with the row count rounded up to 8, so the kernels' 8-row store
+// groups need no per-row guard (the rows beyond Cout are never read).
+static inline long long wgrad_slab_elems(int co_rows, int K) { return (long long)((co_rows + 7) & ~7) * K; }
 // nsplit_out != nullptr: dw holds up to capacity_elems floats; split z writes slab z, *nsplit_out slabs to be summed
-// by wgrad_reduce_unpack (deterministic).  nsplit_out == nullptr: dw is one packed buffer, splits accumulate with atomics.
+// by wgrad_reduce_unpack (deterministic).  nsplit_out == nullptr: dw is one packed buffer, written by a single split.
 hipError_t wgrad_gemm(int dtype, const GatherDesc& g, const void* src, const void* dy, int co_rows, int ldy, float* dw,
                       size_t capacity_elems, int* nsplit_out, hipStream_t st);
 

@@ -160,27 +160,37 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const GatherDesc g, con
   };
 
   // ---- two-stage ring over the half-tiles of this split: one barrier per half-tile (~4 600 cycles of MFMA) ----
+  // (rotated: the trip it = -1 only issues stage 0, so `issue` and `compute` each exist once in the instruction stream)
   const int nt = tend - tbeg;
-  if (nt > 0) {
-    issue(0, tbeg);
-    for (int it = 0; it < nt; ++it) {
+#pragma unroll 1
+  for (int it = -1; it < nt; ++it) {
+    if (it >= 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // my share of stage `it` has landed
       __builtin_amdgcn_s_barrier();                                       // ... everyone's; compute(it-1) is done everywhere
-      if (it + 1 < nt) issue((it + 1) & 1, tbeg + it + 1);
-      compute(it & 1);
     }
+    if (it + 1 < nt) issue((it + 1) & 1, tbeg + it + 1);
+    if (it >= 0) compute(it & 1);
   }
 
   // ---- partial block -> this split's slab [Cout][9][Cs] (lanes run along ci: 128-byte segments) ----
+  // co_rows is a multiple of 8 (the padded channel count), and the 8 rows 8q .. 8q+7 of a 32-block are held by the
+  // lanes' (e & 3, lh): one wave-uniform guard per row group instead of a per-element exec mask (the unrolled
+  // per-element guards were 2/3 of this kernel's code, and a dispatch walks its code cold)
   float* slab = slabs + (size_t)split * slab_elems;
+  const int co_w = __builtin_amdgcn_readfirstlane(c0 + cb * 32);
+  float* p0 = slab + (size_t)(co_w + 4 * lh) * g.K + ci0 + ib * 32 + lr;
 #pragma unroll
-  for (int t = 0; t < TPW; ++t)
+  for (int t = 0; t < TPW; ++t) {
+    const int tap = tap0 + t;
+    if (NTG > 1 && tap >= 9) break;
+    float* pt = p0 + tap * g.Cs;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int co = c0 + cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-      const int tap = tap0 + t;
-      if (co < co_rows && tap < 9) slab[(size_t)co * g.K + tap * g.Cs + ci0 + ib * 32 + lr] = acc[t][e];
+    for (int q = 0; q < 4; ++q) {
+      if (co_w + 8 * q >= co_rows) break;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pt[(size_t)(8 * q + r) * g.K] = acc[t][q * 4 + r];
     }
+  }
 }
 
 template <int BCO, int BCI, int NTG>
@@ -192,7 +202,7 @@ static hipError_t launch_wgrad_halo(const GatherDesc& g, const void* src, const 
   int splits = std::max(1, num_cu / combos);                  // one workgroup per CU, a single round
   if (splits > 8) splits -= splits % 8;                       // the combos of a split land on one XCD (linear id % 8)
   if (splits > ntiles / 4) splits = std::max(1, ntiles / 4);
-  const long long slab_elems = (long long)co_rows * g.K;
+  const long long slab_elems = wgrad_slab_elems(co_rows, g.K);
   if ((size_t)slab_elems * splits > slab_capacity_elems) splits = (int)(slab_capacity_elems / (size_t)slab_elems);
   if (splits < 1) return hipErrorNotSupported;
   if (!force && combos * splits < (num_cu * 3) / 4) return hipErrorNotSupported;   // too little parallelism: wgrad_v2 / v1 fill the chip better

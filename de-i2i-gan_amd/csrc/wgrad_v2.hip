@@ -229,7 +229,7 @@ hipError_t wgrad_v2(const GatherDesc& g, const void* src, const void* dy, int co
   const int nchunks = (g.M + BR - 1) / BR;
   int splits = std::max(1, num_cu / tiles);                  // one workgroup per CU (144 KB LDS), a single round
   if (splits > nchunks / 8) splits = std::max(1, nchunks / 8);
-  const long long slab_elems = (long long)co_rows * g.K;
+  const long long slab_elems = wgrad_slab_elems(co_rows, g.K);
   if ((size_t)slab_elems * splits > slab_capacity_elems) splits = (int)(slab_capacity_elems / (size_t)slab_elems);
   if (splits < 1) return hipErrorNotSupported;
   const int cps = (nchunks + splits - 1) / splits;

@@ -206,7 +206,7 @@ class _Conv2d(torch.autograd.Function):
             L.check(lib.dei2i_conv2d_dgrad_input(byref(d), _p(g), _p(wd), _p(ext), _p(dx), _p(ws), ws.numel() * 4, st),
                     "conv2d_dgrad_input")
         if ctx.needs_input_grad[1]:
-            packed = lib.dei2i_packed_fwd_elems(byref(d))
+            packed = lib.dei2i_wgrad_slab_elems(byref(d))
             # partial slabs: up to 64, or as many as fit 96 MB (a (co, ci, 9-tap) register block per CU is 256 x 295 KB)
             scratch = _workspace(x.device, max(packed * 4, min(max(packed * 4 * 64, 96 << 20), 512 << 20)), slot="wgrad")
             dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)

@@ -75,10 +75,14 @@ int dei2i_conv2d_dgrad(const dei2i_conv* c, const void* dy, const void* wd_packe
  * as interior GEMM (straight into dx) + reflect-ring GEMM + border fold; everything else as dgrad + dei2i_fold_pad. */
 int dei2i_conv2d_dgrad_input(const dei2i_conv* c, const void* dy, const void* wd_packed, void* ext_scratch, void* dx,
                              float* ws, size_t ws_bytes, dei2i_stream s);
-/* dw_packed (fp32, dei2i_packed_fwd_elems) is zeroed by the call, then accumulated with fp32 atomics */
+/* one wgrad slab: the packed [Cout][kh*kw][CinS] fp32 gradient with Cout rounded up to 8 rows (the kernels store
+ * 8-row groups unguarded; the extra rows are never read) */
+size_t dei2i_wgrad_slab_elems(const dei2i_conv* c);
+/* dw_packed (fp32, dei2i_wgrad_slab_elems), written by a single pass over the pixels (plain stores, deterministic);
+ * the production path is dei2i_conv2d_wgrad_oihw, which splits the pixel range over slabs */
 int dei2i_conv2d_wgrad(const dei2i_conv* c, const void* x, const void* dy, float* dw_packed, dei2i_stream s);
 /* wgrad straight to the OIHW fp32 gradient (what autograd hands to the optimizer).  scratch: fp32 device buffer of at
- * least dei2i_packed_fwd_elems(c) floats; extra capacity lets the LDS-DMA kernel split the pixel range over more
+ * least dei2i_wgrad_slab_elems(c) floats; extra capacity lets the kernels split the pixel range over more
  * workgroups (one partial slab per split, summed and un-packed by a second kernel: no float atomics). */
 int dei2i_conv2d_wgrad_oihw(const dei2i_conv* c, const void* x, const void* dy, float* scratch, size_t scratch_elems,
                             float* dw_oihw, dei2i_stream s);
