@@ -47,7 +47,7 @@ SIGNATURES = {
     "dei2i_conv2d_dgrad": (c_int, [_CD, _P, _P, _P, _P, c_size_t, _P]),
     "dei2i_conv2d_dgrad_input": (c_int, [_CD, _P, _P, _P, _P, _P, c_size_t, _P]),
     "dei2i_conv2d_wgrad": (c_int, [_CD, _P, _P, _P, _P]),
-    "dei2i_conv2d_wgrad_oihw": (c_int, [_CD, _P, _P, _P, c_size_t, _P, _P]),
+    "dei2i_conv2d_wgrad_oihw": (c_int, [_CD, _P, _P, _P, c_size_t, _P, c_int, _P]),
     "dei2i_fold_pad": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "dei2i_nchw_to_nhwc": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "dei2i_nhwc_to_nchw": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
@@ -65,7 +65,7 @@ SIGNATURES = {
     "dei2i_colsum": (c_int, [c_int, c_size_t, c_int, _P, _P, _P, _P]),
     "dei2i_bn_bwd_chunks": (c_int, [c_size_t]),
     "dei2i_bn_bwd_partial": (c_int, [c_int, c_size_t, c_int, _P, _P, _P, _P, _P, _P, c_int, _P, _P]),
-    "dei2i_bn_bwd_apply": (c_int, [c_int, c_size_t, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_int, _P, _P, _P, _P]),
+    "dei2i_bn_bwd_apply": (c_int, [c_int, c_size_t, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P, _P]),
     "dei2i_spade_bwd_partial": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P]),
     "dei2i_spade_bwd_apply": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P, c_int, _P, _P, _P, _P, _P]),
     "dei2i_compose_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),

@@ -331,7 +331,7 @@ int dei2i_conv2d_wgrad(const dei2i_conv* c, const void* x, const void* dy, float
  * (scratch >= dei2i_wgrad_slab_elems floats; more lets it split the pixel range further); other shapes take the v1 kernel
  * into scratch[0 : packed elems] and the un-pack kernel. */
 int dei2i_conv2d_wgrad_oihw(const dei2i_conv* c, const void* x, const void* dy, float* scratch, size_t scratch_elems,
-                            float* dw_oihw, dei2i_stream s) {
+                            float* dw_oihw, int accumulate, dei2i_stream s) {
   if (!valid_conv(c) || !x || !dy || !scratch || !dw_oihw) return DEI2I_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)s;
   GatherDesc g = make_fwd_desc(to_shape(c), c->CinS);
@@ -341,20 +341,20 @@ int dei2i_conv2d_wgrad_oihw(const dei2i_conv* c, const void* x, const void* dy, 
     int nsplit = 0;
     hipError_t e = wgrad_halo(g, x, dy, c->Cout, c->CoutS, scratch, scratch_elems, num_cu(), &nsplit, g_use_wgrad_halo == 2, st);
     if (e == hipSuccess)
-      return (int)wgrad_reduce_unpack(scratch, nsplit, (long long)packed, dw_oihw, c->Cout, c->Cin, c->CinS, c->kh * c->kw, st);
+      return (int)wgrad_reduce_unpack(scratch, nsplit, (long long)packed, dw_oihw, c->Cout, c->Cin, c->CinS, c->kh * c->kw, accumulate, st);
     if (e != hipErrorNotSupported) return (int)e;
   }
   if (c->dtype == DT_BF16 && g_use_wgrad_v2) {
     int nsplit = 0;
     hipError_t e = wgrad_v2(g, x, dy, c->Cout, c->CoutS, scratch, scratch_elems, num_cu(), &nsplit, st);
     if (e == hipSuccess)
-      return (int)wgrad_reduce_unpack(scratch, nsplit, (long long)packed, dw_oihw, c->Cout, c->Cin, c->CinS, c->kh * c->kw, st);
+      return (int)wgrad_reduce_unpack(scratch, nsplit, (long long)packed, dw_oihw, c->Cout, c->Cin, c->CinS, c->kh * c->kw, accumulate, st);
     if (e != hipErrorNotSupported) return (int)e;
   }
   int nsplit = 0;
   hipError_t e = wgrad_gemm(c->dtype, g, x, dy, c->Cout, c->CoutS, scratch, scratch_elems, &nsplit, st);
   if (e != hipSuccess) return (int)e;
-  return (int)wgrad_reduce_unpack(scratch, nsplit, (long long)packed, dw_oihw, c->Cout, c->Cin, c->CinS, c->kh * c->kw, st);
+  return (int)wgrad_reduce_unpack(scratch, nsplit, (long long)packed, dw_oihw, c->Cout, c->Cin, c->CinS, c->kh * c->kw, accumulate, st);
 }
 
 int dei2i_fold_pad(int dtype, int N, int H, int W, int C, int pad, int pad_mode, int up, const void* dx_ext,

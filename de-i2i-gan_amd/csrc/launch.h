@@ -57,7 +57,7 @@ hipError_t wgrad_v2(const GatherDesc& g, const void* src, const void* dy, int co
 hipError_t wgrad_halo(const GatherDesc& g, const void* src, const void* dy, int co_rows, int ldy, float* slabs,
                       size_t slab_capacity_elems, int num_cu, int* nsplit_out, bool force, hipStream_t st);
 hipError_t wgrad_reduce_unpack(float* slabs, int nsplit, long long slab_elems, float* dw, int Cout, int Cin, int CinS,
-                               int taps, hipStream_t st);
+                               int taps, int accumulate, hipStream_t st);
 
 inline unsigned grid_for(size_t work_items, int threads, unsigned cap = 256u * 8u) {
   size_t b = (work_items + threads - 1) / threads;

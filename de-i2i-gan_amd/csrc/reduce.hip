@@ -20,8 +20,8 @@ static inline int vec_of(int dtype) { return dtype == DT_BF16 ? 8 : 4; }
 // The sum runs as a ROLLED loop over (quantity, element, channel-vector) outputs on all 256 threads -- a few hundred
 // bytes of code instead of NV*VEC unrolled serial LDS sums on cv threads (a dispatch walks its code cold: code size
 // is launch latency for these short kernels).
-template <int NV, int VEC>
-DEI2I_D void block_combine_store(const float (&vals)[NV][VEC], int cv, int rpp, float* smem, float* __restrict__ dst, int C) {
+template <int NV, int VEC, typename OT = float>
+DEI2I_D void block_combine_store(const float (&vals)[NV][VEC], int cv, int rpp, float* smem, OT* __restrict__ dst, int C) {
   const int tid = threadIdx.x;
   const int vcol = tid % cv, prow = tid / cv;
   __syncthreads();
@@ -39,7 +39,7 @@ DEI2I_D void block_combine_store(const float (&vals)[NV][VEC], int cv, int rpp, 
     float sum = 0.f;
     for (int r = 0; r < rpp; ++r) sum += src[r * cv];
     const int q = qe / VEC, e = qe - q * VEC;
-    dst[(size_t)q * C + vc * VEC + e] = sum;
+    Elem<OT>::store(dst + (size_t)q * C + vc * VEC + e, sum);
   }
 }
 
@@ -211,13 +211,18 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int C,
-                                                              float* __restrict__ dweight, float* __restrict__ dbias) {
+                                                              float* __restrict__ dweight, float* __restrict__ dbias,
+                                                              float* __restrict__ acc_dweight, float* __restrict__ acc_dbias) {
   const int c = blockIdx.x;
   double sq[2];
   combine_records<2>(partial, 0, chunks, C, c, sq);
   if (threadIdx.x != 0) return;
   dbias[c] = (float)sq[0];
   dweight[c] = (float)sq[1];
+  if (acc_dweight != nullptr) {      // a further use of the same parameters in this backward pass: add into its gradient
+    acc_dbias[c] += (float)sq[0];
+    acc_dweight[c] += (float)sq[1];
+  }
 }
 
 // dy = a*(g - sum_g/M - xhat*sum_gx/M) with g = dz*act'(a*y+b), xhat = (y-mean)*rstd, folded per channel into
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(256) void spade_bwd_partial_kernel(const T* __restr
 template <typename T>
 __global__ __launch_bounds__(256) void spade_bwd_border_kernel(const T* __restrict__ dz, const T* __restrict__ x,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                               const T* __restrict__ gb, float* __restrict__ dgb_cls, int H,
+                                                               const T* __restrict__ gb, T* __restrict__ dgb_cls, int H,
                                                                int W, int C, int up) {
   constexpr int VEC = Elem<T>::VEC;
   extern __shared__ float smem[];
@@ -406,13 +411,13 @@ __global__ __launch_bounds__(256) void spade_bwd_border_kernel(const T* __restri
       }
     }
   }
-  block_combine_store<2, VEC>(v, cv, rpp, smem, dgb_cls + (((size_t)n * 5 + cy) * 5 + cx) * 2 * C, C);
+  block_combine_store<2, VEC, T>(v, cv, rpp, smem, dgb_cls + (((size_t)n * 5 + cy) * 5 + cx) * 2 * C, C);
 }
 
 // coef[(n*2 + {0,1})*C + c] = s1/M, s2/M ; interior-class gamma/beta sums added into dgb_cls[n,2,2,:]
 __global__ __launch_bounds__(256) void spade_bwd_finalize_kernel(const float* __restrict__ partial, int N, int chunks, int C,
                                                                  double count, float* __restrict__ coef,
-                                                                 float* __restrict__ dgb_cls) {
+                                                                 void* __restrict__ dgb_cls, int dtype) {
   const int c = blockIdx.x, n = blockIdx.y;
   double sq[4];
   combine_records<4>(partial, (size_t)n * chunks, chunks, C, c, sq);
@@ -421,8 +426,15 @@ __global__ __launch_bounds__(256) void spade_bwd_finalize_kernel(const float* __
   coef[((size_t)n * 2 + 1) * C + c] = (float)(sq[1] / count);
   if (dgb_cls != nullptr) {
     const size_t gpix = ((size_t)n * 5 + 2) * 5 + 2;
-    dgb_cls[gpix * 2 * C + c] += (float)sq[2];
-    dgb_cls[gpix * 2 * C + C + c] += (float)sq[3];
+    if (dtype == DT_BF16) {          // the border kernel wrote the other 24 classes; this is the only writer of (2,2)
+      bf16_t* o = (bf16_t*)dgb_cls;
+      o[gpix * 2 * C + c] = f32_to_bf16((float)sq[2]);
+      o[gpix * 2 * C + C + c] = f32_to_bf16((float)sq[3]);
+    } else {
+      float* o = (float*)dgb_cls;
+      o[gpix * 2 * C + c] = (float)sq[2];
+      o[gpix * 2 * C + C + c] = (float)sq[3];
+    }
   }
 }
 
@@ -681,12 +693,14 @@ int dei2i_bn_bwd_partial(int dtype, size_t pixels, int C, const void* dz, const 
 
 int dei2i_bn_bwd_apply(int dtype, size_t pixels, int C, const void* dz, const void* y, const float* a, const float* b,
                        const float* mean, const float* rstd, int act, int train, const float* partial, int chunks,
-                       float* dweight, float* dbias, void* dy, dei2i_stream s) {
+                       float* dweight, float* dbias, float* acc_dweight, float* acc_dbias, void* dy, dei2i_stream s) {
   const int vec = dtype == DT_BF16 ? 8 : 4;
-  if (pixels == 0 || !cv_ok(dtype, C) || !dz || !y || !a || !b || !mean || !rstd || !partial || !dweight || !dbias || !dy)
+  if (pixels == 0 || !cv_ok(dtype, C) || !dz || !y || !a || !b || !mean || !rstd || !partial || !dweight || !dbias || !dy ||
+      (acc_dweight == nullptr) != (acc_dbias == nullptr))
     return DEI2I_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)s;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(combine_threads(chunks)), 0, st, partial, chunks, C, dweight, dbias);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(combine_threads(chunks)), 0, st, partial, chunks, C, dweight, dbias,
+                     acc_dweight, acc_dbias);
   const size_t nvec = pixels * (size_t)(C / vec);
   const unsigned grid = grid_for((nvec + 1) / 2, 256, 256u * 8u);
   const float inv = 1.f / (float)pixels;
@@ -709,10 +723,6 @@ int dei2i_spade_bwd_partial(int dtype, int N, int H, int W, int C, int up, const
   if (gb_mode == 1 && (H < 4 || W < 4)) return DEI2I_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)s;
   const int chunks = dei2i_moments_chunks(H * W);
-  if (gb_mode == 1) {
-    hipError_t e = hipMemsetAsync(dgb, 0, (size_t)N * 25 * 2 * C * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
-  }
   if (dtype == DT_BF16)
     hipLaunchKernelGGL(spade_bwd_partial_kernel<bf16_t>, dim3(chunks, N), dim3(256), combine_lds(dtype, 4), st,
                        (const bf16_t*)dz, (const bf16_t*)x, mean, rstd, (const bf16_t*)gb, gb_mode,
@@ -724,7 +734,7 @@ int dei2i_spade_bwd_partial(int dtype, int N, int H, int W, int C, int up, const
   if (gb_mode == 1) {
     if (dtype == DT_BF16)
       hipLaunchKernelGGL(spade_bwd_border_kernel<bf16_t>, dim3(25, N), dim3(256), combine_lds(dtype, 2), st, (const bf16_t*)dz,
-                         (const bf16_t*)x, mean, rstd, (const bf16_t*)gb, (float*)dgb, H, W, C, up);
+                         (const bf16_t*)x, mean, rstd, (const bf16_t*)gb, (bf16_t*)dgb, H, W, C, up);
     else
       hipLaunchKernelGGL(spade_bwd_border_kernel<float>, dim3(25, N), dim3(256), combine_lds(dtype, 2), st, (const float*)dz,
                          (const float*)x, mean, rstd, (const float*)gb, (float*)dgb, H, W, C, up);
@@ -733,7 +743,7 @@ int dei2i_spade_bwd_partial(int dtype, int N, int H, int W, int C, int up, const
 }
 
 int dei2i_spade_bwd_apply(int dtype, int N, int H, int W, int C, int up, const void* dz, const void* x, const float* mean,
-                          const float* rstd, const void* gb, int gb_mode, const float* partial, int chunks, float* dgb_cls,
+                          const float* rstd, const void* gb, int gb_mode, const float* partial, int chunks, void* dgb_cls,
                           float* coef, const void* addend, void* dx, dei2i_stream s) {
   const int vec = dtype == DT_BF16 ? 8 : 4;
   if (N <= 0 || H <= 0 || W <= 0 || !cv_ok(dtype, C) || up < 0 || up > 1 || !dz || !x || !mean || !rstd || !gb || !partial ||
@@ -741,7 +751,7 @@ int dei2i_spade_bwd_apply(int dtype, int N, int H, int W, int C, int up, const v
     return DEI2I_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)s;
   hipLaunchKernelGGL(spade_bwd_finalize_kernel, dim3(C, N), dim3(combine_threads(chunks)), 0, st, partial, N, chunks, C,
-                     (double)H * (double)W, coef, dgb_cls);
+                     (double)H * (double)W, coef, dgb_cls, dtype);
   const size_t total = (size_t)N * (H >> up) * (W >> up) * (C / vec);
   const unsigned grid = grid_for(total, 256, 256u * 16u);
   if (dtype == DT_BF16)

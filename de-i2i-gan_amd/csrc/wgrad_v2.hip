@@ -190,7 +190,8 @@ __global__ __launch_bounds__(512) void wgrad_v2_kernel(const GatherDesc g, const
 constexpr int RU_CB = 64;            // channels per block
 constexpr int RU_MAX_TAPS = 64;      // 8x8 (cls_clf at 512x512) is the largest kernel of the path
 __global__ __launch_bounds__(256) void wgrad_reduce_unpack_kernel(const float* __restrict__ slabs, int nsplit, long long slab_elems,
-                                                                  float* __restrict__ dw, int Cout, int Cin, int CinS, int taps) {
+                                                                  float* __restrict__ dw, int Cout, int Cin, int CinS, int taps,
+                                                                  int accumulate) {
   extern __shared__ float ru_lds[];                 // [taps][RU_CB + 1]
   const int co = blockIdx.x, ci0 = blockIdx.y * RU_CB;
   const int cb = min(RU_CB, CinS - ci0);
@@ -215,7 +216,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_unpack_kernel(const float* _
   float* o = dw + ((size_t)co * Cin + ci0) * taps;
   for (int j = threadIdx.x; j < live * taps; j += 256) {
     const int cl = j / taps, t = j - cl * taps;
-    o[j] = ru_lds[t * (RU_CB + 1) + cl];
+    const float v = ru_lds[t * (RU_CB + 1) + cl];
+    o[j] = accumulate ? o[j] + v : v;
   }
 }
 
@@ -286,7 +288,7 @@ __global__ void slab_group_sum_kernel(float* __restrict__ slabs, int nsplit, lon
 }
 
 hipError_t wgrad_reduce_unpack(float* slabs, int nsplit, long long slab_elems, float* dw, int Cout, int Cin, int CinS,
-                               int taps, hipStream_t st) {
+                               int taps, int accumulate, hipStream_t st) {
   if (taps > RU_MAX_TAPS || Cout <= 0 || CinS <= 0) return hipErrorInvalidValue;
   const int cblocks = (CinS + RU_CB - 1) / RU_CB;
   long long stride = slab_elems;
@@ -300,7 +302,7 @@ hipError_t wgrad_reduce_unpack(float* slabs, int nsplit, long long slab_elems, f
   }
   const size_t lds = (size_t)taps * (RU_CB + 1) * sizeof(float);
   hipLaunchKernelGGL(wgrad_reduce_unpack_kernel, dim3(Cout, cblocks), dim3(256), lds, st, (const float*)slabs, nsplit, stride, dw,
-                     Cout, Cin, CinS, taps);
+                     Cout, Cin, CinS, taps, accumulate);
   return hipGetLastError();
 }
 

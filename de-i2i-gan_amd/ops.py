@@ -88,6 +88,32 @@ def _workspace(device, nbytes: int, slot: str = "splitk") -> torch.Tensor:
     return ws
 
 
+# ---- in-place accumulation of parameter gradients within one backward pass --------------------------------------
+# The G step applies every generator layer four times (defectgan_model.py:185-190), so autograd would receive four
+# gradients per parameter and sum them with one add kernel each (171 launches per step).  Instead the first backward
+# node of a parameter in a pass returns a fresh gradient tensor and remembers its address under the pass's graph-task
+# id; the later nodes of the same pass add into that memory inside their own kernels (wgrad reduce, BatchNorm
+# finalize) and return None -- autograd treats an undefined gradient as "no contribution" and still runs the
+# parameter's AccumulateGrad (and its post-accumulate hooks: the data-parallel reducer) once, after its last node.
+# The tensor is kept alive by autograd's input buffer until then; only its address is stored here, so AccumulateGrad
+# can still steal it (no copy).  Non-leaf weights (concatenated gamma|beta) are not tracked.
+_grad_slots = {}
+
+
+def _grad_target(param, shape, device):
+    """-> (tensor to return to autograd or None, its address, accumulate flag)"""
+    tid = torch._C._current_graph_task_id()
+    key = param.data_ptr() if (param.is_leaf and tid >= 0) else None
+    if key is not None:
+        slot = _grad_slots.get(key)
+        if slot is not None and slot[0] == tid and slot[2] == tuple(shape):
+            return None, slot[1], 1
+    t = torch.empty(shape, dtype=torch.float32, device=device)
+    if key is not None:
+        _grad_slots[key] = (tid, t.data_ptr(), tuple(shape))
+    return t, t.data_ptr(), 0
+
+
 _const_vecs = {}
 
 
@@ -209,9 +235,9 @@ class _Conv2d(torch.autograd.Function):
             packed = lib.dei2i_wgrad_slab_elems(byref(d))
             # partial slabs: up to 64, or as many as fit 96 MB (a (co, ci, 9-tap) register block per CU is 256 x 295 KB)
             scratch = _workspace(x.device, max(packed * 4, min(max(packed * 4 * 64, 96 << 20), 512 << 20)), slot="wgrad")
-            dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
-            L.check(lib.dei2i_conv2d_wgrad_oihw(byref(d), _p(x), _p(g), _p(scratch), scratch.numel(), _p(dw), st),
-                    "conv2d_wgrad")
+            dw, dw_ptr, accumulate = _grad_target(weight, weight.shape, x.device)
+            L.check(lib.dei2i_conv2d_wgrad_oihw(byref(d), _p(x), _p(g), _p(scratch), scratch.numel(), c_void_p(dw_ptr), accumulate,
+                                                st), "conv2d_wgrad")
         if ctx.has_bias and ctx.needs_input_grad[2]:
             dbf = torch.empty(couts, dtype=torch.float32, device=x.device)
             rows = g.numel() // couts
@@ -321,6 +347,7 @@ class _BatchNormAct(torch.autograd.Function):
             res = res.contiguous()
         L.check(lib.dei2i_affine_act_fwd(prec.code, n * h * w, c, _p(y), _p(a), _p(b), _p(res), act, _p(out), st), "affine_act")
         ctx.prec, ctx.act, ctx.training, ctx.has_res = prec, act, training, res is not None
+        ctx.params = (weight, bias)
         ctx.save_for_backward(y, a, b, mean, rstd)
         return out
 
@@ -337,12 +364,20 @@ class _BatchNormAct(torch.autograd.Function):
         partial = torch.empty((chunks, 2, c), dtype=torch.float32, device=y.device)
         L.check(lib.dei2i_bn_bwd_partial(prec.code, pixels, c, _p(dout), _p(y), _p(a), _p(b), _p(mean), _p(rstd), ctx.act,
                                          _p(partial), st), "bn_bwd_partial")
-        dweight = torch.empty(c, dtype=torch.float32, device=y.device)
-        dbias = torch.empty(c, dtype=torch.float32, device=y.device)
+        weight, bias = ctx.params
+        dweight, dw_ptr, acc_w = _grad_target(weight, (c,), y.device)
+        dbias, db_ptr, acc_b = _grad_target(bias, (c,), y.device)
+        acc_ptrs = (None, None)
+        if acc_w or acc_b:            # the kernel needs this call's own sums as well: they go to scratch vectors
+            if not (acc_w and acc_b):                      # (cannot happen for an nn.BatchNorm2d; keep the pair in step)
+                raise RuntimeError("batchnorm weight and bias gradients out of step")
+            acc_ptrs = (c_void_p(dw_ptr), c_void_p(db_ptr))
+            tmp = torch.empty((2, c), dtype=torch.float32, device=y.device)
+            dw_ptr, db_ptr = tmp.data_ptr(), tmp.data_ptr() + 4 * c
         dy = torch.empty_like(y)
         L.check(lib.dei2i_bn_bwd_apply(prec.code, pixels, c, _p(dout), _p(y), _p(a), _p(b), _p(mean), _p(rstd), ctx.act,
-                                       1 if ctx.training else 0, _p(partial), chunks, _p(dweight), _p(dbias), _p(dy), st),
-                "bn_bwd_apply")
+                                       1 if ctx.training else 0, _p(partial), chunks, c_void_p(dw_ptr), c_void_p(db_ptr),
+                                       acc_ptrs[0], acc_ptrs[1], _p(dy), st), "bn_bwd_apply")
         return dy, dweight, dbias, (dout if ctx.has_res else None), None, None, None, None, None, None
 
 
@@ -414,10 +449,7 @@ class _SpadeRelu(torch.autograd.Function):
         n, h, w, c = ctx.out_shape
         chunks = lib.dei2i_moments_chunks(h * w)
         partial = torch.empty((n, chunks, 4, c), dtype=torch.float32, device=dev)
-        if gb_mode == 0:
-            dgb = torch.empty_like(gb)
-        else:
-            dgb = torch.empty((n, 5, 5, 2 * c), dtype=torch.float32, device=dev)
+        dgb = torch.empty_like(gb)         # dense (N,H,W,2C), or the (N,5,5,2C) class table -- both written in full
         L.check(lib.dei2i_spade_bwd_partial(prec.code, n, h, w, c, 1 if up else 0, _p(dout), _p(x), _p(mean), _p(rstd),
                                             _p(gb), gb_mode, _p(dgb), _p(partial), st), "spade_bwd_partial")
         coef = torch.empty((n, 2, c), dtype=torch.float32, device=dev)
@@ -425,10 +457,6 @@ class _SpadeRelu(torch.autograd.Function):
         L.check(lib.dei2i_spade_bwd_apply(prec.code, n, h, w, c, 1 if up else 0, _p(dout), _p(x), _p(mean), _p(rstd), _p(gb), gb_mode,
                                           _p(partial), chunks, _p(dgb) if gb_mode == 1 else None, _p(coef), None, _p(dx), st),
                 "spade_bwd_apply")
-        if gb_mode == 1 and prec.dtype != torch.float32:
-            dgb_t = torch.empty(dgb.shape, dtype=prec.dtype, device=dev)
-            L.check(lib.dei2i_cast_from_f32(prec.code, dgb.numel(), _p(dgb), _p(dgb_t), st), "cast")
-            dgb = dgb_t
         return dx, dgb, None, None, None
 
 

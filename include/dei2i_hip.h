@@ -84,8 +84,9 @@ int dei2i_conv2d_wgrad(const dei2i_conv* c, const void* x, const void* dy, float
 /* wgrad straight to the OIHW fp32 gradient (what autograd hands to the optimizer).  scratch: fp32 device buffer of at
  * least dei2i_wgrad_slab_elems(c) floats; extra capacity lets the kernels split the pixel range over more
  * workgroups (one partial slab per split, summed and un-packed by a second kernel: no float atomics). */
+/* accumulate != 0: dw_oihw += (a further use of the same weight in one backward pass adds into its gradient in place) */
 int dei2i_conv2d_wgrad_oihw(const dei2i_conv* c, const void* x, const void* dy, float* scratch, size_t scratch_elems,
-                            float* dw_oihw, dei2i_stream s);
+                            float* dw_oihw, int accumulate, dei2i_stream s);
 /* reflection_pad2d_backward + upsample_nearest2d_backward: fold the dgrad output (N,OH,OW,C) back onto the
  * physical input (N,H,W,C); optional addend (residual-branch gradient) is summed in the same pass. */
 int dei2i_fold_pad(int dtype, int N, int H, int W, int C, int pad, int pad_mode, int up, const void* dx_ext,
@@ -135,23 +136,25 @@ int dei2i_colsum_blocks(size_t rows);
 int dei2i_colsum(int dtype, size_t rows, int C, const void* g, float* partial, float* out, dei2i_stream s);
 /* BatchNorm backward (train): z = act(a*y+b); g = dz*act'(z); needs sum(g), sum(g*xhat) per channel.
  * bn_bwd_partial writes (chunks, 2, C) partial sums over `pixels` rows; bn_bwd_apply finishes:
- *   dy = a * (g - sum_g/M - xhat * sum_gx/M),  dweight = sum_gx, dbias = sum_g.   train = 0 -> dy = a*g. */
+ *   dy = a * (g - sum_g/M - xhat * sum_gx/M),  dweight = sum_gx, dbias = sum_g.   train = 0 -> dy = a*g.
+ *   acc_dweight / acc_dbias (both or neither, may be NULL): this call's sums are ALSO added into them -- the gradient
+ *   buffers of parameters that an earlier node of the same backward pass already wrote. */
 int dei2i_bn_bwd_chunks(size_t pixels);
 int dei2i_bn_bwd_partial(int dtype, size_t pixels, int C, const void* dz, const void* y, const float* a, const float* b,
                          const float* mean, const float* rstd, int act, float* partial, dei2i_stream s);
 int dei2i_bn_bwd_apply(int dtype, size_t pixels, int C, const void* dz, const void* y, const float* a, const float* b,
                        const float* mean, const float* rstd, int act, int train, const float* partial, int chunks,
-                       float* dweight, float* dbias, void* dy, dei2i_stream s);
+                       float* dweight, float* dbias, float* acc_dweight, float* acc_dbias, void* dy, dei2i_stream s);
 /* SPADE backward.  z = relu(v), v = xhat*(1+gamma)+beta is RECOMPUTED from x and the gamma/beta table in both passes (the
- * op keeps neither its output nor a dxhat tensor): g = dz*[v>0]; dgamma = g*xhat, dbeta = g -> dgb (dense T tensor, or
- * fp32 (N,5,5,2C) border-class table); partial (N, chunks, 4, C) fp32 sums of dxhat = g*(1+gamma), dxhat*xhat and the
+ * op keeps neither its output nor a dxhat tensor): g = dz*[v>0]; dgamma = g*xhat, dbeta = g -> dgb (T: dense tensor, or
+ * the (N,5,5,2C) border-class table -- its 24 border classes are written by pass 1, the interior class by pass 2); partial (N, chunks, 4, C) fp32 sums of dxhat = g*(1+gamma), dxhat*xhat and the
  * interior-class dgamma / dbeta.  chunks = dei2i_moments_chunks(H*W of the OUTPUT). */
 int dei2i_spade_bwd_partial(int dtype, int N, int H, int W, int C, int up, const void* dz, const void* x, const float* mean,
                             const float* rstd, const void* gb, int gb_mode, void* dgb, float* partial, dei2i_stream s);
 /* pass 2 (finalize + apply): dx = rstd*(sum_cell dxhat - cnt*mean(dxhat) - cnt*xhat*mean(dxhat*xhat)) (+ addend).
- * coef: fp32 scratch (N,2,C).  dgb_cls: the class-mode fp32 (N,5,5,2C) buffer of pass 1 (interior sums are added), or NULL. */
+ * coef: fp32 scratch (N,2,C).  dgb_cls: the class-mode (N,5,5,2C) table of pass 1 (its interior class is written here), or NULL. */
 int dei2i_spade_bwd_apply(int dtype, int N, int H, int W, int C, int up, const void* dz, const void* x, const float* mean,
-                          const float* rstd, const void* gb, int gb_mode, const float* partial, int chunks, float* dgb_cls,
+                          const float* rstd, const void* gb, int gb_mode, const float* partial, int chunks, void* dgb_cls,
                           float* coef, const void* addend, void* dx, dei2i_stream s);
 
 /* ---- generator heads + compose (generator.py:266-275) ----

@@ -57,7 +57,7 @@ for (H, W, C) in ((256, 256, 64), (128, 128, 128), (64, 64, 256)):
     dwt, dbs = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
     csp = torch.empty(lib.dei2i_colsum_blocks(pix) * C, device=DEV)
     timeit(tag + " bn_bwd_partial", lambda: lib.dei2i_bn_bwd_partial(BF, pix, C, p(dz), p(y), p(a), p(b), p(mean), p(rstd), L.ACT_LRELU, p(bpart), st), 2 * T)
-    timeit(tag + " bn_bwd_apply", lambda: lib.dei2i_bn_bwd_apply(BF, pix, C, p(dz), p(y), p(a), p(b), p(mean), p(rstd), L.ACT_LRELU, 1, p(bpart), bchunks, p(dwt), p(dbs), p(out), st), 3 * T)
+    timeit(tag + " bn_bwd_apply", lambda: lib.dei2i_bn_bwd_apply(BF, pix, C, p(dz), p(y), p(a), p(b), p(mean), p(rstd), L.ACT_LRELU, 1, p(bpart), bchunks, p(dwt), p(dbs), None, None, p(out), st), 3 * T)
     ext = torch.randn(N, H + 2, W + 2, C, device=DEV).bfloat16()
     timeit(tag + " fold_pad reflect1", lambda: lib.dei2i_fold_pad(BF, N, H, W, C, 1, L.PAD_REFLECT, 0, p(ext), None, p(out), st), 2 * T)
     # SPADE (class-mode gamma/beta table), no upsample

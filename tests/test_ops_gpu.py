@@ -60,6 +60,7 @@ CONV_CASES = [
     (64, 128, 3, 1, 1, True, False, 64, 64, 8, False, "none"),     # v2 BN=128, reflect; dgrad -> v2 BN=64
     (128, 64, 3, 1, 1, True, True, 32, 32, 8, False, "none"),      # v2 BN=64 with fused upsample; dgrad -> v2 BN=128
     (64, 128, 4, 2, 1, True, False, 128, 128, 8, False, "leaky_relu"),   # stride 2: 4 dgrad parity classes in one launch
+    (192, 128, 3, 1, 1, False, False, 32, 32, 4, False, "none"),    # wgrad v2 with a 128-column k-tile spanning taps (Cs = 192)
     (128, 192, 3, 1, 1, False, False, 30, 34, 32, True, "none"),   # zero padding through the zero page, ragged M, bias
     (64, 256, 3, 1, 1, True, False, 64, 60, 8, True, "relu"),      # 256x256-tile variant (2-stage ring), ragged M; wgrad v2
     # halo-resident kernel (bf16, stride-1 3x3, H % 8 == 0, W % 32 == 0, >= 128 tiles); the (64,128,...,64,64,8) and the
