@@ -8,6 +8,7 @@ namespace dei2i {
 
 int g_use_wgrad_v2 = 1;
 int g_use_wgrad_halo = 1;
+int g_use_wgrad_thin = 1;
 
 static ConvShape to_shape(const dei2i_conv* c) {
   ConvShape s;
@@ -337,6 +338,13 @@ int dei2i_conv2d_wgrad_oihw(const dei2i_conv* c, const void* x, const void* dy, 
   GatherDesc g = make_fwd_desc(to_shape(c), c->CinS);
   const size_t packed = (size_t)wgrad_slab_elems(c->Cout, g.K);      // slab stride: Cout rounded up to 8 rows
   if (scratch_elems < packed) return DEI2I_ERR_WORKSPACE;
+  if (c->dtype == DT_BF16 && g_use_wgrad_thin) {       // 8-channel input, 7x7 (the stem): halo-resident, windowed B operand
+    int nsplit = 0;
+    hipError_t e = wgrad_thin(g, x, dy, c->Cout, c->CoutS, scratch, scratch_elems, num_cu(), &nsplit, st);
+    if (e == hipSuccess)
+      return (int)wgrad_reduce_unpack(scratch, nsplit, (long long)packed, dw_oihw, c->Cout, c->Cin, c->CinS, c->kh * c->kw, accumulate, st);
+    if (e != hipErrorNotSupported) return (int)e;
+  }
   if (c->dtype == DT_BF16 && g_use_wgrad_halo) {       // stride-1 3x3: (co, ci, 9 taps) block resident in registers
     int nsplit = 0;
     hipError_t e = wgrad_halo(g, x, dy, c->Cout, c->CoutS, scratch, scratch_elems, num_cu(), &nsplit, g_use_wgrad_halo == 2, st);

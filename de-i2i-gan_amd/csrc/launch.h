@@ -56,6 +56,8 @@ hipError_t wgrad_v2(const GatherDesc& g, const void* src, const void* dy, int co
                     size_t slab_capacity_elems, int num_cu, int* nsplit_out, hipStream_t st);
 hipError_t wgrad_halo(const GatherDesc& g, const void* src, const void* dy, int co_rows, int ldy, float* slabs,
                       size_t slab_capacity_elems, int num_cu, int* nsplit_out, bool force, hipStream_t st);
+hipError_t wgrad_thin(const GatherDesc& g, const void* src, const void* dy, int co_rows, int ldy, float* slabs,
+                      size_t slab_capacity_elems, int num_cu, int* nsplit_out, hipStream_t st);
 hipError_t wgrad_reduce_unpack(float* slabs, int nsplit, long long slab_elems, float* dw, int Cout, int Cin, int CinS,
                                int taps, int accumulate, hipStream_t st);
 

@@ -76,6 +76,7 @@ CONV_CASES = [
 CONV_CASES += [
     # thin-input kernel (bf16, 8-channel source vectors, <= 64 outputs, >= 256 tiles of 8x32 pixels)
     (3, 64, 7, 1, 3, True, False, 128, 128, 4, False, "none"),          # generator stem
+    (3, 24, 7, 1, 3, True, False, 64, 64, 2, False, "none"),            # thin-input wgrad with a partial co block
     (3, 64, 4, 2, 1, True, False, 256, 128, 8, True, "leaky_relu"),     # discriminator's first conv: stride 2, bias, LReLU
     (64, 4, 3, 1, 1, True, False, 128, 128, 4, False, "none"),          # heads: the interior dgrad (dY has 8 channels)
     (64, 4, 3, 1, 1, True, False, 16, 32, 4, False, "none"),            # heads wgrad: 64 x 64 block, taps split over two wave groups (forced)
