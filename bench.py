@@ -216,14 +216,14 @@ def main():
         peak = PEAK_TFLOPS[args.dtype]
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         traffic, traffic_src = None, None
-        pmc = os.path.join(REPO, "profiles", "r01_e_pmc_traffic.json")    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        pmc = os.path.join(REPO, "profiles", "r01_f_pmc_traffic.json")    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
         if args.dtype == "bf16" and args.image_size == 256 and args.batch == 16 and os.path.exists(pmc):
             with open(pmc) as f:
                 t = json.load(f)
             fams = [t[k] for k in ("halo_conv", "gather_gemm_v2", "gather_gemm_v1", "thin_cin_conv", "thin_cout_conv") if k in t]
             nl = sum(x["launches"] for x in fams)
             traffic = sum(x["hbm_bytes_per_launch"] * x["launches"] for x in fams) / max(nl, 1)
-            traffic_src = ("profiles/r01_e_pmc_traffic.json (profiles/collect.sh + summarize.py): (2*FETCH_SIZE + WRITE_SIZE)"
+            traffic_src = ("profiles/r01_f_pmc_traffic.json (profiles/collect.sh + summarize.py): (2*FETCH_SIZE + WRITE_SIZE)"
                            "*1024 bytes per launch over the conv fwd/dgrad kernels, separate --pmc passes")
         line["roofline"] = {"bound": "mfma", "kernel": "conv forward + dgrad family: halo_conv_kernel, gather_gemm_v2_kernel, gather_gemm_kernel, thin_cin/thin_cout_conv_kernel",
                             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,

@@ -13,6 +13,7 @@ extern int g_v2_ablate;
 extern int g_use_wgrad_v2;
 extern int g_use_wgrad_halo;
 extern int g_use_wgrad_thin;
+extern int g_wt_splits_per_cu;
 extern int g_halo_mfma32;
 extern unsigned long long* g_v2_dbg;
 static int g_cus = 256;
@@ -82,6 +83,7 @@ int dei2i_set_option(const char* name, int value) {
   if (std::string(name) == "splitk_atomic") { set_splitk_atomic(value); return 0; }
   if (std::string(name) == "wgrad_halo") { g_use_wgrad_halo = value; return 0; }
   if (std::string(name) == "wgrad_thin") { g_use_wgrad_thin = value; return 0; }
+  if (std::string(name) == "wgrad_thin_splits") { g_wt_splits_per_cu = value; return 0; }
   if (std::string(name) == "v2_ablate") { g_v2_ablate = value; return 0; }     // timing-only builds: 1 = no loads, 2 = no MFMA
   return DEI2I_ERR_BAD_ARG;
 }

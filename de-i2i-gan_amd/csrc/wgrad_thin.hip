@@ -172,6 +172,7 @@ __global__ __launch_bounds__(512) void wgrad_thin_kernel(const GatherDesc g, con
   }
 }
 
+int g_wt_splits_per_cu = 0;      // A/B option "wgrad_thin_splits"
 // returns hipErrorNotSupported when the shape does not qualify (the caller falls through to the other wgrad kernels)
 hipError_t wgrad_thin(const GatherDesc& g, const void* src, const void* dy, int co_rows, int ldy, float* slabs,
                       size_t slab_capacity_elems, int num_cu, int* nsplit_out, hipStream_t st) {
@@ -181,7 +182,7 @@ hipError_t wgrad_thin(const GatherDesc& g, const void* src, const void* dy, int 
   if ((long long)g.N * g.Hs * g.Ws * g.Cs >= (1ll << 31)) return hipErrorNotSupported;
   const int ntiles = g.N * (g.Ho / WT_TH) * (g.Wo / WT_TW);
   if (ntiles < 64) return hipErrorNotSupported;
-  int splits = std::min(2 * num_cu, ntiles / 4);                // 44 KB of LDS per workgroup: two per CU
+  int splits = std::min((g_wt_splits_per_cu > 0 ? g_wt_splits_per_cu : 2) * num_cu, ntiles / 4);   // 44 KB of LDS per workgroup
   const long long slab_elems = wgrad_slab_elems(co_rows, g.K);
   if ((size_t)slab_elems * splits > slab_capacity_elems) splits = (int)(slab_capacity_elems / (size_t)slab_elems);
   if (splits < 1) return hipErrorNotSupported;
