@@ -201,7 +201,7 @@ def main():
     pairs = args.batch * world * args.steps
     ms_per_step = 1e3 * elapsed / args.steps
     line = {
-        "metric": "paired 256x256 images/sec (G+D train step)", "value": pairs / elapsed, "unit": "pairs/s",
+        "metric": f"paired {args.image_size}x{args.image_size} images/sec (G+D train step)", "value": pairs / elapsed, "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"defectGAN D+G train step, {args.image_size}x{args.image_size} paired RGB, "
