@@ -55,7 +55,7 @@ SIGNATURES = {
     "dei2i_cast_from_f32": (c_int, [c_int, c_size_t, _P, _P, _P]),
     "dei2i_moments_chunks": (c_int, [c_int]),
     "dei2i_moments_partial": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P]),
-    "dei2i_bn_finalize_train": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P]),
+    "dei2i_bn_finalize_train": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P]),
     "dei2i_bn_finalize_eval": (c_int, [c_int, _P, _P, _P, _P, c_float, _P, _P, _P]),
     "dei2i_in_finalize": (c_int, [c_int, c_int, c_int, _P, c_float, _P, _P, _P]),
     "dei2i_affine_act_fwd": (c_int, [c_int, c_size_t, c_int, _P, _P, _P, _P, c_int, _P, _P]),

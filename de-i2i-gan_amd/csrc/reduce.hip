@@ -116,8 +116,9 @@ __global__ __launch_bounds__(256) void bn_finalize_train_kernel(const float* __r
                                          const float* __restrict__ weight, const float* __restrict__ bias,
                                          float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
                                          float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ a,
-                                         float* __restrict__ b) {
+                                         float* __restrict__ b, long long* __restrict__ num_batches_tracked) {
   const int c = blockIdx.x;
+  if (c == 0 && threadIdx.x == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;   // nn.BatchNorm2d's counter
   double sq[2];
   combine_records<2>(partial, 0, N * chunks, C, c, sq);
   if (threadIdx.x != 0) return;
@@ -629,11 +630,11 @@ int dei2i_moments_partial(int dtype, int N, int HW, int C, const void* x, float*
 
 int dei2i_bn_finalize_train(int N, int HW, int C, const float* partial, const float* weight, const float* bias,
                             float* running_mean, float* running_var, float momentum, float eps, float* mean, float* rstd,
-                            float* a, float* b, dei2i_stream s) {
+                            float* a, float* b, long long* num_batches_tracked, dei2i_stream s) {
   if (N <= 0 || HW <= 0 || C <= 0 || !partial || !weight || !bias || !mean || !rstd || !a || !b) return DEI2I_ERR_BAD_ARG;
   hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(C), dim3(combine_threads(N * dei2i_moments_chunks(HW))), 0, (hipStream_t)s, partial, N,
                      dei2i_moments_chunks(HW), C, (double)N * (double)HW, weight, bias, running_mean, running_var, momentum,
-                     eps, mean, rstd, a, b);
+                     eps, mean, rstd, a, b, num_batches_tracked);
   return (int)hipGetLastError();
 }
 

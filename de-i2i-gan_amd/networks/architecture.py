@@ -79,10 +79,8 @@ class BatchNorm2d(nn.Module):
         nn.init.zeros_(self.bias)
 
     def forward(self, y, act="none", res=None):
-        if self.training:
-            self.num_batches_tracked += 1
         return ops.batchnorm_act(y, self.weight, self.bias, self.running_mean, self.running_var, self.training, act, res,
-                                 self.momentum, self.eps)
+                                 self.momentum, self.eps, self.num_batches_tracked)
 
     def extra_repr(self):
         return f"{self.num_features}, eps={self.eps}, momentum={self.momentum}"

@@ -243,7 +243,7 @@ class _Conv2d(torch.autograd.Function):
             rows = g.numel() // couts
             part = torch.empty(lib.dei2i_colsum_blocks(rows) * couts, dtype=torch.float32, device=x.device)
             L.check(lib.dei2i_colsum(prec.code, rows, couts, _p(g), _p(part), _p(dbf), st), "colsum")
-            db = dbf[:geom.cout].clone()
+            db = dbf if couts == geom.cout else dbf[:geom.cout].clone()
         return dx, dw, db, None, None, None, None
 
 
@@ -318,7 +318,8 @@ def to_nchw(x_nhwc, c: int):
 # --------------------------------------------------------------------------------------------------------------
 class _BatchNormAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, weight, bias, res, running_mean, running_var, training: bool, momentum: float, eps: float, act: int):
+    def forward(ctx, y, weight, bias, res, running_mean, running_var, training: bool, momentum: float, eps: float, act: int,
+                num_batches_tracked=None):
         _require_gpu(y, "batchnorm_act")
         prec = precision_of(y)
         y = y.contiguous()
@@ -336,7 +337,8 @@ class _BatchNormAct(torch.autograd.Function):
             rstd = torch.empty(c, dtype=torch.float32, device=dev)
             L.check(lib.dei2i_moments_partial(prec.code, n, h * w, c, _p(y), _p(partial), st), "moments_partial")
             L.check(lib.dei2i_bn_finalize_train(n, h * w, c, _p(partial), _p(w32), _p(b32), _p(running_mean), _p(running_var),
-                                                momentum, eps, _p(mean), _p(rstd), _p(a), _p(b), st), "bn_finalize_train")
+                                                momentum, eps, _p(mean), _p(rstd), _p(a), _p(b), _p(num_batches_tracked), st),
+                    "bn_finalize_train")
         else:
             L.check(lib.dei2i_bn_finalize_eval(c, _p(w32), _p(b32), _p(running_mean), _p(running_var), eps, _p(a), _p(b), st),
                     "bn_finalize_eval")
@@ -378,12 +380,14 @@ class _BatchNormAct(torch.autograd.Function):
         L.check(lib.dei2i_bn_bwd_apply(prec.code, pixels, c, _p(dout), _p(y), _p(a), _p(b), _p(mean), _p(rstd), ctx.act,
                                        1 if ctx.training else 0, _p(partial), chunks, c_void_p(dw_ptr), c_void_p(db_ptr),
                                        acc_ptrs[0], acc_ptrs[1], _p(dy), st), "bn_bwd_apply")
-        return dy, dweight, dbias, (dout if ctx.has_res else None), None, None, None, None, None, None
+        return dy, dweight, dbias, (dout if ctx.has_res else None), None, None, None, None, None, None, None
 
 
-def batchnorm_act(y, weight, bias, running_mean, running_var, training, act="none", res=None, momentum=0.1, eps=1e-5):
+def batchnorm_act(y, weight, bias, running_mean, running_var, training, act="none", res=None, momentum=0.1, eps=1e-5,
+                  num_batches_tracked=None):
+    """num_batches_tracked: the module's int64 counter, incremented inside the statistics kernel in training mode."""
     return _BatchNormAct.apply(y, weight, bias, res, running_mean, running_var, bool(training), float(momentum), float(eps),
-                               ACT[act])
+                               ACT[act], num_batches_tracked)
 
 
 def add(x, res):

@@ -108,9 +108,10 @@ int dei2i_moments_chunks(int HW);
 int dei2i_moments_partial(int dtype, int N, int HW, int C, const void* x, float* partial, dei2i_stream s);
 /* BatchNorm2d train: batch stats over (N,HW) -> scale/shift a[c], b[c]; mean/rstd saved for backward; running
  * stats updated (momentum 0.1, unbiased var).  All vectors fp32[C]. */
+/* num_batches_tracked (int64 device scalar, may be NULL) is incremented by the same launch */
 int dei2i_bn_finalize_train(int N, int HW, int C, const float* partial, const float* weight, const float* bias,
                             float* running_mean, float* running_var, float momentum, float eps, float* mean,
-                            float* rstd, float* a, float* b, dei2i_stream s);
+                            float* rstd, float* a, float* b, long long* num_batches_tracked, dei2i_stream s);
 int dei2i_bn_finalize_eval(int C, const float* weight, const float* bias, const float* running_mean,
                            const float* running_var, float eps, float* a, float* b, dei2i_stream s);
 /* InstanceNorm2d(affine=False): per (n,c) mean / rstd, fp32 [N][C] */

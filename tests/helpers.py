@@ -58,8 +58,8 @@ class record_kinks:
         def conv(a, out):                # (x, weight, bias, cache, sources, geom, act); the SPADE label-path ReLU is exact
             return (kind_of[a[6]], out, "conv") if a[6] == L.ACT_LRELU else None
 
-        def bn(a, out):                  # (..., act)
-            return (kind_of[a[-1]], out) if a[-1] != L.ACT_NONE else None
+        def bn(a, out):                  # (y, weight, bias, res, running_mean, running_var, training, momentum, eps, act, counter)
+            return (kind_of[a[9]], out) if a[9] != L.ACT_NONE else None
 
         def spade(a, out):
             return ("relu", out)
