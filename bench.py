@@ -21,7 +21,9 @@ import time
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}      # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "fp8": 2500.0}      # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+# (fp8 mode: priced at the bf16 peak -- its e4m3 GEMMs use the non-scaled v_mfma_f32_16x16x32_fp8_fp8, which runs at the
+#  bf16 rate, and most of the step still runs bf16 kernels)
 
 
 def parse():
@@ -31,7 +33,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--image-size", type=int, default=256)
     ap.add_argument("--batch", type=int, default=16, help="pairs per GPU")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"],
+                    help="fp8: e4m3 forward GEMMs of the stride-1 3x3 convs, bf16 everywhere else (BASELINE.json configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=INT",
@@ -203,7 +206,8 @@ def main():
     line = {
         "metric": f"paired {args.image_size}x{args.image_size} images/sec (G+D train step)", "value": pairs / elapsed, "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype if args.dtype != "fp8" else "fp8-e4m3 forward GEMMs of the 3x3 convs + bf16", "data": "synthetic",
         "config": {"workload": f"defectGAN D+G train step, {args.image_size}x{args.image_size} paired RGB, "
                                f"batch {args.batch}/GPU, ngf=ndf=64 num_res=6 num_layers={opt.num_layers} SPADE, Adam(0.5,0.999)",
                    "global_batch": args.batch * world, "parallelism": f"dp{world}",

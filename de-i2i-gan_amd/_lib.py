@@ -47,6 +47,10 @@ SIGNATURES = {
     "dei2i_conv2d_dgrad": (c_int, [_CD, _P, _P, _P, _P, c_size_t, _P]),
     "dei2i_conv2d_dgrad_input": (c_int, [_CD, _P, _P, _P, _P, _P, c_size_t, _P]),
     "dei2i_conv2d_wgrad": (c_int, [_CD, _P, _P, _P, _P]),
+    "dei2i_quantize_fp8": (c_int, [c_size_t, _P, c_float, _P, _P]),
+    "dei2i_pack_weight_fwd_fp8": (c_int, [_CD, _P, _P, c_float, _P, _P, _P]),
+    "dei2i_conv2d_fp8_supported": (c_int, [_CD]),
+    "dei2i_conv2d_fwd_fp8": (c_int, [_CD, _P, _P, _P, _P, c_int, _P, _P]),
     "dei2i_conv2d_wgrad_oihw": (c_int, [_CD, _P, _P, _P, c_size_t, _P, c_int, _P]),
     "dei2i_fold_pad": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "dei2i_nchw_to_nhwc": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),

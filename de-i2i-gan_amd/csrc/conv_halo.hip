@@ -50,12 +50,18 @@ constexpr int HALO_HL = 6;                            // halo LDS-DMA instructio
 
 template <int N> DEI2I_D void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BN, int STAGES, bool DIAG, bool M16>
+// FP8: the operands are e4m3 bytes and the descriptor / pointers describe them as PAIRS (a "bf16" tensor with half the
+// channels), so every address, LDS image and DMA pattern is unchanged; a 16-byte fragment then holds 16 k-values and
+// feeds two v_mfma_f32_16x16x32_fp8_fp8 (low / high 8 bytes -- the same k permutation for both operands), and the
+// epilogue multiplies by *dequant = 1 / (activation scale * weight scale).  Half the LDS and DMA bytes per FLOP.
+template <int BN, int STAGES, bool DIAG, bool M16, bool FP8 = false>
 __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, const bf16_t* __restrict__ src,
                                                         const bf16_t* __restrict__ wgt, const int wrows,
                                                         const float* __restrict__ bias, bf16_t* __restrict__ out,
                                                         const int ldc, const int act, const int tiles_n, const int ablate,
-                                                        unsigned long long* __restrict__ dbg) {
+                                                        unsigned long long* __restrict__ dbg,
+                                                        const float* __restrict__ dequant) {
+  static_assert(!FP8 || M16, "the fp8 variant uses the 16x16x32 shape");
   constexpr int BM = HALO_TH * HALO_TW;             // 256 output pixels
   constexpr int WN = 2, WTN = BN / WN, TM = 2, TN = WTN / 32;
   constexpr int LB = BN / 64;                       // weight LDS-DMA instructions per wave per stage
@@ -219,7 +225,13 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, cons
     for (int i = 0; i < PB; ++i)
 #pragma unroll
       for (int j = 0; j < CB; ++j) {
-        if constexpr (M16)
+        if constexpr (FP8) {
+          const u32x4 bq = f.b[ks][j], aq = f.a[ks][i];
+          const long b0 = (long)(((unsigned long long)bq.y << 32) | bq.x), b1 = (long)(((unsigned long long)bq.w << 32) | bq.z);
+          const long a0 = (long)(((unsigned long long)aq.y << 32) | aq.x), a1 = (long)(((unsigned long long)aq.w << 32) | aq.z);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(b0, a0, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(b1, a1, acc[i][j], 0, 0, 0);
+        } else if constexpr (M16)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.b[ks][j]),
                                                                __builtin_bit_cast(bf16x8, f.a[ks][i]), acc[i][j], 0, 0, 0);
         else
@@ -346,6 +358,7 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, cons
   // all three), padded output channels (n >= wrows) cleared with a bit mask on the packed pair.  The unrolled
   // per-element `act` switch this replaces was 60 % of the kernel's code, and a dispatch walks its code cold.
   const float slope = act_slope(act);
+  const float dq = FP8 ? dequant[0] : 1.f;
   if constexpr (M16) {
     // D row = channel 4*kg + e of its 16-block, col = pixel l16
 #pragma unroll
@@ -358,7 +371,7 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, cons
       for (int i = 0; i < PB; ++i) {
         const int row = (wm * TM + (i >> 1)) * 32 + (i & 1) * 16 + l16;
         *reinterpret_cast<u32x2*>(ctile + row * CROW + col0 * 2) =
-            epi_finish4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3], bq, slope, m01, m23);
+            epi_finish4(acc[i][j][0] * dq, acc[i][j][1] * dq, acc[i][j][2] * dq, acc[i][j][3] * dq, bq, slope, m01, m23);
       }
     }
   } else {
@@ -399,27 +412,29 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, cons
 
 template <int BN, int STAGES>
 static hipError_t launch_halo(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out,
-                              int ldc, int act, hipStream_t st) {
+                              int ldc, int act, const float* dequant, hipStream_t st) {
   const int tiles_m = g.N * (g.Ho / HALO_TH) * (g.Wo / HALO_TW);
   const int tiles_n = (ldc + BN - 1) / BN;
   const size_t lds = 2 * (size_t)HALO_BYTES + (size_t)STAGES * BN * 128 + HALO_GROUPS * 8 * sizeof(int);
   auto kern = halo_conv_kernel<BN, STAGES, false, true>;
   if (g_halo_mfma32) kern = halo_conv_kernel<BN, STAGES, false, false>;     // A/B option: 32x32x16 MFMAs
   if (g_v2_ablate == 6) kern = halo_conv_kernel<BN, STAGES, true, true>;   // diagnostic build: per-phase cycle stamps
+  if (dequant != nullptr) kern = halo_conv_kernel<BN, STAGES, false, true, true>;   // e4m3 operands
   {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
   prof_begin(PROF_GATHER_GEMM, 2.0 * (double)g.M * (double)(g.th * g.tw) * (double)g.Clog * (double)wrows, st);
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, st, g, (const bf16_t*)src, (const bf16_t*)wgt, wrows, bias,
-                     (bf16_t*)out, ldc, act, tiles_n, g_v2_ablate == 6 ? 5 : g_v2_ablate, g_v2_dbg);
+                     (bf16_t*)out, ldc, act, tiles_n, g_v2_ablate == 6 ? 5 : g_v2_ablate, g_v2_dbg, dequant);
   prof_end(PROF_GATHER_GEMM, st);
   return hipGetLastError();
 }
 
 // returns hipErrorNotSupported when the shape does not qualify (the caller falls through to the gather GEMMs)
+// dequant != nullptr selects the fp8 variant (g describes the e4m3 operands as byte pairs: see the kernel)
 hipError_t halo_conv(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out, int ldc,
-                     int act, int num_cu, hipStream_t st) {
+                     int act, int num_cu, hipStream_t st, const float* dequant) {
   if (g.sh != 1 || g.sw != 1 || (g.ys != 1 && g.ys != -1) || (g.xs != 1 && g.xs != -1)) return hipErrorNotSupported;
   if (g.th != 3 || g.tw != 3 || g.wK != g.K || g.wtw != g.tw) return hipErrorNotSupported;       // tap count >= ring depth + 1 (halo issue at tap 1)
   if (g.Cs % 64 != 0 || g.Ho % HALO_TH != 0 || g.Wo % HALO_TW != 0 || g.M != g.N * g.Ho * g.Wo) return hipErrorNotSupported;
@@ -428,10 +443,10 @@ hipError_t halo_conv(const GatherDesc& g, const void* src, const void* wgt, int 
   const int tiles_m = g.N * (g.Ho / HALO_TH) * (g.Wo / HALO_TW);
   if (ldc >= 128) {
     if (tiles_m * ((ldc + 127) / 128) < num_cu / 2) return hipErrorNotSupported;   // small grids: split-K v1 fills the chip better
-    return launch_halo<128, 4>(g, src, wgt, wrows, bias, out, ldc, act, st);
+    return launch_halo<128, 4>(g, src, wgt, wrows, bias, out, ldc, act, dequant, st);
   }
   if (tiles_m < num_cu / 2) return hipErrorNotSupported;
-  return launch_halo<64, 4>(g, src, wgt, wrows, bias, out, ldc, act, st);
+  return launch_halo<64, 4>(g, src, wgt, wrows, bias, out, ldc, act, dequant, st);
 }
 
 }  // namespace dei2i

@@ -37,7 +37,7 @@ hipError_t thin_cout_conv(const GatherDesc& g, const void* src, const void* wgt,
 hipError_t thin_cin_conv(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out, int ldc,
                          int act, int num_cu, hipStream_t st);
 hipError_t halo_conv(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out, int ldc,
-                     int act, int num_cu, hipStream_t st);
+                     int act, int num_cu, hipStream_t st, const float* dequant = nullptr);
 
 hipError_t gather_gemm(int dtype, const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias,
                        void* out, float* ws, size_t ws_bytes, int ldc, int act, hipStream_t st);

@@ -24,6 +24,7 @@ class DefectGanGenerator(BaseNetwork):
         if opt.cycle_gan:
             raise NotImplementedError("cycle_gan output mode is not implemented yet")
         self.prec = ops.get_precision(getattr(opt, "compute_dtype", "bf16"))
+        self.fp8 = ops.wants_fp8(getattr(opt, "compute_dtype", "bf16"))     # e4m3 forward GEMMs of the 3x3 convs
 
         crt_dim = opt.ngf
         self.stem = ConvBlock(opt.input_nc, crt_dim, kernel_size=(7, 7), padding="same", padding_mode="reflect",
@@ -61,6 +62,10 @@ class DefectGanGenerator(BaseNetwork):
         self._packed_heads = ops.PackedWeights()
 
     def forward(self, x, labels, style_feat=None):
+        with ops.fp8_forward(self.fp8):
+            return self._forward(x, labels, style_feat)
+
+    def _forward(self, x, labels, style_feat=None):
         assert isinstance(x, torch.Tensor), "x must be Original Images: Torch.Tensor"
         if labels.dim() == 2:
             labels = labels.reshape(labels.size(0), labels.size(1), 1, 1)

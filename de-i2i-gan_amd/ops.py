@@ -33,10 +33,39 @@ BF16 = Precision("bf16", L.BF16, torch.bfloat16, 8)
 F32 = Precision("f32", L.F32, torch.float32, 4)
 
 
+# ---- fp8 forward mode (BASELINE.json configs[4]) ----------------------------------------------------------------
+# compute_dtype "fp8": tensors, backward and every other kernel are those of the bf16 mode; inside an fp8_forward(True)
+# scope the FORWARD GEMM of the stride-1 3x3 convolutions the fp8 kernel takes runs on e4m3 operands (activations
+# quantised with the fixed scale FP8_ACT_SCALE -- they follow a normalisation layer, |x| = O(1) -- weights with
+# 448 / amax|w| computed on the device).  Layers the fp8 kernel does not take run in bf16 as usual (that is the bf16
+# product path, not a fallback of a failed fp8 call: eligibility is asked first).
+FP8_ACT_SCALE = 16.0
+_fp8_forward = False
+
+
+class fp8_forward:
+    def __init__(self, on: bool):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global _fp8_forward
+        self.prev, _fp8_forward = _fp8_forward, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global _fp8_forward
+        _fp8_forward = self.prev
+        return False
+
+
+def wants_fp8(name) -> bool:
+    return name in ("fp8", "fp8_e4m3", "e4m3")
+
+
 def get_precision(name) -> Precision:
     if isinstance(name, Precision):
         return name
-    if name in (None, "bf16", "bfloat16"):
+    if name in (None, "bf16", "bfloat16") or wants_fp8(name):
         return BF16
     if name in ("f32", "fp32", "float32"):
         return F32
@@ -155,27 +184,49 @@ class PackedWeights:
         self._key = None
         self.fwd = None
         self.dgrad = None
+        self.fp8 = None            # (packed e4m3 forward weights, dequant scalar) of the fp8 forward mode
 
     @staticmethod
     def _stamp(t: torch.Tensor):
         return (t.data_ptr(), t._version, getattr(t, "_dei2i_epoch", 0))
 
-    def get(self, weight: torch.Tensor, sources, prec: Precision, geom: ConvGeom, cins: int, couts: int, need_dgrad: bool):
+    def get(self, weight: torch.Tensor, sources, prec: Precision, geom: ConvGeom, cins: int, couts: int, need_dgrad: bool,
+            need_fwd: bool = True):
         key = (tuple(self._stamp(s) for s in sources), prec.code, cins, couts)
         lib = _lib_for(weight)
         if key != self._key:
-            self._key, self.fwd, self.dgrad = key, None, None
+            self._key, self.fwd, self.dgrad, self.fp8 = key, None, None, None
         d = _desc(prec, geom, 1, max(geom.k, 4), max(geom.k, 4), cins, couts)
         w = weight.detach()
         if w.dtype != torch.float32 or not w.is_contiguous():
             w = w.float().contiguous()
-        if self.fwd is None:
+        if need_fwd and self.fwd is None:
             self.fwd = torch.empty(lib.dei2i_packed_fwd_elems(byref(d)), dtype=prec.dtype, device=weight.device)
             L.check(lib.dei2i_pack_weight_fwd(byref(d), _p(w), _p(self.fwd), _stream()), "pack_weight_fwd")
         if need_dgrad and self.dgrad is None:
             self.dgrad = torch.empty(lib.dei2i_packed_dgrad_elems(byref(d)), dtype=prec.dtype, device=weight.device)
             L.check(lib.dei2i_pack_weight_dgrad(byref(d), _p(w), _p(self.dgrad), _stream()), "pack_weight_dgrad")
         return self.fwd, self.dgrad
+
+    def get_fp8(self, weight: torch.Tensor, sources, prec: Precision, geom: ConvGeom, cins: int, couts: int):
+        """e4m3 forward weights (per-tensor scale 448 / amax|w|, computed on the device) and the dequant scalar
+        1 / (activation scale * weight scale); cached with the same stamps as the bf16 copies."""
+        key = (tuple(self._stamp(s) for s in sources), prec.code, cins, couts)
+        if key != self._key:
+            self._key, self.fwd, self.dgrad, self.fp8 = key, None, None, None
+        if self.fp8 is None:
+            lib = _lib_for(weight)
+            d = _desc(prec, geom, 1, 8, 32, cins, couts)
+            w = weight.detach()
+            if w.dtype != torch.float32 or not w.is_contiguous():
+                w = w.float().contiguous()
+            amax = torch.linalg.vector_norm(w, ord=float("inf")).reshape(1)
+            wq = torch.empty(geom.cout * geom.k * geom.k * cins, dtype=torch.uint8, device=weight.device)
+            dequant = torch.empty(1, dtype=torch.float32, device=weight.device)
+            L.check(lib.dei2i_pack_weight_fwd_fp8(byref(d), _p(w), _p(amax), FP8_ACT_SCALE, _p(wq), _p(dequant), _stream()),
+                    "pack_weight_fwd_fp8")
+            self.fp8 = (wq, dequant)
+        return self.fp8
 
 
 class _Conv2d(torch.autograd.Function):
@@ -188,7 +239,8 @@ class _Conv2d(torch.autograd.Function):
         couts = prec.pad(geom.cout)
         lib = _lib_for(x)
         d = _desc(prec, geom, n, h, w, cins, couts)
-        wf, _ = cache.get(weight, sources, prec, geom, cins, couts, need_dgrad=False)
+        use_fp8 = bool(_fp8_forward and prec is BF16 and lib.dei2i_conv2d_fp8_supported(byref(d)))
+        wf = None if use_fp8 else cache.get(weight, sources, prec, geom, cins, couts, need_dgrad=False)[0]
         ho, wo = c_int(), c_int()
         lib.dei2i_conv2d_out_shape(byref(d), byref(ho), byref(wo))
         y = torch.empty((n, ho.value, wo.value, couts), dtype=prec.dtype, device=x.device)
@@ -197,8 +249,15 @@ class _Conv2d(torch.autograd.Function):
         b32 = None
         if bias is not None:
             b32 = bias.detach().float().contiguous()
-        L.check(lib.dei2i_conv2d_fwd(byref(d), _p(x), _p(wf), _p(b32), act, _p(y), _p(ws), ws.numel() * 4, _stream()),
-                "conv2d_fwd")
+        if use_fp8:
+            wq, dequant = cache.get_fp8(weight, sources, prec, geom, cins, couts)
+            xq = _workspace(x.device, x.numel(), slot="fp8_act")
+            L.check(lib.dei2i_quantize_fp8(x.numel(), _p(x), FP8_ACT_SCALE, _p(xq), _stream()), "quantize_fp8")
+            L.check(lib.dei2i_conv2d_fwd_fp8(byref(d), _p(xq), _p(wq), _p(b32), _p(dequant), act, _p(y), _stream()),
+                    "conv2d_fwd_fp8")
+        else:
+            L.check(lib.dei2i_conv2d_fwd(byref(d), _p(x), _p(wf), _p(b32), act, _p(y), _p(ws), ws.numel() * 4, _stream()),
+                    "conv2d_fwd")
         ctx.geom, ctx.act, ctx.cache, ctx.sources, ctx.prec = geom, act, cache, sources, prec
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, weight, y if act != L.ACT_NONE else None)
@@ -221,7 +280,7 @@ class _Conv2d(torch.autograd.Function):
             g = dy
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            _, wd = ctx.cache.get(weight, ctx.sources, prec, geom, cins, couts, need_dgrad=True)
+            _, wd = ctx.cache.get(weight, ctx.sources, prec, geom, cins, couts, need_dgrad=True, need_fwd=False)
             ws = _workspace(x.device, lib.dei2i_conv2d_workspace_bytes(byref(d)))
             dx = torch.empty_like(x)
             ext = None

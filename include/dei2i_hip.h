@@ -87,6 +87,19 @@ int dei2i_conv2d_wgrad(const dei2i_conv* c, const void* x, const void* dy, float
 /* accumulate != 0: dw_oihw += (a further use of the same weight in one backward pass adds into its gradient in place) */
 int dei2i_conv2d_wgrad_oihw(const dei2i_conv* c, const void* x, const void* dy, float* scratch, size_t scratch_elems,
                             float* dw_oihw, int accumulate, dei2i_stream s);
+/* ---- fp8 (OCP e4m3) forward of the stride-1 3x3 convolutions (BASELINE.json configs[4]) ----
+ * c describes the convolution as usual (dtype = DEI2I_BF16: y, bias and the backward path are bf16 / fp32); x and the
+ * packed weights are e4m3 bytes with the same NHWC / [Cout][9][CinS] layouts (CinS % 128 == 0).  fp32 accumulation;
+ * y = act(dequant[0] * sum(xq * wq) + bias).  No fallback: unsupported shapes return an error, ask _supported first. */
+int dei2i_conv2d_fp8_supported(const dei2i_conv* c);                       /* 1 / 0 */
+/* out[i] = e4m3(clamp(x[i] * scale, +-448)); n % 8 == 0 */
+int dei2i_quantize_fp8(size_t n, const void* x_bf16, float scale, void* out_e4m3, dei2i_stream s);
+/* packed forward weights in e4m3: w_oihw * (448 / amax[0]) (amax: device scalar max|w|); also writes the conv's
+ * dequant[0] = 1 / (act_scale * 448 / amax[0]), act_scale being the scale the activations are quantised with */
+int dei2i_pack_weight_fwd_fp8(const dei2i_conv* c, const float* w_oihw, const float* amax, float act_scale, void* packed_e4m3,
+                              float* dequant, dei2i_stream s);
+int dei2i_conv2d_fwd_fp8(const dei2i_conv* c, const void* x_e4m3, const void* w_e4m3, const float* bias, const float* dequant,
+                         int act, void* y_bf16, dei2i_stream s);
 /* reflection_pad2d_backward + upsample_nearest2d_backward: fold the dgrad output (N,OH,OW,C) back onto the
  * physical input (N,H,W,C); optional addend (residual-branch gradient) is summed in the same pass. */
 int dei2i_fold_pad(int dtype, int N, int H, int W, int C, int pad, int pad_mode, int up, const void* dx_ext,
