@@ -62,8 +62,8 @@ SIGNATURES = {
     "dei2i_bn_finalize_train": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P]),
     "dei2i_bn_finalize_eval": (c_int, [c_int, _P, _P, _P, _P, c_float, _P, _P, _P]),
     "dei2i_in_finalize": (c_int, [c_int, c_int, c_int, _P, c_float, _P, _P, _P]),
-    "dei2i_affine_act_fwd": (c_int, [c_int, c_size_t, c_int, _P, _P, _P, _P, c_int, _P, _P]),
-    "dei2i_spade_act_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P]),
+    "dei2i_affine_act_fwd": (c_int, [c_int, c_size_t, c_int, _P, _P, _P, _P, c_int, _P, _P, c_float, _P]),
+    "dei2i_spade_act_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P, c_float, _P]),
     "dei2i_act_bwd": (c_int, [c_int, c_size_t, _P, _P, c_int, _P, _P]),
     "dei2i_colsum_blocks": (c_int, [c_size_t]),
     "dei2i_colsum": (c_int, [c_int, c_size_t, c_int, _P, _P, _P, _P]),

@@ -99,6 +99,29 @@ DEI2I_D float apply_act(float v, int act) {
   if (act == ACT_LRELU) return v >= 0.f ? v : 0.2f * v;
   return v;
 }
+// ---- fp8 (OCP e4m3fn) quantisation of 8 values: clamp to the finite range (+-448), round to nearest even ----
+DEI2I_D float clamp_e4m3(float v) { return fminf(fmaxf(v, -448.f), 448.f); }
+DEI2I_D u32x2 pack_e4m3_8(const float (&f)[8], float scale) {
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3(f[0] * scale), clamp_e4m3(f[1] * scale), lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3(f[2] * scale), clamp_e4m3(f[3] * scale), lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3(f[4] * scale), clamp_e4m3(f[5] * scale), hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3(f[6] * scale), clamp_e4m3(f[7] * scale), hi, true);
+  u32x2 o;
+  o.x = (uint32_t)lo; o.y = (uint32_t)hi;
+  return o;
+}
+// the e4m3 copy of a just-packed bf16 vector (quantises the ROUNDED bf16 values, so a fused producer and the standalone
+// quantiser give the same bytes)
+DEI2I_D void store_e4m3_of_bf16x8(unsigned char* __restrict__ dst, const u32x4& packed_bf16, float scale) {
+  float r[8];
+  r[0] = __uint_as_float(packed_bf16.x << 16); r[1] = __uint_as_float(packed_bf16.x & 0xffff0000u);
+  r[2] = __uint_as_float(packed_bf16.y << 16); r[3] = __uint_as_float(packed_bf16.y & 0xffff0000u);
+  r[4] = __uint_as_float(packed_bf16.z << 16); r[5] = __uint_as_float(packed_bf16.z & 0xffff0000u);
+  r[6] = __uint_as_float(packed_bf16.w << 16); r[7] = __uint_as_float(packed_bf16.w & 0xffff0000u);
+  *reinterpret_cast<u32x2*>(dst) = pack_e4m3_8(r, scale);
+}
+
 // Branch-free epilogue helpers of the MFMA kernels (the unrolled per-element `act` switch was most of their code, and
 // a dispatch walks its code cold).  act(v) = max(v,0) + slope*min(v,0) with slope 0 / 0.2 / 1 for ReLU / LeakyReLU /
 // none -- exact for all three.

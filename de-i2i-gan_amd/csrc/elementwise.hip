@@ -52,7 +52,8 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict
 // iteration and its coefficients live in registers (INVARIANT); otherwise they are re-read per iteration.
 template <typename T, bool INVARIANT>
 __global__ void affine_act_kernel(const T* __restrict__ x, const float* __restrict__ a, const float* __restrict__ b,
-                                  const T* __restrict__ res, T* __restrict__ out, size_t nvec, int cv, int act) {
+                                  const T* __restrict__ res, T* __restrict__ out, size_t nvec, int cv, int act,
+                                  unsigned char* __restrict__ out8, float scale8) {
   constexpr int VEC = Elem<T>::VEC;
   float av[VEC], bv[VEC];
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -76,7 +77,11 @@ __global__ void affine_act_kernel(const T* __restrict__ x, const float* __restri
       if (res != nullptr) v += r[e];
       f[e] = v;
     }
-    *reinterpret_cast<u32x4*>(out + i * VEC) = Elem<T>::pack(f);
+    const u32x4 pk = Elem<T>::pack(f);
+    *reinterpret_cast<u32x4*>(out + i * VEC) = pk;
+    if constexpr (sizeof(T) == 2) {              // fp8 forward mode: the e4m3 copy the next convolution reads
+      if (out8 != nullptr) store_e4m3_of_bf16x8(out8 + i * 8, pk, scale8);
+    }
   }
 }
 
@@ -86,7 +91,7 @@ DEI2I_D int border_class(int i, int extent) { return i < 2 ? i : (i >= extent - 
 template <typename T>
 __global__ void spade_act_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                                  const T* __restrict__ gb, T* __restrict__ out, int N, int H, int W, int C, int up,
-                                 int gb_mode) {
+                                 int gb_mode, unsigned char* __restrict__ out8, float scale8) {
   constexpr int VEC = Elem<T>::VEC;
   const int cv = C / VEC;
   const int Hs = H >> up, Ws = W >> up;
@@ -113,7 +118,11 @@ __global__ void spade_act_kernel(const T* __restrict__ x, const float* __restric
       const float v = fmaf(xh, 1.f + gm[e], bt[e]);
       o[e] = v > 0.f ? v : 0.f;
     }
-    *reinterpret_cast<u32x4*>(out + i * VEC) = Elem<T>::pack(o);
+    const u32x4 pk = Elem<T>::pack(o);
+    *reinterpret_cast<u32x4*>(out + i * VEC) = pk;
+    if constexpr (sizeof(T) == 2) {
+      if (out8 != nullptr) store_e4m3_of_bf16x8(out8 + i * 8, pk, scale8);
+    }
   }
 }
 
@@ -261,38 +270,42 @@ int dei2i_nhwc_to_nchw(int dtype, int N, int C, int H, int W, int Cs, const void
 }
 
 int dei2i_affine_act_fwd(int dtype, size_t pixels, int C, const void* x, const float* a, const float* b, const void* res,
-                         int act, void* out, dei2i_stream s) {
+                         int act, void* out, void* out_e4m3, float e4m3_scale, dei2i_stream s) {
   const int vec = vec_of(dtype);
   if (pixels == 0 || C <= 0 || C % vec || !x || !a || !b || !out) return DEI2I_ERR_BAD_ARG;
+  if (out_e4m3 != nullptr && (dtype != DT_BF16 || !(e4m3_scale > 0.f))) return DEI2I_ERR_BAD_ARG;
+  unsigned char* o8 = (unsigned char*)out_e4m3;
   const size_t nvec = pixels * (size_t)(C / vec);
   const int cv = C / vec;
   const bool inv = (256 % cv) == 0;
   const unsigned grid = grid_for(nvec, 256, EW_CAP);
   hipStream_t st = (hipStream_t)s;
   if (dtype == DT_BF16) {
-    if (inv) hipLaunchKernelGGL((affine_act_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, a, b, (const bf16_t*)res, (bf16_t*)out, nvec, cv, act);
-    else hipLaunchKernelGGL((affine_act_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, a, b, (const bf16_t*)res, (bf16_t*)out, nvec, cv, act);
+    if (inv) hipLaunchKernelGGL((affine_act_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, a, b, (const bf16_t*)res, (bf16_t*)out, nvec, cv, act, o8, e4m3_scale);
+    else hipLaunchKernelGGL((affine_act_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, a, b, (const bf16_t*)res, (bf16_t*)out, nvec, cv, act, o8, e4m3_scale);
   } else {
-    if (inv) hipLaunchKernelGGL((affine_act_kernel<float, true>), dim3(grid), dim3(256), 0, st, (const float*)x, a, b, (const float*)res, (float*)out, nvec, cv, act);
-    else hipLaunchKernelGGL((affine_act_kernel<float, false>), dim3(grid), dim3(256), 0, st, (const float*)x, a, b, (const float*)res, (float*)out, nvec, cv, act);
+    if (inv) hipLaunchKernelGGL((affine_act_kernel<float, true>), dim3(grid), dim3(256), 0, st, (const float*)x, a, b, (const float*)res, (float*)out, nvec, cv, act, o8, e4m3_scale);
+    else hipLaunchKernelGGL((affine_act_kernel<float, false>), dim3(grid), dim3(256), 0, st, (const float*)x, a, b, (const float*)res, (float*)out, nvec, cv, act, o8, e4m3_scale);
   }
   return (int)hipGetLastError();
 }
 
 int dei2i_spade_act_fwd(int dtype, int N, int H, int W, int C, int up, const void* x, const float* mean, const float* rstd,
-                        const void* gb, int gb_mode, void* out, dei2i_stream s) {
+                        const void* gb, int gb_mode, void* out, void* out_e4m3, float e4m3_scale, dei2i_stream s) {
   const int vec = vec_of(dtype);
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % vec || up < 0 || up > 1 || !x || !mean || !rstd || !gb || !out)
     return DEI2I_ERR_BAD_ARG;
+  if (out_e4m3 != nullptr && (dtype != DT_BF16 || !(e4m3_scale > 0.f))) return DEI2I_ERR_BAD_ARG;
+  unsigned char* o8 = (unsigned char*)out_e4m3;
   if (up && ((H | W) & 1)) return DEI2I_ERR_BAD_ARG;
   if (gb_mode == 1 && (H < 4 || W < 4)) return DEI2I_ERR_BAD_ARG;
   const size_t total = (size_t)N * H * W * (C / vec);
   if (dtype == DT_BF16)
     hipLaunchKernelGGL(spade_act_kernel<bf16_t>, dim3(grid_for(total, 256, EW_CAP)), dim3(256), 0, (hipStream_t)s,
-                       (const bf16_t*)x, mean, rstd, (const bf16_t*)gb, (bf16_t*)out, N, H, W, C, up, gb_mode);
+                       (const bf16_t*)x, mean, rstd, (const bf16_t*)gb, (bf16_t*)out, N, H, W, C, up, gb_mode, o8, e4m3_scale);
   else
     hipLaunchKernelGGL(spade_act_kernel<float>, dim3(grid_for(total, 256, EW_CAP)), dim3(256), 0, (hipStream_t)s,
-                       (const float*)x, mean, rstd, (const float*)gb, (float*)out, N, H, W, C, up, gb_mode);
+                       (const float*)x, mean, rstd, (const float*)gb, (float*)out, N, H, W, C, up, gb_mode, o8, e4m3_scale);
   return (int)hipGetLastError();
 }
 

@@ -16,21 +16,10 @@
 
 namespace dei2i {
 
-DEI2I_D float clamp_e4m3(float v) { return fminf(fmaxf(v, -448.f), 448.f); }   // e4m3fn: finite max 448, no infinities
-
 // 8 bf16 -> 8 e4m3 per thread (16 bytes in, 8 bytes out)
 __global__ void quantize_fp8_kernel(const bf16_t* __restrict__ x, const float scale, unsigned char* __restrict__ out, size_t nvec) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
-    float f[8];
-    Elem<bf16_t>::unpack(*reinterpret_cast<const u32x4*>(x + i * 8), f);
-    int lo = 0, hi = 0;
-    lo = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3(f[0] * scale), clamp_e4m3(f[1] * scale), lo, false);
-    lo = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3(f[2] * scale), clamp_e4m3(f[3] * scale), lo, true);
-    hi = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3(f[4] * scale), clamp_e4m3(f[5] * scale), hi, false);
-    hi = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3(f[6] * scale), clamp_e4m3(f[7] * scale), hi, true);
-    u32x2 o;
-    o.x = (uint32_t)lo; o.y = (uint32_t)hi;
-    *reinterpret_cast<u32x2*>(out + i * 8) = o;
+    store_e4m3_of_bf16x8(out + i * 8, *reinterpret_cast<const u32x4*>(x + i * 8), scale);
   }
 }
 

@@ -58,6 +58,19 @@ class fp8_forward:
         return False
 
 
+_fp8_stash = []          # e4m3 copy produced by the last normalisation kernel, handed to its output tensor by the wrapper
+
+
+def _fp8_copy_wanted(prec, c: int) -> bool:
+    return _fp8_forward and prec is BF16 and c % 128 == 0
+
+
+def _attach_fp8(out):
+    if _fp8_stash:
+        out._dei2i_fp8 = _fp8_stash.pop()
+    return out
+
+
 def wants_fp8(name) -> bool:
     return name in ("fp8", "fp8_e4m3", "e4m3")
 
@@ -251,8 +264,12 @@ class _Conv2d(torch.autograd.Function):
             b32 = bias.detach().float().contiguous()
         if use_fp8:
             wq, dequant = cache.get_fp8(weight, sources, prec, geom, cins, couts)
-            xq = _workspace(x.device, x.numel(), slot="fp8_act")
-            L.check(lib.dei2i_quantize_fp8(x.numel(), _p(x), FP8_ACT_SCALE, _p(xq), _stream()), "quantize_fp8")
+            xq = getattr(x, "_dei2i_fp8", None)      # written by the producing normalisation kernel in the same pass
+            if xq is not None and xq.numel() == x.numel():
+                del x._dei2i_fp8                     # one consumer: release the copy after this launch
+            else:
+                xq = _workspace(x.device, x.numel(), slot="fp8_act")
+                L.check(lib.dei2i_quantize_fp8(x.numel(), _p(x), FP8_ACT_SCALE, _p(xq), _stream()), "quantize_fp8")
             L.check(lib.dei2i_conv2d_fwd_fp8(byref(d), _p(xq), _p(wq), _p(b32), _p(dequant), act, _p(y), _stream()),
                     "conv2d_fwd_fp8")
         else:
@@ -406,7 +423,11 @@ class _BatchNormAct(torch.autograd.Function):
         out = torch.empty_like(y)
         if res is not None:
             res = res.contiguous()
-        L.check(lib.dei2i_affine_act_fwd(prec.code, n * h * w, c, _p(y), _p(a), _p(b), _p(res), act, _p(out), st), "affine_act")
+        xq = torch.empty(out.numel(), dtype=torch.uint8, device=dev) if _fp8_copy_wanted(prec, c) else None
+        L.check(lib.dei2i_affine_act_fwd(prec.code, n * h * w, c, _p(y), _p(a), _p(b), _p(res), act, _p(out), _p(xq), FP8_ACT_SCALE,
+                                         st), "affine_act")
+        if xq is not None:
+            _fp8_stash.append(xq)
         ctx.prec, ctx.act, ctx.training, ctx.has_res = prec, act, training, res is not None
         ctx.params = (weight, bias)
         ctx.save_for_backward(y, a, b, mean, rstd)
@@ -445,8 +466,9 @@ class _BatchNormAct(torch.autograd.Function):
 def batchnorm_act(y, weight, bias, running_mean, running_var, training, act="none", res=None, momentum=0.1, eps=1e-5,
                   num_batches_tracked=None):
     """num_batches_tracked: the module's int64 counter, incremented inside the statistics kernel in training mode."""
-    return _BatchNormAct.apply(y, weight, bias, res, running_mean, running_var, bool(training), float(momentum), float(eps),
-                               ACT[act], num_batches_tracked)
+    del _fp8_stash[:]
+    return _attach_fp8(_BatchNormAct.apply(y, weight, bias, res, running_mean, running_var, bool(training), float(momentum),
+                                           float(eps), ACT[act], num_batches_tracked))
 
 
 def add(x, res):
@@ -464,7 +486,7 @@ class _AffineAdd(torch.autograd.Function):
         out = torch.empty_like(x)
         lib = _lib_for(x)
         L.check(lib.dei2i_affine_act_fwd(prec.code, x.numel() // x.shape[-1], x.shape[-1], _p(x), _p(ones), _p(zeros), _p(res),
-                                         L.ACT_NONE, _p(out), _stream()), "add")
+                                         L.ACT_NONE, _p(out), None, 1.0, _stream()), "add")
         return out
 
     @staticmethod
@@ -494,8 +516,11 @@ class _SpadeRelu(torch.autograd.Function):
         L.check(lib.dei2i_moments_partial(prec.code, n, hs * ws, c, _p(x), _p(partial), st), "moments_partial")
         L.check(lib.dei2i_in_finalize(n, hs * ws, c, _p(partial), eps, _p(mean), _p(rstd), st), "in_finalize")
         out = torch.empty((n, h, w, c), dtype=prec.dtype, device=dev)
+        xq = torch.empty(out.numel(), dtype=torch.uint8, device=dev) if _fp8_copy_wanted(prec, c) else None
         L.check(lib.dei2i_spade_act_fwd(prec.code, n, h, w, c, 1 if up else 0, _p(x), _p(mean), _p(rstd), _p(gb), gb_mode,
-                                        _p(out), st), "spade_act_fwd")
+                                        _p(out), _p(xq), FP8_ACT_SCALE, st), "spade_act_fwd")
+        if xq is not None:
+            _fp8_stash.append(xq)
         ctx.prec, ctx.up, ctx.gb_mode = prec, up, gb_mode
         ctx.out_shape = (n, h, w, c)
         ctx.save_for_backward(x, gb, mean, rstd)        # backward recomputes the ReLU mask; the output is not kept
@@ -524,7 +549,8 @@ class _SpadeRelu(torch.autograd.Function):
 
 
 def spade_relu(x, gb, up: bool, gb_mode: int, eps: float = 1e-5):
-    return _SpadeRelu.apply(x, gb, bool(up), int(gb_mode), float(eps))
+    del _fp8_stash[:]
+    return _attach_fp8(_SpadeRelu.apply(x, gb, bool(up), int(gb_mode), float(eps)))
 
 
 # --------------------------------------------------------------------------------------------------------------

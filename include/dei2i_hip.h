@@ -132,14 +132,15 @@ int dei2i_in_finalize(int N, int HW, int C, const float* partial, float eps, flo
 
 /* ---- fused normalisation + activation, forward ---- */
 /* out = act(a[c]*x + b[c]) (+ res)   -- BatchNorm apply + LeakyReLU (+ ResBlock identity), architecture.py:116-118,174-176 */
+/* out_e4m3 (bf16 only, may be NULL): also write e4m3(out * e4m3_scale) -- the operand copy of the fp8 forward mode */
 int dei2i_affine_act_fwd(int dtype, size_t pixels, int C, const void* x, const float* a, const float* b, const void* res,
-                         int act, void* out, dei2i_stream s);
+                         int act, void* out, void* out_e4m3, float e4m3_scale, dei2i_stream s);
 /* SPADE + ReLU (normalization.py:24-37, architecture.py:241-245,343-350):
  *   out[n,h,w,c] = relu( (x[n,h>>up,w>>up,c] - mean[n,c]) * rstd[n,c] * (1 + gamma) + beta ) (+ nothing)
  * gb is (N, Hg, Wg, 2*C): gamma = [..., :C], beta = [..., C:].  gb_mode 0: Hg x Wg == output extent;
  * gb_mode 1: Hg = Wg = 5 "border class" table (labels constant over space; class = min(i,2) / 4-(H-1-i)). */
 int dei2i_spade_act_fwd(int dtype, int N, int H, int W, int C, int up, const void* x, const float* mean,
-                        const float* rstd, const void* gb, int gb_mode, void* out, dei2i_stream s);
+                        const float* rstd, const void* gb, int gb_mode, void* out, void* out_e4m3, float e4m3_scale, dei2i_stream s);
 
 /* ---- backward of the above ---- */
 /* g = dz * act'(z) (LeakyReLU / ReLU expressed through the saved output z) */

@@ -49,8 +49,8 @@ for (H, W, C) in ((256, 256, 64), (128, 128, 128), (64, 64, 256)):
     chunks = lib.dei2i_moments_chunks(H * W)
     partial = torch.empty(N, chunks, 4, C, device=DEV)
     timeit(tag + " moments_partial", lambda: lib.dei2i_moments_partial(BF, N, H * W, C, p(x), p(partial), st), T)
-    timeit(tag + " affine_act", lambda: lib.dei2i_affine_act_fwd(BF, pix, C, p(x), p(a), p(b), None, L.ACT_LRELU, p(out), st), 2 * T)
-    timeit(tag + " affine_act+res", lambda: lib.dei2i_affine_act_fwd(BF, pix, C, p(x), p(a), p(b), p(y), L.ACT_NONE, p(out), st), 3 * T)
+    timeit(tag + " affine_act", lambda: lib.dei2i_affine_act_fwd(BF, pix, C, p(x), p(a), p(b), None, L.ACT_LRELU, p(out), None, 1.0, st), 2 * T)
+    timeit(tag + " affine_act+res", lambda: lib.dei2i_affine_act_fwd(BF, pix, C, p(x), p(a), p(b), p(y), L.ACT_NONE, p(out), None, 1.0, st), 3 * T)
     timeit(tag + " act_bwd", lambda: lib.dei2i_act_bwd(BF, pix * C, p(dz), p(y), L.ACT_LRELU, p(out), st), 3 * T)
     bchunks = lib.dei2i_bn_bwd_chunks(pix)
     bpart = torch.empty(bchunks, 2, C, device=DEV)
@@ -64,7 +64,7 @@ for (H, W, C) in ((256, 256, 64), (128, 128, 128), (64, 64, 256)):
     mean_n = torch.randn(N, C, device=DEV)
     rstd_n = torch.rand(N, C, device=DEV) + 0.5
     gb = torch.randn(N, 5, 5, 2 * C, device=DEV).bfloat16()
-    timeit(tag + " spade_act", lambda: lib.dei2i_spade_act_fwd(BF, N, H, W, C, 0, p(x), p(mean_n), p(rstd_n), p(gb), 1, p(out), st), 2 * T)
+    timeit(tag + " spade_act", lambda: lib.dei2i_spade_act_fwd(BF, N, H, W, C, 0, p(x), p(mean_n), p(rstd_n), p(gb), 1, p(out), None, 1.0, st), 2 * T)
     dgb = torch.empty(N, 5, 5, 2 * C, device=DEV)
     coef = torch.empty(N, 2, C, device=DEV)
     z = torch.relu(torch.randn(N, H, W, C, device=DEV)).bfloat16()

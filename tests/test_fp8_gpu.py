@@ -70,6 +70,29 @@ def test_conv_forward_fp8_tracks_bf16(ops, cin, cout, h, n, reflect, up, act):
     assert 1e-4 < float(err) < 0.06, float(err)      # > 0: the fp8 kernel really ran; < 6 %: see module docstring
 
 
+def test_fused_e4m3_copies_of_the_normalisation_kernels_equal_the_quantiser(ops):
+    """In the fp8 scope the BatchNorm-act and SPADE-act kernels write the e4m3 operand copy in the same pass; it must be
+    byte-identical to quantising their bf16 output (so a conv gives the same result whichever way its operand came)."""
+    from de_i2i_gan_amd import _lib as L
+    lib = L.load()
+    torch.manual_seed(9)
+    n, h, c = 2, 32, 128
+    y = torch.randn(n, h, h, c, device=DEV).to(torch.bfloat16)
+    w, b = torch.rand(c, device=DEV) + 0.5, torch.randn(c, device=DEV) * 0.1
+    rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    gb = (torch.randn(n, 5, 5, 2 * c, device=DEV) * 0.3).to(torch.bfloat16)
+    with torch.no_grad(), ops.fp8_forward(True):
+        outs = [ops.batchnorm_act(y, w, b, rm, rv, True, "leaky_relu"), ops.spade_relu(y, gb, True, 1)]
+    with torch.no_grad():
+        plain = ops.batchnorm_act(y, w, b, torch.zeros(c, device=DEV), torch.ones(c, device=DEV), True, "leaky_relu")
+    assert not hasattr(plain, "_dei2i_fp8") and torch.equal(plain, outs[0])
+    for out in outs:
+        q = out._dei2i_fp8
+        ref = torch.empty(out.numel(), dtype=torch.uint8, device=DEV)
+        L.check(lib.dei2i_quantize_fp8(out.numel(), ops._p(out), ops.FP8_ACT_SCALE, ops._p(ref), ops._stream()), "quantize")
+        assert q.dtype == torch.uint8 and q.numel() == out.numel() and torch.equal(q, ref)
+
+
 def test_unsupported_shapes_stay_bf16_and_fp8_call_refuses_them(ops):
     from de_i2i_gan_amd import _lib as L
     lib = L.load()
