@@ -64,6 +64,8 @@ class DefectGanModel(BaseModel):
         """defectgan_model.py:173-249"""
         nm_labels, df_labels = self._get_labels(df_labels)
         self.netG.clear_spade_cache()
+        if not os.environ.get("DEI2I_SPLIT_D"):
+            self.netG.prime_spade((df_labels, nm_labels))        # both label sets' SPADE tables in one pass
         fake_defects, df_prob = self.netG(bg_data, df_labels)
         recover_normals, rec_df_prob = self.netG(fake_defects, nm_labels)
         fake_normals, nm_prob = self.netG(df_data, nm_labels)

@@ -216,15 +216,13 @@ class SPADE(nn.Module):
         n, hs, ws, c = x.shape
         h, w = (2 * hs, 2 * ws) if up else (hs, ws)
         class_mode = segmap.shape[2] == 1 and segmap.shape[3] == 1 and h >= 4 and w >= 4
+        self._ran_class_mode = class_mode                 # prime() only serves modules that run (norm_s never does)
         if not class_mode:
             return ops.spade_relu(x, self._gamma_beta(segmap, prec, False, h, w), up, 0)
         # The class table depends only on (label map, this module's weights), not on x: the loss graphs call G several
         # times with the SAME label tensors (defectgan_model.py:185-190), so the table -- with its autograd history,
         # autograd sums the gradients of all its uses -- is computed once per (label tensor, weight state, grad mode).
-        params = (self.mlp_shared[0].weight, self.mlp_shared[0].bias, self.mlp_gamma.weight, self.mlp_gamma.bias,
-                  self.mlp_beta.weight, self.mlp_beta.bias)
-        key = (id(segmap), segmap._version, prec.code, torch.is_grad_enabled(),
-               tuple(ops.PackedWeights._stamp(p) + (p.requires_grad,) for p in params))
+        key = self._table_key(segmap, prec)
         hit = self._gb_cache.get(key)
         if hit is None:
             gb = self._gamma_beta(segmap, prec, True, h, w)
@@ -234,6 +232,28 @@ class SPADE(nn.Module):
         else:
             gb = hit[1]
         return ops.spade_relu(x, gb, up, 1)
+
+    def _table_key(self, segmap, prec):
+        params = (self.mlp_shared[0].weight, self.mlp_shared[0].bias, self.mlp_gamma.weight, self.mlp_gamma.bias,
+                  self.mlp_beta.weight, self.mlp_beta.bias)
+        return (id(segmap), segmap._version, prec.code, torch.is_grad_enabled(),
+                tuple(ops.PackedWeights._stamp(p) + (p.requires_grad,) for p in params))
+
+    def prime(self, segmaps, prec):
+        """Compute the class tables of several (N,C,1,1) label tensors in ONE pass over their concatenation and memoize
+        each tensor's slice: the same function as one pass per tensor (the table convs act per sample), with half the
+        launches of the 5x5 table path (forward and backward) when a loss graph uses two label sets."""
+        if not getattr(self, "_ran_class_mode", False):
+            return
+        if len(segmaps) != 2 or any(s.dim() != 4 or s.shape[2] != 1 or s.shape[3] != 1 for s in segmaps):
+            return
+        gb = self._gamma_beta(torch.cat(list(segmaps), 0), prec, True, 0, 0)
+        self._gb_cache.clear()
+        off = 0
+        for sgm in segmaps:
+            n = sgm.shape[0]
+            self._gb_cache[self._table_key(sgm, prec)] = (sgm, gb[off:off + n])
+            off += n
 
 
 def _style_norm(style_norm_block_type, label_nc, f, hidden_nc):

@@ -89,6 +89,12 @@ class DefectGanGenerator(BaseNetwork):
         output, spatial_prob = ops.compose(raw, x)
         return output, spatial_prob
 
+    def prime_spade(self, label_tensors):
+        """Batch the SPADE class-table computation of the label sets a loss graph is about to use (see SPADE.prime)."""
+        for m in self.modules():
+            if hasattr(m, "prime") and hasattr(m, "_gb_cache"):
+                m.prime(label_tensors, self.prec)
+
     def clear_spade_cache(self):
         """Drop the memoized SPADE gamma/beta tables (they carry autograd history: a table must not outlive the loss
         graph it was built in).  The model calls this at the start of every loss computation."""
