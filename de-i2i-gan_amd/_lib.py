@@ -39,6 +39,7 @@ SIGNATURES = {
     "dei2i_packed_dgrad_elems": (c_size_t, [_CD]),
     "dei2i_pack_weight_fwd": (c_int, [_CD, _P, _P, _P]),
     "dei2i_pack_weight_dgrad": (c_int, [_CD, _P, _P, _P]),
+    "dei2i_pack_weight_both": (c_int, [_CD, _P, _P, _P, _P]),
     "dei2i_unpack_wgrad": (c_int, [_CD, _P, _P, c_float, _P]),
     "dei2i_conv2d_out_shape": (None, [_CD, POINTER(c_int), POINTER(c_int)]),
     "dei2i_conv2d_dgrad_shape": (None, [_CD, POINTER(c_int), POINTER(c_int)]),

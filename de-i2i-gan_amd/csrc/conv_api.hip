@@ -51,6 +51,32 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w, T* __restrict__ d
   }
 }
 
+// forward layout and every dgrad parity class of one weight in ONE launch (a weight is re-packed once per optimizer step;
+// with ~50 convolutions per net every saved launch is ~4.5 us of device time)
+struct PackAll {
+  long long fwd_total;
+  long long cls_begin[17];       // element offsets of the dgrad classes in the packed dgrad buffer (+ total at [ncls])
+  int ay[16], ax[16], th[16], tw[16];
+  int ncls;
+};
+template <typename T>
+__global__ void pack_all_kernel(const float* __restrict__ w, T* __restrict__ fwd, T* __restrict__ dgrad, const PackAll pa, int Cout,
+                                int Cin, int CinS, int CoutS, int kh, int kw, int s) {
+  const long long total = pa.fwd_total + pa.cls_begin[pa.ncls];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    if (i < pa.fwd_total) {
+      const long long si = packed_fwd_src(i, Cin, CinS, kh * kw);
+      Elem<T>::store(fwd + i, si >= 0 ? w[si] : 0.f);
+    } else {
+      const long long j = i - pa.fwd_total;
+      int k = 0;
+      while (k + 1 < pa.ncls && j >= pa.cls_begin[k + 1]) ++k;
+      const long long si = packed_dgrad_src(j - pa.cls_begin[k], Cout, Cin, CoutS, kh, kw, s, pa.ay[k], pa.ax[k], pa.th[k], pa.tw[k]);
+      Elem<T>::store(dgrad + j, si >= 0 ? w[si] : 0.f);
+    }
+  }
+}
+
 __global__ void unpack_wgrad_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin, int CinS,
                                     int taps, float beta) {
   const size_t total = (size_t)Cout * Cin * taps;
@@ -202,6 +228,33 @@ int dei2i_pack_weight_dgrad(const dei2i_conv* c, const float* w, void* packed, d
                            c->kh, c->kw, c->stride, ay, ax, th, tw);
       off += total;
     }
+  return (int)hipGetLastError();
+}
+
+int dei2i_pack_weight_both(const dei2i_conv* c, const float* w, void* packed_fwd, void* packed_dgrad, dei2i_stream s) {
+  if (!valid_conv(c) || !w || !packed_fwd || !packed_dgrad || c->stride > 4) return DEI2I_ERR_BAD_ARG;
+  PackAll pa;
+  pa.fwd_total = (long long)dei2i_packed_fwd_elems(c);
+  pa.ncls = 0;
+  long long off = 0;
+  for (int ay = 0; ay < c->stride; ++ay)
+    for (int ax = 0; ax < c->stride; ++ax) {
+      const int th = dgrad_taps(c->kh, c->stride, ay), tw = dgrad_taps(c->kw, c->stride, ax);
+      const long long total = (long long)c->Cin * th * tw * c->CoutS;
+      if (total == 0) continue;
+      pa.ay[pa.ncls] = ay; pa.ax[pa.ncls] = ax; pa.th[pa.ncls] = th; pa.tw[pa.ncls] = tw;
+      pa.cls_begin[pa.ncls++] = off;
+      off += total;
+    }
+  pa.cls_begin[pa.ncls] = off;
+  for (int k = pa.ncls + 1; k < 17; ++k) pa.cls_begin[k] = off;
+  const unsigned grid = grid_for((size_t)(pa.fwd_total + off), 256);
+  if (c->dtype == DT_BF16)
+    hipLaunchKernelGGL(pack_all_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, w, (bf16_t*)packed_fwd, (bf16_t*)packed_dgrad,
+                       pa, c->Cout, c->Cin, c->CinS, c->CoutS, c->kh, c->kw, c->stride);
+  else
+    hipLaunchKernelGGL(pack_all_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)s, w, (float*)packed_fwd, (float*)packed_dgrad,
+                       pa, c->Cout, c->Cin, c->CinS, c->CoutS, c->kh, c->kw, c->stride);
   return (int)hipGetLastError();
 }
 

@@ -213,6 +213,10 @@ class PackedWeights:
         w = weight.detach()
         if w.dtype != torch.float32 or not w.is_contiguous():
             w = w.float().contiguous()
+        if need_fwd and need_dgrad and self.fwd is None and self.dgrad is None:       # the training path: one launch
+            self.fwd = torch.empty(lib.dei2i_packed_fwd_elems(byref(d)), dtype=prec.dtype, device=weight.device)
+            self.dgrad = torch.empty(lib.dei2i_packed_dgrad_elems(byref(d)), dtype=prec.dtype, device=weight.device)
+            L.check(lib.dei2i_pack_weight_both(byref(d), _p(w), _p(self.fwd), _p(self.dgrad), _stream()), "pack_weight_both")
         if need_fwd and self.fwd is None:
             self.fwd = torch.empty(lib.dei2i_packed_fwd_elems(byref(d)), dtype=prec.dtype, device=weight.device)
             L.check(lib.dei2i_pack_weight_fwd(byref(d), _p(w), _p(self.fwd), _stream()), "pack_weight_fwd")
@@ -253,7 +257,10 @@ class _Conv2d(torch.autograd.Function):
         lib = _lib_for(x)
         d = _desc(prec, geom, n, h, w, cins, couts)
         use_fp8 = bool(_fp8_forward and prec is BF16 and lib.dei2i_conv2d_fp8_supported(byref(d)))
-        wf = None if use_fp8 else cache.get(weight, sources, prec, geom, cins, couts, need_dgrad=False)[0]
+        # trainable weights: a backward pass of this optimizer step will want the dgrad layout too (also when THIS call
+        # is the no-grad generator pass of the D step) -> both layouts in one pack launch
+        wf = None if use_fp8 else cache.get(weight, sources, prec, geom, cins, couts,
+                                            need_dgrad=any(s_.requires_grad for s_ in sources))[0]
         ho, wo = c_int(), c_int()
         lib.dei2i_conv2d_out_shape(byref(d), byref(ho), byref(wo))
         y = torch.empty((n, ho.value, wo.value, couts), dtype=prec.dtype, device=x.device)

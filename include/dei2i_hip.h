@@ -57,6 +57,8 @@ size_t dei2i_packed_fwd_elems(const dei2i_conv* c);      /* Cout * kh*kw * CinS 
 size_t dei2i_packed_dgrad_elems(const dei2i_conv* c);    /* sum over stride^2 parity classes of Cin * taps * CoutS */
 int dei2i_pack_weight_fwd(const dei2i_conv* c, const float* w_oihw, void* packed, dei2i_stream s);
 int dei2i_pack_weight_dgrad(const dei2i_conv* c, const float* w_oihw, void* packed, dei2i_stream s);
+/* both layouts in one launch (the training path: a weight is re-packed once per optimizer step) */
+int dei2i_pack_weight_both(const dei2i_conv* c, const float* w_oihw, void* packed_fwd, void* packed_dgrad, dei2i_stream s);
 /* packed fp32 wgrad [Cout][kh*kw][CinS] -> OIHW fp32 (beta = 0: overwrite, 1: accumulate) */
 int dei2i_unpack_wgrad(const dei2i_conv* c, const float* dw_packed, float* dw_oihw, float beta, dei2i_stream s);
 
