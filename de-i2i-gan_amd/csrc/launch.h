@@ -9,7 +9,7 @@
 
 namespace dei2i {
 
-enum ProfFamily : int { PROF_GATHER_GEMM = 0, PROF_WGRAD = 1, PROF_FAMILIES = 2 };
+enum ProfFamily : int { PROF_GATHER_GEMM = 0, PROF_WGRAD = 1, PROF_HALO_CONV = 2, PROF_FAMILIES = 3 };
 void prof_begin(int family, double flops, hipStream_t st);
 void prof_end(int family, hipStream_t st);
 

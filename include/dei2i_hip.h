@@ -207,8 +207,9 @@ int dei2i_adam_step(const dei2i_adam_rec* table_dev, int count, int64_t max_n, f
                     float eps, float bias_c1, float bias_c2_sqrt, float grad_scale, dei2i_stream s);
 
 /* ---- in-library kernel timing (bench.py roofline leg): HIP events around every launch of one kernel family ---- */
-#define DEI2I_PROF_GATHER_GEMM 0
+#define DEI2I_PROF_GATHER_GEMM 0  /* the other conv forward / dgrad kernels: gather GEMM v1 / v2, thin convs */
 #define DEI2I_PROF_WGRAD 1
+#define DEI2I_PROF_HALO_CONV 2   /* halo_conv_kernel alone (its launches are not part of family 0) */
 int dei2i_prof_enable(int family, int on);
 /* synchronises the recorded events; returns launches, total ms and total algorithmic FLOPs since enable */
 int dei2i_prof_collect(int family, int64_t* launches, double* total_ms, double* total_flops);
