@@ -37,6 +37,8 @@ def parse():
                     help="fp8: e4m3 forward GEMMs of the stride-1 3x3 convs, bf16 everywhere else (BASELINE.json configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--stage", default="defectgan", choices=["defectgan", "mae"],
+                    help="mae: the MAE-GAN pre-training step (SURVEY.md section 8f rank 1) instead of the headline defectGAN step")
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=INT",
                     help="library option for A/B runs on one box, e.g. halo_conv=0 (dei2i_set_option)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child process of the default run
@@ -50,7 +52,10 @@ def make_opt(args, device):
     from types import SimpleNamespace
     import torch
     s = args.image_size
-    return SimpleNamespace(
+    mae = getattr(args, "stage", "defectgan") == "mae"     # options/defectgan_options.py:150-189 (MAE stage defaults)
+    extra = dict(optimizer="adamw", scheduler="cos", lr=[1.5e-4], lr_decay=0.05, loss_weight=[10, 3, 1], num_epochs=200,
+                 split_training=False, mask_token_type="position", mask_ratio=0.75, patch_size=8) if mae else {}
+    opt = SimpleNamespace(
         model="defectgan", num_res=6, cycle_gan=False, label_nc=6, skip_conn=False, ngf=64, ndf=64, input_nc=3,
         use_spectral=False, num_scales=3 if s >= 512 else 2, style_norm_block_type="spade", hidden_nc=128,
         style_distill=False, embed_nc=768, add_noise=False, num_layers=5 if s >= 128 else 4, image_size=s,
@@ -59,6 +64,9 @@ def make_opt(args, device):
         name="bench", iters_per_epoch=1000, num_epochs=-1, num_iters=10 ** 6, lr=[2e-4], optimizer="adam", scheduler="step",
         lr_decay=5e-3, loss_weight=[2, 5, 5, 5, 1], num_critics=1, diff_aug="", sean_alpha=None, use_running_stats=False,
         save_latest_freq=10 ** 9, compute_dtype=args.dtype, defer_loss_sync=True)
+    for k, v in extra.items():
+        setattr(opt, k, v)
+    return opt
 
 
 def synthetic_batch(n, size, seed, label_nc=6):
@@ -162,7 +170,13 @@ def main():
         _lib.check(_lib.load().dei2i_set_option(name.encode(), int(val)), "set_option " + kv)
     opt = make_opt(args, device)
     torch.manual_seed(123)                           # reference default (utils/util.py:21); same weights on every rank
-    tr = DefectGanTrainer(opt)
+    if args.stage == "mae":
+        from de_i2i_gan_amd.trainers.mae_trainer import MAETrainer
+        tr = MAETrainer(opt)
+        step = lambda: tr.step(bg, lab)                      # noqa: E731
+    else:
+        tr = DefectGanTrainer(opt)
+        step = lambda: tr.step(bg, lab, df)                  # noqa: E731
     if world > 1:
         attach_ddp(tr)
     bg, lab, df = synthetic_batch(args.batch, args.image_size, seed=7 + rank)
@@ -176,7 +190,7 @@ def main():
     if rank == 0:
         print("[bench] model built; %d warm-up + %d timed steps ..." % (args.warmup, args.steps), file=sys.stderr, flush=True)
     for _ in range(args.warmup):
-        tr.step(bg, lab, df)
+        step()
     lib = _lib.load()
     sync()
     if not args.no_roofline:
@@ -184,7 +198,7 @@ def main():
             lib.dei2i_prof_enable(fid, 1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        tr.step(bg, lab, df)
+        step()
     sync()
     elapsed = time.perf_counter() - t0
     fam = {}
@@ -194,7 +208,8 @@ def main():
             _lib.check(lib.dei2i_prof_collect(fid, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)), "prof_collect")
             fam[name] = (n.value, ms.value, fl.value)
             lib.dei2i_prof_enable(fid, 0)
-    tr.flush_losses()
+    if hasattr(tr, "flush_losses"):
+        tr.flush_losses()
     if rank == 0:
         print("[bench] timed region done: %.2f ms/step" % (1e3 * elapsed / args.steps), file=sys.stderr, flush=True)
     if world > 1:
@@ -209,12 +224,17 @@ def main():
     pairs = args.batch * world * args.steps
     ms_per_step = 1e3 * elapsed / args.steps
     line = {
-        "metric": f"paired {args.image_size}x{args.image_size} images/sec (G+D train step)", "value": pairs / elapsed, "unit": "pairs/s",
+        "metric": (f"paired {args.image_size}x{args.image_size} images/sec (G+D train step)" if args.stage == "defectgan" else
+                   f"{args.image_size}x{args.image_size} images/sec (MAE-GAN pre-training D+G step)"), "value": pairs / elapsed, "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype if args.dtype != "fp8" else "fp8-e4m3 forward GEMMs of the 3x3 convs + bf16", "data": "synthetic",
-        "config": {"workload": f"defectGAN D+G train step, {args.image_size}x{args.image_size} paired RGB, "
-                               f"batch {args.batch}/GPU, ngf=ndf=64 num_res=6 num_layers={opt.num_layers} SPADE, Adam(0.5,0.999)",
+        "config": {"workload": (f"defectGAN D+G train step, {args.image_size}x{args.image_size} paired RGB, "
+                                f"batch {args.batch}/GPU, ngf=ndf=64 num_res=6 num_layers={opt.num_layers} SPADE, Adam(0.5,0.999)"
+                                if args.stage == "defectgan" else
+                                f"MAE-GAN pre-training D+G step (mask_ratio 0.75, patch 8, position mask token), "
+                                f"{args.image_size}x{args.image_size} RGB, batch {args.batch}/GPU, ngf=ndf=64 num_res=6 "
+                                f"num_layers={opt.num_layers} SPADE, AdamW(0.9,0.95) through GradScaler"),
                    "global_batch": args.batch * world, "parallelism": f"dp{world}",
                    "spade_path": "collapsed (5x5 border-class gamma/beta for 1x1 label maps)"},
         "losses_last_step": {k: round(v[-1], 5) for kind in tr.losses.values() for k, v in kind.items() if v},

@@ -1,6 +1,7 @@
-// Fused multi-tensor Adam: one launch updates every parameter tensor of a network.
-// torch.optim.Adam single-tensor semantics (no weight decay, no amsgrad), reference call site
-// trainers/base_trainer.py:75-89 (betas (0.5, 0.999), eps 1e-8):
+// Fused multi-tensor Adam / AdamW: one launch updates every parameter tensor of a network.
+// torch.optim.Adam single-tensor semantics (no amsgrad), reference call site trainers/base_trainer.py:75-89
+// (Adam betas (0.5, 0.999); AdamW betas (0.9, 0.95) with torch's default decoupled weight decay 1e-2 for the MAE stage):
+//   p *= 1 - lr*wd  (AdamW only: keep = 1 - lr*wd, 1 for Adam)
 //   m += (1-b1)(g-m); v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 #include <hip/hip_runtime.h>
 
@@ -11,7 +12,7 @@ namespace dei2i {
 
 __global__ __launch_bounds__(256) void adam_kernel(const dei2i_adam_rec* __restrict__ table, float lr, float beta1,
                                                    float beta2, float eps, float bias_c1, float bias_c2_sqrt,
-                                                   float grad_scale) {
+                                                   float grad_scale, float keep) {
   const dei2i_adam_rec rec = table[blockIdx.y];
   const float step_size = lr / bias_c1;
   const float inv_c2 = 1.f / bias_c2_sqrt;
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const dei2i_adam_rec* __restr
       mp[e] = mp[e] + (1.f - beta1) * (gv - mp[e]);
       vp[e] = beta2 * vp[e] + (1.f - beta2) * gv * gv;
       const float denom = sqrtf(vp[e]) * inv_c2 + eps;
-      pp[e] = pp[e] - step_size * (mp[e] / denom);
+      pp[e] = pp[e] * keep - step_size * (mp[e] / denom);
     }
     reinterpret_cast<float4*>(rec.p)[i] = p;
     reinterpret_cast<float4*>(rec.m)[i] = m;
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const dei2i_adam_rec* __restr
     const float v = beta2 * rec.v[i] + (1.f - beta2) * gv * gv;
     rec.m[i] = m;
     rec.v[i] = v;
-    rec.p[i] = rec.p[i] - step_size * (m / (sqrtf(v) * inv_c2 + eps));
+    rec.p[i] = rec.p[i] * keep - step_size * (m / (sqrtf(v) * inv_c2 + eps));
   }
 }
 
@@ -52,12 +53,13 @@ __global__ __launch_bounds__(256) void adam_kernel(const dei2i_adam_rec* __restr
 using namespace dei2i;
 
 extern "C" int dei2i_adam_step(const dei2i_adam_rec* table_dev, int count, int64_t max_n, float lr, float beta1, float beta2,
-                               float eps, float bias_c1, float bias_c2_sqrt, float grad_scale, dei2i_stream s) {
+                               float eps, float bias_c1, float bias_c2_sqrt, float grad_scale, float decoupled_decay,
+                               dei2i_stream s) {
   if (!table_dev || count <= 0 || max_n <= 0) return DEI2I_ERR_BAD_ARG;
   int64_t bx = (max_n / 4 + 255) / 256;
   if (bx < 1) bx = 1;
   if (bx > 512) bx = 512;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)bx, (unsigned)count), dim3(256), 0, (hipStream_t)s, table_dev, lr, beta1, beta2,
-                     eps, bias_c1, bias_c2_sqrt, grad_scale);
+                     eps, bias_c1, bias_c2_sqrt, grad_scale, 1.f - lr * decoupled_decay);
   return (int)hipGetLastError();
 }

@@ -1,10 +1,13 @@
-"""DefectGanModel (models/defectgan_model.py:18-104,173-314): the loss graphs of the D step and the G step."""
+"""DefectGanModel (models/defectgan_model.py:18-171,173-314,361-383): the loss graphs of the D step and the G step of the
+defectGAN stage, and of the MAE-GAN pre-training stage (modes ``mae_*``)."""
 import os
 
 import torch
 
+from ..networks.architecture import MaskToken
 from ..networks.discriminator import DefectGanDiscriminator
 from ..networks.generator import DefectGanGenerator
+from ..utils.masks import draw_shifted_mask, expand_shifted_mask
 from .base_model import BaseModel
 
 
@@ -22,11 +25,30 @@ class DefectGanModel(BaseModel):
         if self.opt.is_train or hasattr(opt, "clf_loss_type"):
             assert opt.clf_loss_type is not None, "clf_loss_type should be initialized in dataset"
             self.clf_loss_type = opt.clf_loss_type
+        if hasattr(opt, "mask_token_type"):              # learnable mask token of the MAE stage (defectgan_model.py:31-32)
+            self.mask_token = MaskToken(opt).to(opt.device, non_blocking=True)
 
     def __call__(self, mode, data, labels, df_data=None, img_only=False, mask=None):
         data, labels = data.to(self.opt.device, non_blocking=True), labels.to(self.opt.device, non_blocking=True)
         if df_data is not None:
             df_data = df_data.to(self.opt.device, non_blocking=True)
+        if mode.startswith("mae"):
+            if getattr(self.opt, "split_training", False):
+                raise NotImplementedError("split_training (training G and D of the MAE stage individually) is not implemented")
+            if mode == "mae_generator":
+                self.netD.eval()
+                self.netG.train()
+                return self._compute_mae_generator_loss(data, labels)
+            if mode == "mae_discriminator":
+                self.netD.train()
+                self.netG.eval()
+                return self._compute_mae_discriminator_loss(data, labels)
+            if mode == "mae_inference":
+                self.netD.eval()
+                self.netG.eval()
+                with torch.no_grad():
+                    return self._compute_mae_generator_loss(data, labels)
+            raise ValueError(f"|mode {mode}| is invalid")
         if mode == "generator":
             self.netD.eval()
             self.netG.train()
@@ -59,6 +81,64 @@ class DefectGanModel(BaseModel):
         sizes = [t.shape[0] for t in images]
         src, cls = self.netD(torch.cat(images, 0))
         return list(zip(src.split(sizes), cls.split(sizes)))
+
+    # ---- MAE-GAN pre-training stage (defectgan_model.py:106-171, 361-383) ----------------------------------------
+    def _repair_mask(self, imgs, labels, mask=None):
+        """Draw a shifted patch mask (host RNG, like the reference), fill the masked pixels with the mask token and
+        let the generator repair the image."""
+        if mask is not None:
+            masks = self._upload_mask(mask)
+        else:       # the reference's RNG draws on the host (utils/util.py:61-71); the expansion to pixels on the device
+            row0, col0, keep = draw_shifted_mask(imgs.size(), self.opt.patch_size, self.opt.mask_ratio)
+            masks = expand_shifted_mask(self._upload_mask(keep), row0, col0, self.opt.patch_size, imgs.size(2), imgs.size(3))
+        self.netG.clear_spade_cache()
+        predicted, _ = self.netG(self.mask_token(imgs, masks), self._expand_seg(labels))
+        return predicted, masks
+
+    def _upload_mask(self, masks):
+        """Host mask -> device without stalling the host: a pageable host->device copy waits for the GPU work queued
+        before it, so the mask goes through one of a few persistent pinned staging buffers (each guarded by an event)."""
+        dev = torch.device(self.opt.device)
+        if masks.device.type != "cpu" or dev.type != "cuda":
+            return masks.to(dev, non_blocking=True)
+        ring = self.__dict__.setdefault("_mask_ring", [])
+        slot = self.__dict__.get("_mask_slot", 0)
+        self.__dict__["_mask_slot"] = (slot + 1) % 4
+        if len(ring) <= slot or ring[slot][0].shape != masks.shape:
+            entry = (torch.empty(masks.shape, dtype=masks.dtype, pin_memory=True), torch.cuda.Event())
+            if len(ring) <= slot:
+                ring.append(entry)
+            else:
+                ring[slot] = entry
+        buf, done = ring[slot]
+        done.synchronize()                            # the copy that last used this buffer (four uploads ago) has finished
+        buf.copy_(masks)
+        out = buf.to(dev, non_blocking=True)
+        done.record(torch.cuda.current_stream(dev))
+        return out
+
+    def _compute_mae_generator_loss(self, imgs, labels):
+        """(rec, gan, clf): l1(G(masked), x), bce(D(G(masked)), 1), bce(cls(G(masked)), labels)"""
+        predicted, _ = self._repair_mask(imgs, labels)
+        rec_loss = self._cal_loss(predicted, imgs, "l1")
+        d_params = [p for p in self.netD.parameters() if p.requires_grad]     # D's weight gradients are never read here
+        for p in d_params:
+            p.requires_grad_(False)
+        try:
+            fake_src, fake_cls = self.netD(predicted)
+        finally:
+            for p in d_params:
+                p.requires_grad_(True)
+        return rec_loss, self._cal_loss(fake_src, 1.0, "bce"), self._cal_loss(fake_cls, labels.view_as(fake_cls), self.clf_loss_type)
+
+    def _compute_mae_discriminator_loss(self, imgs, labels):
+        """(gan, clf): mean(bce(D(G(masked)), 0), bce(D(x), 1)), bce(cls(x), labels); G runs in eval mode, no grad"""
+        with torch.no_grad():
+            predicted, _ = self._repair_mask(imgs, labels)
+        (real_src, real_cls), (fake_src, _) = self._netD_batched(imgs, predicted.detach())
+        clf_loss = self._cal_loss(real_cls, labels.view_as(real_cls), self.clf_loss_type)
+        gan_loss = self._mean([self._cal_loss(fake_src, 0.0, "bce"), self._cal_loss(real_src, 1.0, "bce")])
+        return gan_loss, clf_loss
 
     def _compute_generator_loss(self, bg_data, df_labels, df_data):
         """defectgan_model.py:173-249"""

@@ -315,3 +315,32 @@ class NormResBlock(nn.Module):
         h = self.conv_0(self.norm_0(x, labels))
         h = self.conv_1(self.norm_1(h, labels))
         return ops.add(h, x)
+
+
+class MaskToken(nn.Module):
+    """Learnable fill of the masked pixels of the MAE stage (architecture.py:392-418): ``imgs * masks + token * (1 - masks)``
+    on the NCHW fp32 images (3 channels -- host-side plumbing in front of the generator, plain torch ops).
+    Kinds: zero | mean (per-image channel mean of the kept pixels / mask_ratio, as the reference computes it) | scalar |
+    vector | position | full; the last four own one parameter named ``mask_token``."""
+
+    SHAPES = {"scalar": lambda c, s: (1, 1, 1, 1), "vector": lambda c, s: (1, c, 1, 1),
+              "position": lambda c, s: (1, 1, s, s), "full": lambda c, s: (1, c, s, s)}
+
+    def __init__(self, opt):
+        super().__init__()
+        self.mask_token_type = opt.mask_token_type
+        self.mask_ratio = opt.mask_ratio
+        if self.mask_token_type in ("zero", "mean"):
+            self.mask_token = 0
+        elif self.mask_token_type in self.SHAPES:
+            self.mask_token = nn.Parameter(torch.zeros(self.SHAPES[self.mask_token_type](opt.input_nc, opt.image_size)))
+        else:
+            raise ValueError("Unknown mask token type: {}".format(self.mask_token_type))
+
+    def forward(self, imgs, masks):
+        kept = imgs * masks
+        token = self.mask_token
+        if self.mask_token_type == "mean":
+            mean = kept.mean(dim=(2, 3)) / self.mask_ratio
+            token = self.mask_token = mean.reshape(mean.size(0), mean.size(1), 1, 1)
+        return kept + token * (1 - masks)

@@ -1,8 +1,9 @@
 """Fused multi-tensor Adam on the HIP kernel (csrc/adam.hip): one launch per optimizer step.
 
-A ``torch.optim.Optimizer`` subclass, so ``lr_scheduler``s and ``param_groups`` keep working the way the reference's
-BaseTrainer uses them (trainers/base_trainer.py:68-126).  Semantics = torch.optim.Adam (no weight decay, no amsgrad):
-parameters whose ``grad`` is None are skipped and get no state."""
+A ``torch.optim.Optimizer`` subclass, so ``lr_scheduler``s, ``param_groups`` / ``add_param_group`` and
+``torch.amp.GradScaler`` keep working the way the reference's trainers use them (trainers/base_trainer.py:68-126,
+mae_trainer.py:28,139-158).  Semantics = torch.optim.Adam (no amsgrad), or torch.optim.AdamW with ``weight_decay > 0``
+(decoupled: p *= 1 - lr*wd before the update): parameters whose ``grad`` is None are skipped and get no state."""
 import ctypes
 import math
 
@@ -13,10 +14,10 @@ from . import ops
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
-        if lr < 0.0 or eps < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, weight_decay=0.0):
+        if lr < 0.0 or eps < 0.0 or weight_decay < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0):
             raise ValueError("invalid Adam hyper-parameter")
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.grad_scale = float(grad_scale)
 
     @torch.no_grad()
@@ -42,10 +43,10 @@ class FusedAdam(torch.optim.Optimizer):
                 by_step.setdefault(st["step"], []).append(p)
             b1, b2 = group["betas"]
             for t, plist in by_step.items():
-                self._launch(plist, t, float(group["lr"]), b1, b2, group["eps"])
+                self._launch(plist, t, float(group["lr"]), b1, b2, group["eps"], float(group.get("weight_decay", 0.0)))
         return loss
 
-    def _launch(self, plist, t, lr, b1, b2, eps):
+    def _launch(self, plist, t, lr, b1, b2, eps, weight_decay=0.0):
         dev = plist[0].device
         lib = ops._lib_for(plist[0])
         n = len(plist)
@@ -63,7 +64,7 @@ class FusedAdam(torch.optim.Optimizer):
         table.copy_(torch.tensor(rows, dtype=torch.int64))
         table_dev = table.to(dev, non_blocking=True)
         L.check(lib.dei2i_adam_step(ctypes.c_void_p(table_dev.data_ptr()), n, max_n, lr, b1, b2, eps, 1.0 - b1 ** t,
-                                    math.sqrt(1.0 - b2 ** t), self.grad_scale, ops._stream()), "adam_step")
+                                    math.sqrt(1.0 - b2 ** t), self.grad_scale, weight_decay, ops._stream()), "adam_step")
         for p in plist:
             p._dei2i_epoch = getattr(p, "_dei2i_epoch", 0) + 1      # raw-pointer update: invalidate packed copies
             p._dei2i_keep = None

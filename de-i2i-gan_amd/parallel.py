@@ -160,5 +160,8 @@ def attach_ddp(trainer, process_group=None, **kw) -> GradReducer:
     for name, net in trainer.model.networks.items():
         red.attach(net)
         trainer.optimizers[name].grad_scale = 1.0 / red.world
+    mask_token = getattr(trainer.model, "mask_token", None)         # MAE stage: trained by the generator's optimizer
+    if isinstance(mask_token, torch.nn.Module):
+        red.attach(mask_token)
     trainer.reducer = red
     return red

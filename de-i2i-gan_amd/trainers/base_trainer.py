@@ -3,6 +3,7 @@ import math
 from collections import defaultdict
 
 import numpy as np
+import torch
 from torch import optim
 
 from ..models import create_model
@@ -43,6 +44,10 @@ class BaseTrainer:
         self._init_lr(opt)
         self._create_optimizer(opt)
         self._create_scheduler(opt)
+        # defer_loss_sync: keep the per-step losses on the device and convert them in one batch in flush_losses()
+        # instead of the reference's .item() per loss (one host sync each, defectgan_trainer.py:164-168,179-180)
+        self.defer_loss_sync = bool(getattr(opt, "defer_loss_sync", False))
+        self._pending = []
 
     def _init_lr(self, opt):
         self.lr = opt.lr[0]
@@ -53,8 +58,12 @@ class BaseTrainer:
         if opt.optimizer == "adam":
             optim_cls = FusedAdam                       # torch.optim.Adam(betas=(0.5, 0.999)) in the reference (:75-77)
             optim_args["betas"] = (0.5, 0.999)
-        elif opt.optimizer in ("sgd", "rmsprop", "adamw"):
-            raise NotImplementedError(f"optimizer [{opt.optimizer}]: only 'adam' (the reference default) has a fused kernel")
+        elif opt.optimizer == "adamw":
+            optim_cls = FusedAdam                       # torch.optim.AdamW(betas=(0.9, 0.95)) in the reference (:78-80)
+            optim_args["betas"] = (0.9, 0.95)
+            optim_args["weight_decay"] = 1e-2           # torch.optim.AdamW's default, which the reference relies on
+        elif opt.optimizer in ("sgd", "rmsprop"):
+            raise NotImplementedError(f"optimizer [{opt.optimizer}]: only 'adam' / 'adamw' have a fused kernel")
         else:
             raise NameError(f"optimizer named {opt.optimizer} not defined")
         self.optimizers = {}
@@ -90,6 +99,25 @@ class BaseTrainer:
         for _ in range(self.first_epoch):
             for scheduler in self.schedulers.values():
                 scheduler.step()
+
+    # ---- loss bookkeeping (self.losses[kind][name] lists, like the reference) ----------------------------------
+    def _record(self, keys, tensors):
+        stacked = torch.stack([t.detach() for t in tensors])
+        if self.defer_loss_sync:
+            self._pending.append((keys, stacked))
+        else:
+            for (kind, name), v in zip(keys, stacked.tolist()):        # ONE device->host read for the group
+                self.losses[kind][name].append(v)
+
+    def flush_losses(self):
+        if self._pending:
+            flat = torch.cat([s for _, s in self._pending]).tolist()
+            i = 0
+            for keys, s in self._pending:
+                for kind, name in keys:
+                    self.losses[kind][name].append(flat[i])
+                    i += 1
+            self._pending = []
 
     def _update_per_epoch(self, epoch=None):
         for model_name in self.schedulers.keys():

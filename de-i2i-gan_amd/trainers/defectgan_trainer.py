@@ -20,10 +20,6 @@ class DefectGanTrainer(BaseTrainer):
         self._init_losses()
         if opt.phase == "val":
             raise NotImplementedError("phase='val' builds FID/LPIPS metric networks (downloaded weights): out of scope")
-        # defer_loss_sync: keep the per-step losses on the device and convert them in one batch in flush_losses()
-        # instead of the reference's .item() per loss (7 host syncs per step, defectgan_trainer.py:164-168,179-180)
-        self.defer_loss_sync = bool(getattr(opt, "defer_loss_sync", False))
-        self._pending = []
         self.reducer = None          # set by parallel.attach_ddp(): gradient all-reduce across ranks
 
     def _init_lr(self, opt):
@@ -32,25 +28,6 @@ class DefectGanTrainer(BaseTrainer):
 
     def _init_losses(self):
         self.losses = {loss_type: defaultdict(list) for loss_type in self.loss_types}
-
-    # ---- loss bookkeeping -------------------------------------------------------------------------------------
-    def _record(self, keys, tensors):
-        stacked = torch.stack([t.detach() for t in tensors])
-        if self.defer_loss_sync:
-            self._pending.append((keys, stacked))
-        else:
-            for (kind, name), v in zip(keys, stacked.tolist()):        # ONE device->host read for the group
-                self.losses[kind][name].append(v)
-
-    def flush_losses(self):
-        if self._pending:
-            flat = torch.cat([s for _, s in self._pending]).tolist()
-            i = 0
-            for keys, s in self._pending:
-                for kind, name in keys:
-                    self.losses[kind][name].append(flat[i])
-                    i += 1
-            self._pending = []
 
     # ---- the step ---------------------------------------------------------------------------------------------
     def _train_generator_once(self, bg_data, df_labels, df_data):

@@ -204,7 +204,8 @@ typedef struct dei2i_adam_rec {
   int64_t n;
 } dei2i_adam_rec;
 int dei2i_adam_step(const dei2i_adam_rec* table_dev, int count, int64_t max_n, float lr, float beta1, float beta2,
-                    float eps, float bias_c1, float bias_c2_sqrt, float grad_scale, dei2i_stream s);
+                    float eps, float bias_c1, float bias_c2_sqrt, float grad_scale, float decoupled_decay, dei2i_stream s);
+/* decoupled_decay: AdamW's weight decay (p *= 1 - lr*decay before the Adam update); 0 = torch.optim.Adam */
 
 /* ---- in-library kernel timing (bench.py roofline leg): HIP events around every launch of one kernel family ---- */
 #define DEI2I_PROF_GATHER_GEMM 0  /* the other conv forward / dgrad kernels: gather GEMM v1 / v2, thin convs */

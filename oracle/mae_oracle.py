@@ -1,0 +1,144 @@
+"""CPU restatement of the reference's MAE-GAN pre-training step.
+
+TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``): the checker for ``de_i2i_gan_amd.trainers.mae_trainer``; pinned
+against the reference itself by ``tests/golden/gen_mae_goldens.py``.  Same functional style as ``defectgan_oracle``
+(whose generator / discriminator / loss primitives it reuses); paths below are relative to ``/root/reference/defectGAN``.
+
+The step (trainers/mae_trainer.py:86-158): per iteration one discriminator update and one generator update on the SAME
+image batch, each drawing its own random patch mask;  D loss = mean(bce(D(G(masked)), 0), bce(D(x), 1)) + w_clf_D *
+bce(cls(x), labels);  G loss = bce(D(G(masked)), 1) + w_rec * l1(G(masked), x) + w_clf_G * bce(cls(G(masked)), labels);
+AdamW(betas (0.9, 0.95), weight decay 0.01) on D, and on G + the mask token."""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import defectgan_oracle as O
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------- #
+# patch masks (utils/util.py:48-71): 1 = keep, 0 = masked; drawn with the global torch RNG on the CPU
+# --------------------------------------------------------------------------- #
+def generate_mask(image_size, patch_size: int, mask_ratio: float) -> Tensor:
+    """utils/util.py:48-58 -- one Bernoulli(1 - mask_ratio) keep-bit per patch, nearest-upsampled to pixels."""
+    b, _, h, w = image_size
+    keep = torch.bernoulli(torch.full((b, 1, h // patch_size, w // patch_size), 1.0 - mask_ratio))
+    return F.interpolate(keep, scale_factor=patch_size, mode="nearest")
+
+
+def generate_shifted_mask(image_size, patch_size: int, mask_ratio: float) -> Tensor:
+    """utils/util.py:61-71 -- the patch grid is shifted by a random (h, w) offset below one patch: a mask one patch
+    larger is drawn and cropped.  RNG order: h shift, w shift, then the Bernoulli field."""
+    b, c, h, w = image_size
+    hs = int(torch.randint(low=0, high=patch_size, size=(1,)))
+    ws = int(torch.randint(low=0, high=patch_size, size=(1,)))
+    big = generate_mask((b, c, h + patch_size, w + patch_size), patch_size, mask_ratio)
+    return big[:, :, hs:hs + h, ws:ws + w]
+
+
+# --------------------------------------------------------------------------- #
+# mask token (models/networks/architecture.py:392-418)
+# --------------------------------------------------------------------------- #
+def mask_token_shape(kind: str, input_nc: int, image_size: int) -> Optional[Tuple[int, ...]]:
+    return {"zero": None, "mean": None, "scalar": (1, 1, 1, 1), "vector": (1, input_nc, 1, 1),
+            "position": (1, 1, image_size, image_size), "full": (1, input_nc, image_size, image_size)}[kind]
+
+
+def apply_mask_token(token: Optional[Tensor], imgs: Tensor, masks: Tensor, kind: str, mask_ratio: float) -> Tensor:
+    """architecture.py:410-418: kept pixels pass, masked pixels become the token ('mean': the per-image channel mean of
+    the kept pixels divided by mask_ratio, as the reference computes it; 'zero': 0)."""
+    masked = imgs * masks
+    if kind == "zero":
+        return masked
+    if kind == "mean":
+        m = masked.mean(dim=(2, 3)) / mask_ratio
+        return masked + m.reshape(m.shape[0], m.shape[1], 1, 1) * (1 - masks)
+    return masked + token * (1 - masks)
+
+
+# --------------------------------------------------------------------------- #
+# losses (models/defectgan_model.py:106-171, 361-383)
+# --------------------------------------------------------------------------- #
+def repair(SG, token, imgs, labels, masks, cfg, kind, mask_ratio, training):
+    seg = labels.reshape(labels.shape[0], labels.shape[1], 1, 1)
+    pred, _ = O.generator_forward(SG, apply_mask_token(token, imgs, masks, kind, mask_ratio), seg, cfg, training=training)
+    return pred
+
+
+def mae_generator_losses(SG, SD, token, imgs, labels, masks, cfg, kind="position", mask_ratio=0.75):
+    """_compute_mae_generator_loss (defectgan_model.py:106-131), G in train mode, D in eval mode -> (rec, gan, clf)."""
+    pred = repair(SG, token, imgs, labels, masks, cfg, kind, mask_ratio, training=True)
+    rec = O.l1(pred, imgs)
+    src, cls = O.discriminator_forward(SD, pred, cfg)
+    gan = O.bce_logits(src, torch.ones_like(src))
+    clf = O.bce_logits(cls, labels.view_as(cls))
+    return rec, gan, clf
+
+
+def mae_discriminator_losses(SG, SD, token, imgs, labels, masks, cfg, kind="position", mask_ratio=0.75):
+    """_compute_mae_discriminator_loss (defectgan_model.py:150-171), G in eval mode under no_grad -> (gan, clf)."""
+    real_src, real_cls = O.discriminator_forward(SD, imgs, cfg)
+    clf = O.bce_logits(real_cls, labels.view_as(real_cls))
+    with torch.no_grad():
+        pred = repair(SG, token, imgs, labels, masks, cfg, kind, mask_ratio, training=False)
+    fake_src, _ = O.discriminator_forward(SD, pred.detach(), cfg)
+    gan = torch.stack([O.bce_logits(fake_src, torch.zeros_like(fake_src)), O.bce_logits(real_src, torch.ones_like(real_src))]).mean()
+    return gan, clf
+
+
+# --------------------------------------------------------------------------- #
+# AdamW (torch.optim.AdamW single-tensor semantics; base_trainer.py:78-80: betas (0.9, 0.95), default weight decay 1e-2)
+# --------------------------------------------------------------------------- #
+def adamw_update(S: Dict[str, Tensor], grads: Dict[str, Optional[Tensor]], st: O.AdamState, lr: float,
+                 betas=(0.9, 0.95), eps: float = 1e-8, weight_decay: float = 1e-2) -> None:
+    b1, b2 = betas
+    with torch.no_grad():
+        for k, g in grads.items():
+            if g is None:
+                continue
+            p = S[k]
+            if k not in st.step:
+                st.step[k] = 0
+                st.m[k] = torch.zeros_like(p)
+                st.v[k] = torch.zeros_like(p)
+            st.step[k] += 1
+            t = st.step[k]
+            p.mul_(1 - lr * weight_decay)                      # decoupled decay first
+            st.m[k].lerp_(g, 1 - b1)
+            st.v[k].mul_(b2).addcmul_(g, g, value=1 - b2)
+            denom = (st.v[k].sqrt() / math.sqrt(1 - b2 ** t)).add_(eps)
+            p.addcdiv_(st.m[k], denom, value=-lr / (1 - b1 ** t))
+
+
+def step(SG, SD, token: Dict[str, Tensor], stG, stD, imgs, labels, masks_d, masks_g, cfg, *, lr=1.5e-4,
+         loss_weight=(10, 3, 1), kind="position", mask_ratio=0.75):
+    """One MAE iteration (mae_trainer.py:97-99, 124-158): D update, then G (+ mask token) update.  ``token`` is a
+    one-entry dict {'mask_token': tensor} (empty for the parameter-free kinds) so it shares the Adam bookkeeping."""
+    w_rec, w_clf_d, w_clf_g = loss_weight
+    tok = token.get("mask_token")
+    for k in O.param_keys(SD):
+        SD[k].requires_grad_(True)
+    d_gan, d_clf = mae_discriminator_losses(SG, SD, tok, imgs, labels, masks_d, cfg, kind, mask_ratio)
+    gD = O._grads(d_gan + d_clf * w_clf_d, SD)
+    adamw_update(SD, gD, stD, lr)
+    for k in O.param_keys(SG):
+        SG[k].requires_grad_(True)
+    if tok is not None:
+        tok.requires_grad_(True)
+    for k in O.param_keys(SD):
+        SD[k].requires_grad_(False)
+    rec, gan, clf = mae_generator_losses(SG, SD, tok, imgs, labels, masks_g, cfg, kind, mask_ratio)
+    g_loss = gan + rec * w_rec + clf * w_clf_g
+    both = dict(SG)
+    if tok is not None:
+        both["mask_token"] = tok
+    gG = O._grads(g_loss, both)
+    adamw_update(both, gG, stG, lr)
+    for k in O.param_keys(SD):
+        SD[k].requires_grad_(True)
+    return {"d_gan": float(d_gan), "d_clf": float(d_clf), "g_rec": float(rec), "g_gan": float(gan), "g_clf": float(clf)}, gD, gG

@@ -1,0 +1,71 @@
+"""GPU: the MAE-GAN pre-training step of the product (MAETrainer: mask token, shifted patch masks, mae_* loss graphs,
+fused AdamW through a GradScaler) against the fixtures captured from the reference's MAETrainer
+(tests/golden/gen_mae_goldens.py).  The masks come from the same seeded host RNG as the reference's.
+
+Tolerances: f32 mode -- iteration-1 losses 1e-4 (pure forward), iteration-2 losses 2e-2 (behind AdamW's sign-like first
+steps, see test_model_gpu.py), post-step parameter norms 1e-3; bf16 -- 2e-2 / 0.2 on these formula-filled tiny nets."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import formula_fill, make_opt
+from oracle import defectgan_oracle as O
+from test_mae_oracle_goldens import load
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def build(c, pname, grad_scaler=False):
+    from de_i2i_gan_amd.trainers.mae_trainer import MAETrainer
+    opt = make_opt(c, DEV, pname, grad_scaler=grad_scaler, optimizer="adamw", scheduler="cos", lr=[1.5e-4], lr_decay=0.05, loss_weight=[10, 3, 1],
+                   num_epochs=8, split_training=False, mask_token_type=c["mask_token_type"], mask_ratio=c["mask_ratio"],
+                   patch_size=c["patch_size"])
+    tr = MAETrainer(opt)
+    formula_fill(tr.model.netG)
+    formula_fill(tr.model.netD)
+    with torch.no_grad():
+        mt = tr.model.mask_token.mask_token
+        mt.copy_((O.formula_tensor("mask_token", tuple(mt.shape)) * 0.25).to(mt.device))
+    return tr
+
+
+@pytest.mark.parametrize("pname,grad_scaler", [("f32", False), ("f32", True), ("bf16", False)])
+@pytest.mark.parametrize("name", ["m0_img32_b2_position", "m1_img64_b2_vector"])
+def test_mae_two_iterations_match_reference_goldens(name, pname, grad_scaler):
+    """grad_scaler=True: the updates go through torch.amp.GradScaler like the reference's GPU path (loss x 2^16, fp32
+    gradients un-scaled before the fused AdamW): same numbers."""
+    meta, arr, c, cfg = load(name)
+    tr = build(c, pname, grad_scaler)
+    assert tr.scaler.is_enabled() == grad_scaler
+    assert abs(tr.optimizers["D"].param_groups[0]["lr"] - meta["lr_effective"]) < 1e-12      # cosine scheduler stepped once
+    assert len(tr.optimizers["G"].param_groups) == 2                                          # generator + mask token
+    imgs, labels, _ = O.synthetic_batch(c["batch"], c["image_size"])
+    torch.manual_seed(meta["seed"])
+    for it in range(2):
+        tr.step(imgs, labels)
+        L = tr.losses
+        got = np.array([L["gan"]["D"][-1], L["clf"]["D"][-1], L["rec"]["train"][-1], L["gan"]["G"][-1], L["clf"]["G"][-1]])
+        tol = ({"f32": 1e-4, "bf16": 2e-2} if it == 0 else {"f32": 2e-2, "bf16": 0.2})[pname]
+        assert np.max(np.abs(got - arr["losses"][it]) / np.abs(arr["losses"][it])) < tol, (it, got, arr["losses"][it])
+    if pname == "f32":
+        sd = tr.model.netD.state_dict()
+        mine = np.array([float(sd[k].double().norm()) for k in meta["D_check_keys"]])
+        assert np.max(np.abs(mine - arr["D_post_norm"]) / arr["D_post_norm"]) < 1e-3
+        tok = tr.model.mask_token.mask_token.detach().cpu().numpy()
+        assert np.abs(tok - arr["mask_token_post"]).max() < 2 * 2 * meta["lr_effective"] + 1e-6   # <= two sign-like steps apart
+
+
+def test_mae_inference_mode_and_mask_token_gradient():
+    meta, arr, c, cfg = load("m0_img32_b2_position")
+    tr = build(c, "f32")
+    imgs, labels, _ = O.synthetic_batch(c["batch"], c["image_size"])
+    torch.manual_seed(3)
+    rec, gan, clf = tr.model("mae_inference", imgs, labels)
+    assert not rec.requires_grad and all(np.isfinite([float(rec), float(gan), float(clf)]))
+    torch.manual_seed(3)
+    rec2, gan2, clf2 = tr.model("mae_generator", imgs, labels)
+    (gan2 + 10 * rec2 + clf2).backward()
+    g = tr.model.mask_token.mask_token.grad
+    assert g is not None and g.shape == (1, 1, 32, 32) and float(g.abs().sum()) > 0
+    assert all(p.grad is None for p in tr.model.netD.parameters())       # D's weight gradients are not computed in the G update
