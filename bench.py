@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--stage", default="defectgan", choices=["defectgan", "mae"],
                     help="mae: the MAE-GAN pre-training step (SURVEY.md section 8f rank 1) instead of the headline defectGAN step")
+    ap.add_argument("--use-spectral", action="store_true", help="the README recipes' --use_spectral (spectral-normalised convs)")
+    ap.add_argument("--add-noise", action="store_true", help="the README recipes' --add_noise (NoiseInjection after decoder convs)")
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=INT",
                     help="library option for A/B runs on one box, e.g. halo_conv=0 (dei2i_set_option)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child process of the default run
@@ -57,8 +59,9 @@ def make_opt(args, device):
                  split_training=False, mask_token_type="position", mask_ratio=0.75, patch_size=8) if mae else {}
     opt = SimpleNamespace(
         model="defectgan", num_res=6, cycle_gan=False, label_nc=6, skip_conn=False, ngf=64, ndf=64, input_nc=3,
-        use_spectral=False, num_scales=3 if s >= 512 else 2, style_norm_block_type="spade", hidden_nc=128,
-        style_distill=False, embed_nc=768, add_noise=False, num_layers=5 if s >= 128 else 4, image_size=s,
+        use_spectral=bool(getattr(args, "use_spectral", False)), num_scales=3 if s >= 512 else 2,
+        style_norm_block_type="spade", hidden_nc=128, style_distill=False, embed_nc=768,
+        add_noise=bool(getattr(args, "add_noise", False)), num_layers=5 if s >= 128 else 4, image_size=s,
         batch_size=args.batch, device=torch.device(device), is_train=True, clf_loss_type="bce", continue_training=False,
         load_model_name=None, init_type="normal", init_variance=0.02, phase="train", ckpt_dir=Path(tempfile.mkdtemp()),
         name="bench", iters_per_epoch=1000, num_epochs=-1, num_iters=10 ** 6, lr=[2e-4], optimizer="adam", scheduler="step",
@@ -236,7 +239,8 @@ def main():
                                 f"{args.image_size}x{args.image_size} RGB, batch {args.batch}/GPU, ngf=ndf=64 num_res=6 "
                                 f"num_layers={opt.num_layers} SPADE, AdamW(0.9,0.95) through GradScaler"),
                    "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                   "spade_path": "collapsed (5x5 border-class gamma/beta for 1x1 label maps)"},
+                   "spade_path": "collapsed (5x5 border-class gamma/beta for 1x1 label maps)",
+                   "use_spectral": bool(args.use_spectral), "add_noise": bool(args.add_noise)},
         "losses_last_step": {k: round(v[-1], 5) for kind in tr.losses.values() for k, v in kind.items() if v},
     }
     if fam:

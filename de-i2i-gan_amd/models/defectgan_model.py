@@ -76,7 +76,10 @@ class DefectGanModel(BaseModel):
         statistics (PatchGAN convs + LeakyReLU only, discriminator.py:60-90), so this is the same function as the
         reference's one call per batch -- with 2-4x fewer, 2-4x larger kernels on its small-M deep layers and one weight
         gradient per layer instead of one per call."""
-        if os.environ.get("DEI2I_SPLIT_D"):               # A/B switch: the reference's call-per-batch structure
+        # --use_spectral: every training-mode call runs one power iteration on D's (u, v), so the reference's four /
+        # two calls are NOT one call on the concatenation -- keep its call-per-batch structure then (eval mode is fine)
+        per_call_state = getattr(self.opt, "use_spectral", False) and self.netD.training
+        if os.environ.get("DEI2I_SPLIT_D") or per_call_state:     # (env: A/B switch)
             return [self.netD(t) for t in images]
         sizes = [t.shape[0] for t in images]
         src, cls = self.netD(torch.cat(images, 0))
@@ -178,7 +181,9 @@ class DefectGanModel(BaseModel):
         nm_labels, df_labels = self._get_labels(df_labels)
         self.netG.clear_spade_cache()
         with torch.no_grad():
-            if self.netG.training or os.environ.get("DEI2I_SPLIT_D"):
+            # (--add_noise: the reference draws one noise field per generator call; keep its two calls so that a seeded /
+            #  injected noise source is consumed exactly as the reference consumes it)
+            if self.netG.training or os.environ.get("DEI2I_SPLIT_D") or getattr(self.opt, "add_noise", False):
                 fake_defects, _ = self.netG(bg_data, df_labels)
                 fake_normals, _ = self.netG(df_data, nm_labels)
             else:

@@ -39,13 +39,20 @@ class Conv2d(nn.Module):
             raise NotImplementedError(f"padding_mode [{padding_mode}] is not implemented")
         self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding = in_channels, out_channels, k, s, pad
         self.padding_mode = padding_mode
-        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, k, k))
+        self._register_weight(torch.empty(out_channels, in_channels, k, k))
         self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
         self._packed = ops.PackedWeights()
         self.reset_parameters()
 
+    def _register_weight(self, w):
+        self.weight = nn.Parameter(w)
+
+    def effective_weight(self):
+        """-> (weight tensor the conv uses, the parameters / buffers its packed copies depend on)"""
+        return self.weight, (self.weight,)
+
     def reset_parameters(self):
-        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        nn.init.kaiming_uniform_(self._parameters.get("weight_orig", self._parameters.get("weight")), a=math.sqrt(5))
         if self.bias is not None:
             bound = 1 / math.sqrt(self.in_channels * self.kernel_size * self.kernel_size)
             nn.init.uniform_(self.bias, -bound, bound)
@@ -55,7 +62,8 @@ class Conv2d(nn.Module):
                             self.padding_mode == "reflect" and self.padding > 0, up)
 
     def forward(self, x, act="none", up=False):
-        return ops.conv2d(x, self.weight, self.bias, self._packed, self.geom(up), act)
+        w, sources = self.effective_weight()
+        return ops.conv2d(x, w, self.bias, self._packed, self.geom(up), act, sources=sources)
 
     def extra_repr(self):
         return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, "
@@ -94,6 +102,9 @@ class Act(nn.Module):
         super().__init__()
         self.name = name
 
+    def forward(self, x):
+        return x
+
     def extra_repr(self):
         return str(self.name)
 
@@ -108,15 +119,77 @@ def get_act_layer(act_str):
     raise NameError(f"activation layer named {act_str} not defined")
 
 
+class SpectralConv2d(Conv2d):
+    """torch.nn.utils.spectral_norm(nn.Conv2d(...)) as the reference applies it with ``--use_spectral``
+    (architecture.py:68-72,109-112,238-239,338-341): parameter ``weight_orig``, buffers ``weight_u`` / ``weight_v`` (same
+    state_dict keys), effective weight = weight_orig / sigma with sigma = u . (W v), W = weight_orig as a
+    (Cout, Cin*k*k) matrix; in training mode every forward first runs one power iteration on (u, v) in place (no grad),
+    in eval mode the stored vectors are used as they are.  The iteration and sigma are a handful of small fp32 torch
+    launches per forward (not fused into the weight-packing kernel yet); gradients flow to weight_orig through sigma by
+    autograd.  Like the reference's old-style hook, ``.weight`` is a derived tensor, so ``init_weights`` -- which writes
+    into ``m.weight.data`` -- leaves ``weight_orig`` at nn.Conv2d's default initialisation."""
+    EPS = 1e-12
+
+    def _register_weight(self, w):
+        self.weight_orig = nn.Parameter(w)
+        cout = w.shape[0]
+        self.register_buffer("weight_u", nn.functional.normalize(torch.randn(cout), dim=0, eps=self.EPS))
+        self.register_buffer("weight_v", nn.functional.normalize(torch.randn(w[0].numel()), dim=0, eps=self.EPS))
+
+    def _sigma_weight(self, iterate):
+        wmat = self.weight_orig.flatten(1)
+        u, v = self.weight_u, self.weight_v
+        if iterate:
+            with torch.no_grad():
+                v.copy_(nn.functional.normalize(torch.mv(wmat.t(), u), dim=0, eps=self.EPS))
+                u.copy_(nn.functional.normalize(torch.mv(wmat, v), dim=0, eps=self.EPS))
+            u, v = u.clone(), v.clone()            # the buffers are updated in place again by the next forward
+        sigma = torch.dot(u, torch.mv(wmat, v))
+        return self.weight_orig / sigma
+
+    @property
+    def weight(self):
+        return self._sigma_weight(False).detach()
+
+    def effective_weight(self):
+        w = self._sigma_weight(self.training)
+        w._dei2i_per_call = True          # derived anew per forward: the packed-weight cache keys on this tensor too
+        return w, (self.weight_orig, self.weight_u, self.weight_v)
+
+
+def make_conv(use_spectral, *args, **kw):
+    return (SpectralConv2d if use_spectral else Conv2d)(*args, **kw)
+
+
 def _is_batchnorm(norm_layer):
     return norm_layer is BatchNorm2d or norm_layer is nn.BatchNorm2d
 
 
+class NoiseInjection(nn.Module):
+    """x + weight * noise with one N(0,1) value per pixel, shared by the channels (architecture.py:374-389, the
+    'constant' weight type the blocks use).  Works on the NHWC activations: the noise is drawn as (N,1,H,W) like the
+    reference (device RNG, or ``ops.noise_source`` when a test injects it) and broadcast over the channel axis with plain
+    torch ops -- not fused into the producing conv's epilogue yet."""
+
+    def __init__(self):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(1, 1, 1, 1))
+
+    def forward(self, x, noise=None):
+        n, h, w, _ = x.shape
+        if noise is None:
+            noise = ops.draw_noise((n, 1, h, w), x.device)
+        noise = noise.to(device=x.device, dtype=x.dtype).reshape(n, h, w, 1)
+        return x + self.weight.reshape(1, 1, 1, 1).to(x.dtype) * noise
+
+
+def _noise(add_noise):
+    return NoiseInjection() if add_noise else Act(None)
+
+
 def _reject(use_spectral=False, add_noise=False):
-    if use_spectral:
-        raise NotImplementedError("use_spectral is not implemented yet (SURVEY.md section 8f rank 2)")
     if add_noise:
-        raise NotImplementedError("add_noise is not implemented yet (SURVEY.md section 8f rank 2)")
+        raise NotImplementedError("add_noise on this block is not used by the reference (generator.py:230-241)")
 
 
 class ConvBlock(nn.Module):
@@ -125,8 +198,7 @@ class ConvBlock(nn.Module):
     def __init__(self, f_in, f_out, kernel_size=(3, 3), stride=(1, 1), padding=0, padding_mode="zeros", bias=False,
                  norm_layer=None, act_layer=None, use_spectral=False):
         super().__init__()
-        _reject(use_spectral)
-        blocks = [Conv2d(f_in, f_out, kernel_size, stride, padding, padding_mode, bias)]
+        blocks = [make_conv(use_spectral, f_in, f_out, kernel_size, stride, padding, padding_mode, bias)]
         self._has_norm = norm_layer is not None
         if self._has_norm:
             if not _is_batchnorm(norm_layer):
@@ -157,7 +229,7 @@ class DeConvBlock(nn.Module):
         _reject(use_spectral, add_noise)
         if up_scale or norm_layer is not None:
             raise NotImplementedError("DeConvBlock with up_scale / norm is not on the reference hot path")
-        self.de_conv_block = nn.Sequential(Conv2d(f_in, f_out, kernel_size, stride, padding, padding_mode, bias),
+        self.de_conv_block = nn.Sequential(make_conv(use_spectral, f_in, f_out, kernel_size, stride, padding, padding_mode, bias),
                                            get_act_layer(act_layer))
 
     @property
@@ -270,19 +342,18 @@ class NormConvBlock(nn.Module):
                  kernel_size=(3, 3), stride=(1, 1), padding=0, padding_mode="zeros", bias=False, up_scale=False,
                  norm_layer=None, act_layer="relu", use_spectral=False, add_noise=False):
         super().__init__()
-        _reject(use_spectral, add_noise)
         if act_layer != "relu":
             raise NotImplementedError("NormConvBlock: the reference uses ReLU here")
         self.up_scale = up_scale
         self.up = Act("nearest x2" if up_scale else None)
-        self.noise = Act(None)
+        self.noise = _noise(add_noise)
         self.style_norm_block_type = style_norm_block_type
         self.norm = _style_norm(style_norm_block_type, label_nc, f_in, hidden_nc)
-        self.conv = Conv2d(f_in, f_out, kernel_size, stride, padding, padding_mode, bias)
+        self.conv = make_conv(use_spectral, f_in, f_out, kernel_size, stride, padding, padding_mode, bias)
         self.act = get_act_layer(act_layer)
 
     def forward(self, x, labels, style_feat=None):
-        return self.conv(self.norm(x, labels, up=self.up_scale))
+        return self.noise(self.conv(self.norm(x, labels, up=self.up_scale)))
 
 
 class NormResBlock(nn.Module):
@@ -293,27 +364,26 @@ class NormResBlock(nn.Module):
                  kernel_size=(3, 3), stride=(1, 1), padding=0, padding_mode="zeros", bias=False, up_scale=False,
                  norm_layer=None, act_layer="relu", use_spectral=False, add_noise=False):
         super().__init__()
-        _reject(use_spectral, add_noise)
         if up_scale:
             raise NotImplementedError("NormResBlock(up_scale=True) is not on the reference hot path")
         if act_layer != "relu":
             raise NotImplementedError("NormResBlock: the reference uses ReLU here")
         self.up_scale = False
         self.up = Act("nearest x2")
-        self.noise_0, self.noise_1 = Act(None), Act(None)
+        self.noise_0, self.noise_1 = _noise(add_noise), _noise(add_noise)
         f_mid = min(f_in, f_out)
         self.style_norm_block_type = style_norm_block_type
         self.norm_0 = _style_norm(style_norm_block_type, label_nc, f_in, hidden_nc)
         self.norm_1 = _style_norm(style_norm_block_type, label_nc, f_mid, hidden_nc)
         self.norm_s = _style_norm(style_norm_block_type, label_nc, f_in, hidden_nc)
         self.act = get_act_layer(act_layer)
-        self.conv_0 = Conv2d(f_in, f_mid, kernel_size, stride, padding, padding_mode, bias)
-        self.conv_1 = Conv2d(f_mid, f_out, kernel_size, stride, padding, padding_mode, bias)
-        self.conv_s = Conv2d(f_in, f_out, kernel_size, stride, padding, padding_mode, bias)
+        self.conv_0 = make_conv(use_spectral, f_in, f_mid, kernel_size, stride, padding, padding_mode, bias)
+        self.conv_1 = make_conv(use_spectral, f_mid, f_out, kernel_size, stride, padding, padding_mode, bias)
+        self.conv_s = make_conv(use_spectral, f_in, f_out, kernel_size, stride, padding, padding_mode, bias)
 
     def forward(self, x, labels, style_feat=None):
-        h = self.conv_0(self.norm_0(x, labels))
-        h = self.conv_1(self.norm_1(h, labels))
+        h = self.noise_0(self.conv_0(self.norm_0(x, labels)))
+        h = self.noise_1(self.conv_1(self.norm_1(h, labels)))
         return ops.add(h, x)
 
 

@@ -156,6 +156,16 @@ def _grad_target(param, shape, device):
     return t, t.data_ptr(), 0
 
 
+# ---- NoiseInjection's draw (architecture.py:385-389): N(0,1) on the activations' device; tests install a provider ----
+noise_source = None
+
+
+def draw_noise(shape, device):
+    if noise_source is not None:
+        return noise_source(tuple(shape))
+    return torch.randn(shape, device=device)
+
+
 _const_vecs = {}
 
 
@@ -204,8 +214,11 @@ class PackedWeights:
         return (t.data_ptr(), t._version, getattr(t, "_dei2i_epoch", 0))
 
     def get(self, weight: torch.Tensor, sources, prec: Precision, geom: ConvGeom, cins: int, couts: int, need_dgrad: bool,
-            need_fwd: bool = True):
-        key = (tuple(self._stamp(s) for s in sources), prec.code, cins, couts)
+            need_fwd: bool = True, per_call: bool = False):
+        # per_call: the weight is DERIVED from the sources anew on every forward and differs between calls whose sources
+        # carry the same stamps by the time backward runs (spectral norm: u, v are iterated in place by later forwards)
+        # -- its own address identifies the call
+        key = (tuple(self._stamp(s) for s in sources), prec.code, cins, couts, self._stamp(weight) if per_call else None)
         lib = _lib_for(weight)
         if key != self._key:
             self._key, self.fwd, self.dgrad, self.fp8 = key, None, None, None
@@ -228,7 +241,7 @@ class PackedWeights:
     def get_fp8(self, weight: torch.Tensor, sources, prec: Precision, geom: ConvGeom, cins: int, couts: int):
         """e4m3 forward weights (per-tensor scale 448 / amax|w|, computed on the device) and the dequant scalar
         1 / (activation scale * weight scale); cached with the same stamps as the bf16 copies."""
-        key = (tuple(self._stamp(s) for s in sources), prec.code, cins, couts)
+        key = (tuple(self._stamp(s) for s in sources), prec.code, cins, couts, None)
         if key != self._key:
             self._key, self.fwd, self.dgrad, self.fp8 = key, None, None, None
         if self.fp8 is None:
@@ -256,11 +269,12 @@ class _Conv2d(torch.autograd.Function):
         couts = prec.pad(geom.cout)
         lib = _lib_for(x)
         d = _desc(prec, geom, n, h, w, cins, couts)
-        use_fp8 = bool(_fp8_forward and prec is BF16 and lib.dei2i_conv2d_fp8_supported(byref(d)))
+        per_call = bool(getattr(weight, "_dei2i_per_call", False))
+        use_fp8 = bool(_fp8_forward and prec is BF16 and not per_call and lib.dei2i_conv2d_fp8_supported(byref(d)))
         # trainable weights: a backward pass of this optimizer step will want the dgrad layout too (also when THIS call
         # is the no-grad generator pass of the D step) -> both layouts in one pack launch
         wf = None if use_fp8 else cache.get(weight, sources, prec, geom, cins, couts,
-                                            need_dgrad=any(s_.requires_grad for s_ in sources))[0]
+                                            need_dgrad=any(s_.requires_grad for s_ in sources), per_call=per_call)[0]
         ho, wo = c_int(), c_int()
         lib.dei2i_conv2d_out_shape(byref(d), byref(ho), byref(wo))
         y = torch.empty((n, ho.value, wo.value, couts), dtype=prec.dtype, device=x.device)
@@ -282,7 +296,7 @@ class _Conv2d(torch.autograd.Function):
         else:
             L.check(lib.dei2i_conv2d_fwd(byref(d), _p(x), _p(wf), _p(b32), act, _p(y), _p(ws), ws.numel() * 4, _stream()),
                     "conv2d_fwd")
-        ctx.geom, ctx.act, ctx.cache, ctx.sources, ctx.prec = geom, act, cache, sources, prec
+        ctx.geom, ctx.act, ctx.cache, ctx.sources, ctx.prec, ctx.per_call = geom, act, cache, sources, prec, per_call
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, weight, y if act != L.ACT_NONE else None)
         return y
@@ -304,7 +318,8 @@ class _Conv2d(torch.autograd.Function):
             g = dy
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            _, wd = ctx.cache.get(weight, ctx.sources, prec, geom, cins, couts, need_dgrad=True, need_fwd=False)
+            _, wd = ctx.cache.get(weight, ctx.sources, prec, geom, cins, couts, need_dgrad=True, need_fwd=False,
+                                  per_call=ctx.per_call)
             ws = _workspace(x.device, lib.dei2i_conv2d_workspace_bytes(byref(d)))
             dx = torch.empty_like(x)
             ext = None

@@ -44,6 +44,8 @@ class Cfg:
     lr: float = 2e-4
     betas: Tuple[float, float] = (0.5, 0.999)           # trainers/base_trainer.py:75-77
     eps: float = 1e-8
+    use_spectral: bool = False                          # --use_spectral (architecture.py:68-72,109-112,238-239,338-341)
+    add_noise: bool = False                             # --add_noise (architecture.py:207-211,283-288,374-389)
 
 
 # --------------------------------------------------------------------------- #
@@ -180,10 +182,49 @@ def spade(S: Dict[str, Tensor], prefix: str, x: Tensor, seg: Tensor) -> Tensor:
 # --------------------------------------------------------------------------- #
 # blocks
 # --------------------------------------------------------------------------- #
+def weight_of(S: Dict[str, Tensor], key: str, training: bool) -> Tensor:
+    """The weight a conv uses.  Plain convs: S[key].  Under --use_spectral the conv was wrapped by
+    torch.nn.utils.spectral_norm (old-style hook): S holds key+'_orig', '_u', '_v' and the weight is
+    weight_orig / sigma, sigma = u . (W v) with W = weight_orig as a (Cout, Cin*kh*kw) matrix; a training-mode forward
+    first runs ONE power iteration v <- normalize(W^T u), u <- normalize(W v) in place, without gradient
+    (torch/nn/utils/spectral_norm.py, n_power_iterations=1, eps=1e-12)."""
+    if key in S:
+        return S[key]
+    w, u, v = S[key + "_orig"], S[key + "_u"], S[key + "_v"]
+    wm = w.flatten(1)
+    if training:
+        with torch.no_grad():
+            v.copy_(F.normalize(torch.mv(wm.t(), u), dim=0, eps=1e-12))
+            u.copy_(F.normalize(torch.mv(wm, v), dim=0, eps=1e-12))
+        u, v = u.clone(), v.clone()
+    return w / torch.dot(u, torch.mv(wm, v))
+
+
+# NoiseInjection draws image.new_empty(N,1,H,W).normal_() (architecture.py:385-389); the goldens replace the draw by a
+# deterministic provider so that reference, oracle and product see the same noise: NOISE_SOURCE(shape) -> tensor
+NOISE_SOURCE = None
+
+
+def shape_noise(shape) -> Tensor:
+    """The goldens' stand-in for the N(0,1) draw: an RNG-free tensor that depends on the shape only (so reference, oracle
+    and product agree whatever the order of their calls), roughly unit variance."""
+    return formula_tensor("noise" + "x".join(str(int(d)) for d in shape), tuple(shape)) * 1.7
+
+
+def inject_noise(S: Dict[str, Tensor], key: str, x: Tensor) -> Tensor:
+    """architecture.py:374-389: x + weight * noise, noise (N,1,H,W); identity when the block was built without
+    add_noise (no such key)."""
+    if key not in S:
+        return x
+    shape = (x.shape[0], 1, x.shape[2], x.shape[3])
+    noise = NOISE_SOURCE(shape) if NOISE_SOURCE is not None else torch.randn(shape)
+    return x + S[key] * noise.to(x.dtype)
+
+
 def conv_block_bn(S, prefix: str, x: Tensor, *, k: int, stride: int, pad: int, act: bool,
                   training: bool) -> Tensor:
     """architecture.py:79-118 ConvBlock: conv(no bias, reflect) -> BatchNorm2d -> [LeakyReLU]."""
-    y = conv2d(x, S[prefix + ".conv_block.0.weight"], stride=stride, pad=pad, mode="reflect")
+    y = conv2d(x, weight_of(S, prefix + ".conv_block.0.weight", training), stride=stride, pad=pad, mode="reflect")
     y = batchnorm(S, prefix + ".conv_block.1", y, training)
     return leaky_relu(y) if act else y
 
@@ -208,17 +249,20 @@ def generator_forward(S: Dict[str, Tensor], x: Tensor, labels: Tensor, cfg: Cfg,
     # NormResBlocks (up_scale=False: norm_s/conv_s never run) -- architecture.py:343-357
     for i in range(cfg.num_res // 2):
         p = f"dec_res_blk.{i}"
-        h = conv2d(relu(spade(S, p + ".norm_0", feat, labels)), S[p + ".conv_0.weight"],
+        h = conv2d(relu(spade(S, p + ".norm_0", feat, labels)), weight_of(S, p + ".conv_0.weight", training),
                    pad=1, mode="reflect")
-        h = conv2d(relu(spade(S, p + ".norm_1", h, labels)), S[p + ".conv_1.weight"],
+        h = inject_noise(S, p + ".noise_0.weight", h)
+        h = conv2d(relu(spade(S, p + ".norm_1", h, labels)), weight_of(S, p + ".conv_1.weight", training),
                    pad=1, mode="reflect")
+        h = inject_noise(S, p + ".noise_1.weight", h)
         feat = h + feat
     # NormConvBlocks: up -> SPADE -> ReLU -> conv -- architecture.py:241-245
     for i in range(cfg.num_scales):
         p = f"dec_blk.{i}"
         feat = upsample2x(feat)
-        feat = conv2d(relu(spade(S, p + ".norm", feat, labels)), S[p + ".conv.weight"],
+        feat = conv2d(relu(spade(S, p + ".norm", feat, labels)), weight_of(S, p + ".conv.weight", training),
                       pad=1, mode="reflect")
+        feat = inject_noise(S, p + ".noise.weight", feat)
     # NaN guard -- generator.py:266-267
     if torch.isnan(feat).any():
         feat = torch.nan_to_num(feat)
@@ -228,11 +272,13 @@ def generator_forward(S: Dict[str, Tensor], x: Tensor, labels: Tensor, cfg: Cfg,
     return out, prob
 
 
-def discriminator_forward(S: Dict[str, Tensor], x: Tensor, cfg: Cfg) -> Tuple[Tensor, Tensor]:
-    """DefectGanDiscriminator.forward -- discriminator.py:92-98; layers :60-90 (no norm anywhere)."""
+def discriminator_forward(S: Dict[str, Tensor], x: Tensor, cfg: Cfg, training: bool = False) -> Tuple[Tensor, Tensor]:
+    """DefectGanDiscriminator.forward -- discriminator.py:92-98; layers :60-90 (no norm anywhere).  ``training`` only
+    matters under --use_spectral (one power iteration per training-mode call; the two heads are never spectral)."""
     feat = x
     for i in range(cfg.num_layers + 1):
-        feat = leaky_relu(conv2d(feat, S[f"enc_blk.{i}.conv_block.0.weight"], stride=2, pad=1, mode="reflect"))
+        feat = leaky_relu(conv2d(feat, weight_of(S, f"enc_blk.{i}.conv_block.0.weight", training), stride=2, pad=1,
+                                 mode="reflect"))
     src = conv2d(feat, S["src_clf.conv_block.0.weight"], pad=1, mode="reflect")
     cls = conv2d(feat, S["cls_clf.conv_block.0.weight"])               # kernel = full extent, valid
     return src, cls.reshape(cls.shape[0], cls.shape[1])
@@ -269,10 +315,10 @@ def discriminator_losses(SG, SD, bg: Tensor, df_labels: Tensor, df: Tensor, cfg:
     with torch.no_grad():
         fake_defects, _ = generator_forward(SG, bg, df_l, cfg, training=False)
         fake_normals, _ = generator_forward(SG, df, nm_l, cfg, training=False)
-    fd_src, _ = discriminator_forward(SD, fake_defects, cfg)
-    fn_src, _ = discriminator_forward(SD, fake_normals, cfg)
-    rd_src, rd_cls = discriminator_forward(SD, df, cfg)
-    rn_src, rn_cls = discriminator_forward(SD, bg, cfg)
+    fd_src, _ = discriminator_forward(SD, fake_defects, cfg, training=True)      # netD.train(): 4 calls, in this order
+    fn_src, _ = discriminator_forward(SD, fake_normals, cfg, training=True)
+    rd_src, rd_cls = discriminator_forward(SD, df, cfg, training=True)
+    rn_src, rn_cls = discriminator_forward(SD, bg, cfg, training=True)
     ones, zeros = torch.ones_like(rd_src), torch.zeros_like(fd_src)
     gan = torch.stack([bce_logits(fd_src, zeros), bce_logits(fn_src, zeros),
                        bce_logits(rd_src, ones), bce_logits(rn_src, ones)]).mean()
@@ -342,7 +388,7 @@ def adam_update(S: Dict[str, Tensor], grads: Dict[str, Optional[Tensor]], st: Ad
 # --------------------------------------------------------------------------- #
 def param_keys(S: Dict[str, Tensor]) -> List[str]:
     return [k for k in S if not (k.endswith("running_mean") or k.endswith("running_var")
-                                 or k.endswith("num_batches_tracked"))]
+                                 or k.endswith("num_batches_tracked") or k.endswith("weight_u") or k.endswith("weight_v"))]
 
 
 def _grads(loss: Tensor, S: Dict[str, Tensor]) -> Dict[str, Optional[Tensor]]:
@@ -405,26 +451,40 @@ def generator_state_shapes(cfg: Cfg) -> Dict[str, Tuple[int, ...]]:
         sh[prefix + ".mlp_beta.weight"] = (c, cfg.hidden_nc, 3, 3)
         sh[prefix + ".mlp_beta.bias"] = (c,)
 
+    def conv(key, shape, spectral=None):
+        """spectral_norm'd convs hold weight_orig + the power-iteration vectors u (Cout) and v (Cin*kh*kw)"""
+        if cfg.use_spectral if spectral is None else spectral:
+            sh[key + "_orig"] = shape
+            sh[key + "_u"] = (shape[0],)
+            sh[key + "_v"] = (shape[1] * shape[2] * shape[3],)
+        else:
+            sh[key] = shape
+
     c = cfg.ngf
-    sh["stem.conv_block.0.weight"] = (c, cfg.input_nc, 7, 7)
+    conv("stem.conv_block.0.weight", (c, cfg.input_nc, 7, 7))
     bn("stem.conv_block.1", c)
     for i in range(cfg.num_scales):
-        sh[f"enc_blk.{i}.conv_block.0.weight"] = (2 * c, c, 4, 4)
+        conv(f"enc_blk.{i}.conv_block.0.weight", (2 * c, c, 4, 4))
         bn(f"enc_blk.{i}.conv_block.1", 2 * c)
         c *= 2
     for i in range(cfg.num_res // 2):
         for j in (0, 1):
-            sh[f"enc_res_blk.{i}.res_block.{j}.conv_block.0.weight"] = (c, c, 3, 3)
+            conv(f"enc_res_blk.{i}.res_block.{j}.conv_block.0.weight", (c, c, 3, 3))
             bn(f"enc_res_blk.{i}.res_block.{j}.conv_block.1", c)
     for i in range(cfg.num_res // 2):
         p = f"dec_res_blk.{i}"
+        if cfg.add_noise:
+            sh[f"{p}.noise_0.weight"] = (1, 1, 1, 1)
+            sh[f"{p}.noise_1.weight"] = (1, 1, 1, 1)
         for nm in ("norm_0", "norm_1", "norm_s"):
             sp(f"{p}.{nm}", c)
         for nm in ("conv_0", "conv_1", "conv_s"):
-            sh[f"{p}.{nm}.weight"] = (c, c, 3, 3)
+            conv(f"{p}.{nm}.weight", (c, c, 3, 3))
     for i in range(cfg.num_scales):
+        if cfg.add_noise:
+            sh[f"dec_blk.{i}.noise.weight"] = (1, 1, 1, 1)
         sp(f"dec_blk.{i}.norm", c)
-        sh[f"dec_blk.{i}.conv.weight"] = (c // 2, c, 3, 3)
+        conv(f"dec_blk.{i}.conv.weight", (c // 2, c, 3, 3))
         c //= 2
     sh["foreground_head.de_conv_block.0.weight"] = (3, c, 3, 3)
     sh["distribution_head.de_conv_block.0.weight"] = (1, c, 3, 3)
@@ -434,10 +494,16 @@ def generator_state_shapes(cfg: Cfg) -> Dict[str, Tuple[int, ...]]:
 def discriminator_state_shapes(cfg: Cfg) -> Dict[str, Tuple[int, ...]]:
     """Key -> shape manifest of DefectGanDiscriminator.state_dict() (discriminator.py:49-90)."""
     sh: Dict[str, Tuple[int, ...]] = {}
+    def conv(key, shape):
+        if cfg.use_spectral:
+            sh[key + "_orig"], sh[key + "_u"], sh[key + "_v"] = shape, (shape[0],), (shape[1] * shape[2] * shape[3],)
+        else:
+            sh[key] = shape
+
     c = cfg.ndf
-    sh["enc_blk.0.conv_block.0.weight"] = (c, cfg.input_nc, 4, 4)
+    conv("enc_blk.0.conv_block.0.weight", (c, cfg.input_nc, 4, 4))
     for i in range(cfg.num_layers):
-        sh[f"enc_blk.{i + 1}.conv_block.0.weight"] = (2 * c, c, 4, 4)
+        conv(f"enc_blk.{i + 1}.conv_block.0.weight", (2 * c, c, 4, 4))
         c *= 2
     ks = cfg.image_size // 2 ** (cfg.num_layers + 1)
     sh["cls_clf.conv_block.0.weight"] = (cfg.label_nc, c, ks, ks)

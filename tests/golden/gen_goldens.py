@@ -56,6 +56,11 @@ CONFIGS = {
     # per channel) makes every fp32 ReLU/L1 branch flip weigh more: the reference's fp32 G grad norms sit up to 16 %
     # from the oracle's fp32 ones, while an fp64 run of both agrees to 1e-9 on every key (checked when this config
     # was added: reference modules .double(), same losses to 1e-15).
+    # the README recipes' options: every ConvBlock / decoder conv under torch.nn.utils.spectral_norm (one power iteration
+    # per training-mode forward) and NoiseInjection after the decoder convs.  The noise draw is replaced by a
+    # deterministic, shape-keyed provider (shape_noise below) in reference, oracle and product alike.
+    "t3_img32_b2_sn_noise": dict(image_size=32, batch=2, num_layers=3, ngf=8, ndf=8, hidden_nc=16, use_spectral=True,
+                                 add_noise=True, tol_step2=8e-2, tol_gradnorm=0.3, tol_post=5e-2, tol_running=0.2),
     "t2_img64_s3_b2": dict(image_size=64, batch=2, num_layers=4, ngf=8, ndf=8, hidden_nc=16, num_scales=3,
                            tol_step2=8e-2, tol_gradnorm=0.3, tol_post=5e-2, tol_running=0.2),
 }
@@ -64,8 +69,8 @@ CONFIGS = {
 def make_opt(c):
     return SimpleNamespace(
         model="defectgan", num_res=6, cycle_gan=False, label_nc=6, skip_conn=False, ngf=c["ngf"], ndf=c["ndf"],
-        input_nc=3, use_spectral=False, num_scales=c.get("num_scales", 2), style_norm_block_type="spade", hidden_nc=c["hidden_nc"],
-        style_distill=False, embed_nc=768, add_noise=False, num_layers=c["num_layers"],
+        input_nc=3, use_spectral=c.get("use_spectral", False), num_scales=c.get("num_scales", 2), style_norm_block_type="spade", hidden_nc=c["hidden_nc"],
+        style_distill=False, embed_nc=768, add_noise=c.get("add_noise", False), num_layers=c["num_layers"],
         image_size=c["image_size"], batch_size=c["batch"], device=torch.device("cpu"), is_train=True,
         clf_loss_type="bce", continue_training=False, load_model_name=None, init_type="normal",
         init_variance=0.02, phase="train", ckpt_dir=Path(tempfile.mkdtemp()), name="golden",
@@ -101,7 +106,10 @@ def grad_norms(net):
             heads.append(np.zeros(4, np.float32))
         else:
             vals.append(float(p.grad.double().norm()))
-            heads.append(p.grad.flatten()[:4].float().numpy().copy())
+            h4 = np.zeros(4, np.float32)
+            g4 = p.grad.flatten()[:4].float().numpy()
+            h4[:g4.size] = g4                      # (noise weights have a single element)
+            heads.append(h4)
     return keys, np.array(vals), np.stack(heads)
 
 
@@ -127,9 +135,15 @@ def rel_dev(a, b, what, tol, floor=1e-4):
 
 def run_config(name, c):
     cfg = O.Cfg(image_size=c["image_size"], ngf=c["ngf"], ndf=c["ndf"], num_layers=c["num_layers"],
-                hidden_nc=c["hidden_nc"], num_scales=c.get("num_scales", 2))
+                hidden_nc=c["hidden_nc"], num_scales=c.get("num_scales", 2), use_spectral=c.get("use_spectral", False),
+                add_noise=c.get("add_noise", False))
     opt = make_opt(c)
     tr = DefectGanTrainer(opt)
+    if c.get("add_noise"):
+        # NoiseInjection draws image.new_empty(N,1,H,W).normal_(): from here on (the weights are initialised) every
+        # normal_() fill -- there is no other one on the step -- comes from the deterministic provider
+        torch.Tensor.normal_ = lambda self, mean=0.0, std=1.0, generator=None: self.copy_(O.shape_noise(tuple(self.shape)))
+        O.NOISE_SOURCE = O.shape_noise
     G, D = tr.model.netG, tr.model.netD
     fill(G)
     fill(D)
@@ -150,6 +164,7 @@ def run_config(name, c):
     seg = labels.reshape(c["batch"], 6, 1, 1)
     with torch.no_grad():
         G.eval()
+        D.eval()                      # (spectral norm: no power iteration here, the steps below start from the filled u, v)
         out_e, prob_e = G(bg, seg)
         src_e, cls_e = D(out_e)
         # spatial (2x2) label map: inference path (test_defectgan.py:221-228)
@@ -228,10 +243,13 @@ def run_config(name, c):
             arrays["bn::" + k] = v.numpy().copy()
             assert_close(SG[k], v, "running stat " + k, rtol=c.get("tol_running", 5e-2))
     # a few complete post-step tensors (small ones) for element-wise checks
+    def stored(sd, k):                                   # spectral convs keep their parameter under key + "_orig"
+        return sd[k] if k in sd else sd[k + "_orig"]
+
     for k in ("stem.conv_block.0.weight", "dec_blk.1.conv.weight", "foreground_head.de_conv_block.0.weight"):
-        arrays["Gp::" + k] = G.state_dict()[k].numpy().copy()
+        arrays["Gp::" + k] = stored(G.state_dict(), k).numpy().copy()
     for k in ("enc_blk.0.conv_block.0.weight", "src_clf.conv_block.0.weight"):
-        arrays["Dp::" + k] = D.state_dict()[k].numpy().copy()
+        arrays["Dp::" + k] = stored(D.state_dict(), k).numpy().copy()
 
     # ---- DDP-equivalent golden: world=2 micro-batches, grad accumulation, local BN ----
     world = 2

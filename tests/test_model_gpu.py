@@ -45,7 +45,9 @@ def check_fwd(got, ref, pname, bf16_rms=0.12):
 
 
 def build(c, pname, **over):
+    from de_i2i_gan_amd import ops
     from de_i2i_gan_amd.trainers.defectgan_trainer import DefectGanTrainer
+    ops.noise_source = O.shape_noise if c.get("add_noise") else None        # the goldens' stand-in for the N(0,1) draw
     tr = DefectGanTrainer(make_opt(c, DEV, pname, **over))
     formula_fill(tr.model.netG)
     formula_fill(tr.model.netD)
@@ -53,7 +55,7 @@ def build(c, pname, **over):
 
 
 @pytest.mark.parametrize("pname", ["f32", "bf16"])
-@pytest.mark.parametrize("name", ["t0_img32_b2", "t1_img64_b4", "t2_img64_s3_b2"])
+@pytest.mark.parametrize("name", ["t0_img32_b2", "t1_img64_b4", "t2_img64_s3_b2", "t3_img32_b2_sn_noise"])
 def test_forward_matches_reference_goldens(name, pname):
     meta, arr, c, cfg = load_golden(name)
     tr = build(c, pname)
@@ -62,13 +64,15 @@ def test_forward_matches_reference_goldens(name, pname):
     bg_d, lab_d = bg.to(DEV), labels.to(DEV)
     # bf16 on the formula-filled nets: the three-scale t2 net normalises over an 8x8 bottleneck (64 pixels per
     # instance-norm channel), which amplifies the 2^-9 activation rounding further than t0/t1 (measured 0.18 RMS)
-    check = functools.partial(check_fwd, bf16_rms=0.3 if c.get("num_scales", 2) == 3 else 0.12)
+    # (t3: spectral normalisation keeps the bf16 rms error small -- 0.08 -- but single output pixels deviate more)
+    check = functools.partial(check_fwd, bf16_rms=0.3 if (c.get("num_scales", 2) == 3 or c.get("use_spectral")) else 0.12)
     _forward_checks(G, D, tr, arr, c, bg, bg_d, lab_d, pname, check)
 
 
 def _forward_checks(G, D, tr, arr, c, bg, bg_d, lab_d, pname, check_fwd):
     with torch.no_grad():
         G.eval()
+        D.eval()                          # as in the golden script (spectral norm: no power iteration in eval mode)
         out, prob = G(bg_d, lab_d.reshape(c["batch"], 6, 1, 1))
         assert out.shape == (c["batch"], 3, c["image_size"], c["image_size"]) and out.dtype == torch.float32
         check_fwd(out, arr["G_out_eval"], pname)
@@ -150,7 +154,7 @@ def test_step_gradients_match_oracle_fp64(name, c, gtol):
 
 
 @pytest.mark.parametrize("pname", ["f32", "bf16"])
-@pytest.mark.parametrize("name", ["t0_img32_b2", "t1_img64_b4", "t2_img64_s3_b2"])
+@pytest.mark.parametrize("name", ["t0_img32_b2", "t1_img64_b4", "t2_img64_s3_b2", "t3_img32_b2_sn_noise"])
 def test_two_train_steps_match_reference_goldens(name, pname):
     meta, arr, c, cfg = load_golden(name)
     tr = build(c, pname)
@@ -163,7 +167,7 @@ def test_two_train_steps_match_reference_goldens(name, pname):
             dn = np.array([float(p.grad.double().norm()) for _, p in D.named_parameters()])
             assert [k for k, _ in D.named_parameters()] == meta["D_grad_keys"]
             # bf16: D sees G's fake images, i.e. the bf16 forward noise of the formula-filled G (0.12 RMS, 0.3 on t2)
-            dtol = 2e-3 if pname == "f32" else (0.3 if c.get("num_scales", 2) == 3 else 0.15)
+            dtol = 2e-3 if pname == "f32" else (0.3 if (c.get("num_scales", 2) == 3 or c.get("use_spectral")) else 0.15)
             assert np.max(np.abs(dn - arr["D_grad_norms_step1"]) / arr["D_grad_norms_step1"]) < dtol
         tr._train_generator_once(bg, labels, df)
         if it == 0:
@@ -202,7 +206,8 @@ def test_two_train_steps_match_reference_goldens(name, pname):
                 # (measured <= 0.09).  test_bf16_tracks_f32_with_reference_init covers the realistic case.
                 assert maxrel(sdg[k], arr["bn::" + k]) < 0.2, k
     for k in ("enc_blk.0.conv_block.0.weight", "src_clf.conv_block.0.weight"):
-        d = (sd[k].cpu() - torch.from_numpy(arr["Dp::" + k])).abs()
+        mine = sd[k] if k in sd else sd[k + "_orig"]          # spectral convs keep their parameter under key + "_orig"
+        d = (mine.cpu() - torch.from_numpy(arr["Dp::" + k])).abs()
         assert d.max().item() <= 5 * cfg.lr          # sign-like early Adam steps (|update| <= ~1.1 lr each): see test_oracle_goldens.py
 
 

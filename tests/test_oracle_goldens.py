@@ -10,7 +10,7 @@ import torch
 from oracle import defectgan_oracle as O
 
 GOLD = Path(__file__).resolve().parent / "golden"
-NAMES = ["t0_img32_b2", "t1_img64_b4", "t2_img64_s3_b2"]   # t2: num_scales=3, the 512x512 architecture
+NAMES = ["t0_img32_b2", "t1_img64_b4", "t2_img64_s3_b2", "t3_img32_b2_sn_noise"]   # t2: num_scales=3; t3: spectral norm + noise
 
 
 def load(name):
@@ -18,7 +18,9 @@ def load(name):
     arr = np.load(GOLD / f"{name}.npz")        # allow_pickle defaults to False
     c = meta["config"]
     cfg = O.Cfg(image_size=c["image_size"], ngf=c["ngf"], ndf=c["ndf"], num_layers=c["num_layers"],
-                hidden_nc=c["hidden_nc"], num_scales=c.get("num_scales", 2))
+                hidden_nc=c["hidden_nc"], num_scales=c.get("num_scales", 2), use_spectral=c.get("use_spectral", False),
+                add_noise=c.get("add_noise", False))
+    O.NOISE_SOURCE = O.shape_noise if c.get("add_noise") else None      # the goldens' deterministic stand-in for N(0,1)
     return meta, arr, c, cfg
 
 
@@ -32,7 +34,10 @@ def test_manifest_matches_reference_state_dict(name):
     meta, arr, c, cfg = load(name)
     assert list(O.generator_state_shapes(cfg).keys()) == meta["G_keys"]
     assert list(O.discriminator_state_shapes(cfg).keys()) == meta["D_keys"]
-    assert len(meta["G_keys"]) == 133 + 13 * (c.get("num_scales", 2) - 2)   # one more ConvBlock (6) + NormConvBlock (7) per scale
+    if not c.get("use_spectral"):
+        assert len(meta["G_keys"]) == 133 + 13 * (c.get("num_scales", 2) - 2)   # one more ConvBlock (6) + NormConvBlock (7) per scale
+    else:
+        assert len(meta["G_keys"]) == 181 and "stem.conv_block.0.weight_u" in meta["G_keys"]   # + u, v per spectral conv, + noise weights
 
 
 @pytest.mark.parametrize("name", NAMES)
