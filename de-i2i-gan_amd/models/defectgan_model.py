@@ -7,6 +7,7 @@ import torch
 from ..networks.architecture import MaskToken
 from ..networks.discriminator import DefectGanDiscriminator
 from ..networks.generator import DefectGanGenerator
+from ..utils.diffaug import diff_augment
 from ..utils.masks import draw_shifted_mask, expand_shifted_mask
 from .base_model import BaseModel
 
@@ -18,8 +19,6 @@ class DefectGanModel(BaseModel):
         assert image_size & (image_size - 1) == 0, "Image size must be a power of 2"
         if opt.style_norm_block_type != "spade":
             raise NotImplementedError("only style_norm_block_type='spade' (the reference default) is implemented")
-        if getattr(opt, "diff_aug", ""):
-            raise NotImplementedError("DiffAugment policies are not implemented yet (SURVEY.md section 8f rank 2)")
         self.netG = DefectGanGenerator(opt).to(opt.device, non_blocking=True)
         self.netD = DefectGanDiscriminator(opt).to(opt.device, non_blocking=True)
         if self.opt.is_train or hasattr(opt, "clf_loss_type"):
@@ -159,9 +158,10 @@ class DefectGanModel(BaseModel):
         d_params = [p for p in self.netD.parameters() if p.requires_grad]
         for p in d_params:
             p.requires_grad_(False)
+        policy = getattr(self.opt, "diff_aug", "")            # DiffAugment on what D sees (defectgan_model.py:200-203)
         try:
             (fake_defects_src, fake_defects_cls), (fake_normals_src, fake_normals_cls) = \
-                self._netD_batched(fake_defects, fake_normals)
+                self._netD_batched(diff_augment(fake_defects, policy), diff_augment(fake_normals, policy))
         finally:
             for p in d_params:
                 p.requires_grad_(True)
@@ -191,8 +191,11 @@ class DefectGanModel(BaseModel):
                 # InstanceNorm is per sample, so one pass over both batches is the same function as two passes
                 fakes, _ = self.netG(torch.cat([bg_data, df_data], 0), torch.cat([df_labels, nm_labels], 0))
                 fake_defects, fake_normals = fakes.split([bg_data.shape[0], df_data.shape[0]])
+        policy = getattr(self.opt, "diff_aug", "")            # defectgan_model.py:266-270: fakes first, then the real batches
+        fake_defects, fake_normals = diff_augment(fake_defects.detach(), policy), diff_augment(fake_normals.detach(), policy)
+        df_data, bg_data = diff_augment(df_data, policy), diff_augment(bg_data, policy)
         (fake_defects_src, _), (fake_normals_src, _), (real_defects_src, real_defects_cls), \
-            (real_normals_src, real_normals_cls) = self._netD_batched(fake_defects.detach(), fake_normals.detach(), df_data, bg_data)
+            (real_normals_src, real_normals_cls) = self._netD_batched(fake_defects, fake_normals, df_data, bg_data)
         gan_loss = [self._cal_loss(fake_defects_src, 0.0, "bce"), self._cal_loss(fake_normals_src, 0.0, "bce"),
                     self._cal_loss(real_defects_src, 1.0, "bce"), self._cal_loss(real_normals_src, 1.0, "bce")]
         clf_loss = [self._cal_loss(real_defects_cls, df_labels.view_as(real_defects_cls), self.clf_loss_type),

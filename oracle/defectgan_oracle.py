@@ -46,6 +46,7 @@ class Cfg:
     eps: float = 1e-8
     use_spectral: bool = False                          # --use_spectral (architecture.py:68-72,109-112,238-239,338-341)
     add_noise: bool = False                             # --add_noise (architecture.py:207-211,283-288,374-389)
+    diff_aug: str = ""                                  # --diff_aug policy list (utils/diffaug.py; defectgan_model.py:200-203,266-270)
 
 
 # --------------------------------------------------------------------------- #
@@ -308,6 +309,48 @@ def _labels(df_labels: Tensor) -> Tuple[Tensor, Tensor]:
     return nm.reshape(n, c, 1, 1), df_labels.reshape(n, c, 1, 1)
 
 
+# --------------------------------------------------------------------------- #
+# DiffAugment (utils/diffaug.py:9-76), restated per sample with slices; random draws from the global CPU RNG in the
+# reference's order: per policy function one draw of shape (N,1,1,1) floats or two draws of (N,1,1) integers
+# --------------------------------------------------------------------------- #
+def diff_augment(x: Tensor, policy: str) -> Tensor:
+    if not policy:
+        return x
+    n, _, h, w = x.shape
+    for name in policy.split(","):
+        if name == "color":
+            x = x + (torch.rand(n, 1, 1, 1) - 0.5)                                           # brightness
+            m = x.mean(dim=1, keepdim=True)
+            x = (x - m) * (torch.rand(n, 1, 1, 1) * 2) + m                                   # saturation
+            m = x.mean(dim=[1, 2, 3], keepdim=True)
+            x = (x - m) * (torch.rand(n, 1, 1, 1) + 0.5) + m                                 # contrast
+        elif name == "translation":
+            my, mx = int(h * 0.125 + 0.5), int(w * 0.125 + 0.5)
+            ty = torch.randint(-my, my + 1, size=[n, 1, 1]).flatten().tolist()
+            tx = torch.randint(-mx, mx + 1, size=[n, 1, 1]).flatten().tolist()
+            rows = []
+            for i in range(n):                       # out[i, :, r, c] = x[i, :, r + ty, c + tx], zero outside
+                o = torch.zeros_like(x[i])
+                r0, r1 = max(0, -ty[i]), min(h, h - ty[i])
+                c0, c1 = max(0, -tx[i]), min(w, w - tx[i])
+                if r1 > r0 and c1 > c0:
+                    o[:, r0:r1, c0:c1] = x[i, :, r0 + ty[i]:r1 + ty[i], c0 + tx[i]:c1 + tx[i]]
+                rows.append(o)
+            x = torch.stack(rows)
+        elif name == "cutout":
+            ch, cw = int(h * 0.5 + 0.5), int(w * 0.5 + 0.5)
+            cy = torch.randint(0, h + (1 - ch % 2), size=[n, 1, 1]).flatten().tolist()
+            cx = torch.randint(0, w + (1 - cw % 2), size=[n, 1, 1]).flatten().tolist()
+            keep = torch.ones(n, 1, h, w, dtype=x.dtype)
+            for i in range(n):
+                t, l = cy[i] - ch // 2, cx[i] - cw // 2
+                keep[i, :, max(0, t):max(0, min(h, t + ch)), max(0, l):max(0, min(w, l + cw))] = 0
+            x = x * keep
+        else:
+            raise KeyError(name)
+    return x
+
+
 def discriminator_losses(SG, SD, bg: Tensor, df_labels: Tensor, df: Tensor, cfg: Cfg):
     """DefectGanModel._compute_discriminator_loss -- defectgan_model.py:251-292.
     netD.train(); netG.eval() (:87-90) -> G's BatchNorm uses running stats."""
@@ -315,6 +358,8 @@ def discriminator_losses(SG, SD, bg: Tensor, df_labels: Tensor, df: Tensor, cfg:
     with torch.no_grad():
         fake_defects, _ = generator_forward(SG, bg, df_l, cfg, training=False)
         fake_normals, _ = generator_forward(SG, df, nm_l, cfg, training=False)
+    fake_defects, fake_normals = diff_augment(fake_defects, cfg.diff_aug), diff_augment(fake_normals, cfg.diff_aug)
+    df, bg = diff_augment(df, cfg.diff_aug), diff_augment(bg, cfg.diff_aug)          # defectgan_model.py:266-270
     fd_src, _ = discriminator_forward(SD, fake_defects, cfg, training=True)      # netD.train(): 4 calls, in this order
     fn_src, _ = discriminator_forward(SD, fake_normals, cfg, training=True)
     rd_src, rd_cls = discriminator_forward(SD, df, cfg, training=True)
@@ -335,8 +380,8 @@ def generator_losses(SG, SD, bg: Tensor, df_labels: Tensor, df: Tensor, cfg: Cfg
     recover_normals, rec_df_prob = generator_forward(SG, fake_defects, nm_l, cfg, training=True)
     fake_normals, nm_prob = generator_forward(SG, df, nm_l, cfg, training=True)
     recover_defects, rec_nm_prob = generator_forward(SG, fake_normals, df_l, cfg, training=True)
-    fd_src, fd_cls = discriminator_forward(SD, fake_defects, cfg)
-    fn_src, fn_cls = discriminator_forward(SD, fake_normals, cfg)
+    fd_src, fd_cls = discriminator_forward(SD, diff_augment(fake_defects, cfg.diff_aug), cfg)     # defectgan_model.py:200-205
+    fn_src, fn_cls = discriminator_forward(SD, diff_augment(fake_normals, cfg.diff_aug), cfg)
     ones = torch.ones_like(fd_src)
     gan = torch.stack([bce_logits(fd_src, ones), bce_logits(fn_src, ones)]).mean()
     clf = torch.stack([bce_logits(fd_cls, df_l.view_as(fd_cls)),

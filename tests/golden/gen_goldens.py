@@ -61,6 +61,9 @@ CONFIGS = {
     # deterministic, shape-keyed provider (shape_noise below) in reference, oracle and product alike.
     "t3_img32_b2_sn_noise": dict(image_size=32, batch=2, num_layers=3, ngf=8, ndf=8, hidden_nc=16, use_spectral=True,
                                  add_noise=True, tol_step2=8e-2, tol_gradnorm=0.3, tol_post=5e-2, tol_running=0.2),
+    # DiffAugment on everything the discriminator sees (host RNG: the seed below reproduces the draws)
+    "t4_img32_b2_diffaug": dict(image_size=32, batch=2, num_layers=3, ngf=8, ndf=8, hidden_nc=16,
+                                diff_aug="color,translation,cutout", tol_step2=8e-2, tol_gradnorm=0.3, tol_post=5e-2),
     "t2_img64_s3_b2": dict(image_size=64, batch=2, num_layers=4, ngf=8, ndf=8, hidden_nc=16, num_scales=3,
                            tol_step2=8e-2, tol_gradnorm=0.3, tol_post=5e-2, tol_running=0.2),
 }
@@ -75,7 +78,7 @@ def make_opt(c):
         clf_loss_type="bce", continue_training=False, load_model_name=None, init_type="normal",
         init_variance=0.02, phase="train", ckpt_dir=Path(tempfile.mkdtemp()), name="golden",
         iters_per_epoch=10, num_epochs=-1, num_iters=100, lr=[2e-4], optimizer="adam", scheduler="step",
-        lr_decay=5e-3, loss_weight=[2, 5, 5, 5, 1], num_critics=1, diff_aug="", sean_alpha=None,
+        lr_decay=5e-3, loss_weight=[2, 5, 5, 5, 1], num_critics=1, diff_aug=c.get("diff_aug", ""), sean_alpha=None,
         use_running_stats=False, save_latest_freq=10 ** 9)
 
 
@@ -136,7 +139,7 @@ def rel_dev(a, b, what, tol, floor=1e-4):
 def run_config(name, c):
     cfg = O.Cfg(image_size=c["image_size"], ngf=c["ngf"], ndf=c["ndf"], num_layers=c["num_layers"],
                 hidden_nc=c["hidden_nc"], num_scales=c.get("num_scales", 2), use_spectral=c.get("use_spectral", False),
-                add_noise=c.get("add_noise", False))
+                add_noise=c.get("add_noise", False), diff_aug=c.get("diff_aug", ""))
     opt = make_opt(c)
     tr = DefectGanTrainer(opt)
     if c.get("add_noise"):
@@ -198,7 +201,9 @@ def run_config(name, c):
     # ---- two consecutive D+G steps through the reference trainer ----
     stG, stD = O.AdamState(), O.AdamState()
     ref_losses, ora_losses = [], []
+    meta["step_seed"] = 4100          # iteration `it` runs under torch.manual_seed(step_seed + it) (DiffAugment's host draws)
     for it in range(2):
+        torch.manual_seed(meta["step_seed"] + it)
         tr._train_discriminator_once(bg, labels, df)
         if it == 0:
             k, v, h = grad_norms(D)
@@ -212,6 +217,7 @@ def run_config(name, c):
         L = tr.losses
         ref_losses.append([L["gan"]["D"][-1], L["clf"]["D"][-1], L["gan"]["G"][-1], L["clf"]["G"][-1],
                            L["aux"]["rec"][-1], L["aux"]["cyc"][-1], L["aux"]["con"][-1]])
+        torch.manual_seed(meta["step_seed"] + it)              # the oracle consumes the RNG in the same order (D step, G step)
         ol, gD, gG = O.step(SG, SD, stG, stD, bg, labels, df, cfg)
         ora_losses.append([ol[k] for k in ("d_gan", "d_clf", "g_gan", "g_clf", "g_rec", "g_cyc", "g_con")])
         if it == 0:

@@ -18,7 +18,7 @@ def load_golden(name):
     c = meta["config"]
     cfg = O.Cfg(image_size=c["image_size"], ngf=c["ngf"], ndf=c["ndf"], num_layers=c["num_layers"], hidden_nc=c["hidden_nc"],
                 num_scales=c.get("num_scales", 2), use_spectral=c.get("use_spectral", False),
-                add_noise=c.get("add_noise", False))
+                add_noise=c.get("add_noise", False), diff_aug=c.get("diff_aug", ""))
     O.NOISE_SOURCE = O.shape_noise if c.get("add_noise") else None      # the goldens' deterministic stand-in for N(0,1)
     return meta, arr, c, cfg
 
@@ -32,7 +32,7 @@ def make_opt(c, device, compute_dtype="f32", **over):
         batch_size=c["batch"], device=torch.device(device), is_train=True, clf_loss_type="bce", continue_training=False,
         load_model_name=None, init_type="normal", init_variance=0.02, phase="train", ckpt_dir=Path(tempfile.mkdtemp()),
         name="t", iters_per_epoch=10, num_epochs=-1, num_iters=100, lr=[2e-4], optimizer="adam", scheduler="step",
-        lr_decay=5e-3, loss_weight=[2, 5, 5, 5, 1], num_critics=1, diff_aug="", sean_alpha=None, use_running_stats=False,
+        lr_decay=5e-3, loss_weight=[2, 5, 5, 5, 1], num_critics=1, diff_aug=c.get("diff_aug", ""), sean_alpha=None, use_running_stats=False,
         save_latest_freq=10 ** 9, compute_dtype=compute_dtype)
     for k, v in over.items():
         setattr(opt, k, v)
