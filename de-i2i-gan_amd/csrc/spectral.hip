@@ -1,0 +1,204 @@
+// Spectral normalisation of a conv weight (torch.nn.utils.spectral_norm as the reference applies it with --use_spectral,
+// architecture.py:68-72,109-112,238-239,338-341), W = weight_orig viewed as a (Cout, K) fp32 matrix, K = Cin*kh*kw:
+//   training forward:  t = W^T u;  v = t / max(|t|, eps);  s = W v;  u = s / max(|s|, eps);  sigma = u . s
+//   eval forward    :  s = W v;  sigma = u . s            (stored u, v as they are)
+//   w_eff = W / sigma
+//   backward (u, v constants):  dW = G / sigma - (sum(G . W) / sigma^2) * u v^T
+// As plain torch ops this is ~14 small launches per conv forward and ~11 per backward (3 000 launches per step with the
+// README recipe options); here it is 5 / 3 launches forward and 2 backward, all reductions in a fixed order
+// (deterministic).  The in-place (u, v) buffers are updated by the kernels; the vectors sigma was computed with are also
+// written to u_used / v_used, which the backward pass reads (later forwards iterate the buffers again).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dei2i_hip.h"
+#include "common.h"
+#include "launch.h"
+
+namespace dei2i {
+
+constexpr float SN_EPS = 1e-12f;
+constexpr int SN_COLS = 64;             // columns per workgroup of the W^T u pass
+
+DEI2I_D float sn_block_sum(float v, float* red) {       // 256 threads, fixed order
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// t[k] = sum_r W[r][k] u[r]; part[blockIdx.x] = sum over this block's columns of t[k]^2.
+// 64 columns per workgroup, the rows dealt to its four waves (wave g takes rows g, g+4, ...): four times the
+// workgroups of a 256-column strip (K = 2304 is only 9 strips) and every wave still reads 256 contiguous bytes per row.
+__global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* __restrict__ W, const float* __restrict__ u, int Cout, int K,
+                                                      float* __restrict__ t, float* __restrict__ part) {
+  __shared__ float acc4[4][SN_COLS];
+  __shared__ float red[4];
+  const int col = threadIdx.x & (SN_COLS - 1), g = threadIdx.x / SN_COLS;
+  const int k = blockIdx.x * SN_COLS + col;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (k < K) {
+    int r = g;
+    for (; r + 12 < Cout; r += 16) {
+      a0 = fmaf(W[(size_t)r * K + k], u[r], a0);
+      a1 = fmaf(W[(size_t)(r + 4) * K + k], u[r + 4], a1);
+      a2 = fmaf(W[(size_t)(r + 8) * K + k], u[r + 8], a2);
+      a3 = fmaf(W[(size_t)(r + 12) * K + k], u[r + 12], a3);
+    }
+    for (; r < Cout; r += 4) a0 = fmaf(W[(size_t)r * K + k], u[r], a0);
+  }
+  acc4[g][col] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  float tk = 0.f;
+  if (g == 0) {
+    tk = (acc4[0][col] + acc4[1][col]) + (acc4[2][col] + acc4[3][col]);
+    if (k < K) t[k] = tk; else tk = 0.f;
+  }
+  const float s = sn_block_sum(tk * tk, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// out[i] = in[i] / max(sqrt(sum part), eps), written to both destinations; scal[slot] = that norm.  Every workgroup sums
+// the partials itself with the same fixed pattern (strided per thread, then the block tree), so all agree bit for bit.
+__global__ __launch_bounds__(256) void sn_normalize_kernel(const float* __restrict__ in, const float* __restrict__ part, int nparts,
+                                                           int n, float* __restrict__ dst_a, float* __restrict__ dst_b,
+                                                           float* __restrict__ scal, int slot, int write_sigma) {
+  __shared__ float red[4];
+  float p = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) p += part[i];
+  const float tot = sn_block_sum(p, red);
+  const float norm = sqrtf(tot);
+  const float inv = 1.f / fmaxf(norm, SN_EPS);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float v = in[i] * inv;
+    dst_a[i] = v;
+    dst_b[i] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    scal[slot] = norm;
+    if (write_sigma) scal[2] = tot * inv;                  // sigma = u . s with u = s / max(|s|, eps)
+  }
+}
+
+// s[r] = sum_k W[r][k] v[k]  (one workgroup per row); part[r] = s[r]^2 (training) or u[r] * s[r] (eval: sigma partials)
+__global__ __launch_bounds__(256) void sn_w_v_kernel(const float* __restrict__ W, const float* __restrict__ v, const float* __restrict__ u,
+                                                     int K, float* __restrict__ s, float* __restrict__ part, int eval_mode) {
+  __shared__ float red[4];
+  const int r = blockIdx.x;
+  const float* row = W + (size_t)r * K;
+  float a0 = 0.f, a1 = 0.f;
+  int k = threadIdx.x;
+  for (; k + 256 < K; k += 512) {
+    a0 = fmaf(row[k], v[k], a0);
+    a1 = fmaf(row[k + 256], v[k + 256], a1);
+  }
+  if (k < K) a0 = fmaf(row[k], v[k], a0);
+  const float sr = sn_block_sum(a0 + a1, red);
+  if (threadIdx.x == 0) {
+    s[r] = sr;
+    part[r] = eval_mode ? u[r] * sr : sr * sr;
+  }
+}
+
+// eval mode: scal[2] = sigma = sum part; also copy the stored vectors into u_used / v_used
+__global__ __launch_bounds__(256) void sn_eval_sigma_kernel(const float* __restrict__ part, int Cout, const float* __restrict__ u,
+                                                            const float* __restrict__ v, int K, float* __restrict__ u_used,
+                                                            float* __restrict__ v_used, float* __restrict__ scal) {
+  __shared__ float red[4];
+  if (blockIdx.x == 0) {
+    float p = 0.f;
+    for (int i = threadIdx.x; i < Cout; i += 256) p += part[i];
+    const float tot = sn_block_sum(p, red);
+    if (threadIdx.x == 0) scal[2] = tot;
+  }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Cout + K; i += gridDim.x * blockDim.x) {
+    if (i < Cout) u_used[i] = u[i];
+    else v_used[i - Cout] = v[i - Cout];
+  }
+}
+
+__global__ void sn_scale_kernel(const float* __restrict__ W, const float* __restrict__ scal, size_t n, float* __restrict__ out) {
+  const float inv = 1.f / scal[2];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = W[i] * inv;
+}
+
+// part[block] = sum over the block's elements of G . W_eff   (W_eff = W / sigma, so sum(G.W) = sigma * sum(G.W_eff))
+__global__ __launch_bounds__(256) void sn_bwd_dot_kernel(const float* __restrict__ G, const float* __restrict__ Weff, size_t n,
+                                                         float* __restrict__ part) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a = fmaf(G[i], Weff[i], a);
+  const float s = sn_block_sum(a, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// dW[r][k] = (G[r][k] - c * u[r] v[k]) / sigma,  c = sum(G . W_eff)
+__global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restrict__ G, const float* __restrict__ part, int nparts,
+                                                           const float* __restrict__ scal, const float* __restrict__ u,
+                                                           const float* __restrict__ v, int Cout, int K, float* __restrict__ dW) {
+  __shared__ float red[4];
+  float p = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) p += part[i];
+  const float c = sn_block_sum(p, red);
+  const float inv = 1.f / scal[2];
+  const size_t n = (size_t)Cout * K;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / K), k = (int)(i - (size_t)r * K);
+    dW[i] = (G[i] - c * u[r] * v[k]) * inv;
+  }
+}
+
+static inline int sn_dot_blocks(size_t n) {
+  size_t b = n / 4096;
+  return (int)(b < 1 ? 1 : (b > 256 ? 256 : b));
+}
+
+}  // namespace dei2i
+
+using namespace dei2i;
+
+extern "C" {
+
+size_t dei2i_spectral_scratch_floats(int Cout, int K) { return (size_t)K + Cout + (size_t)((K + SN_COLS - 1) / SN_COLS) + Cout + 256; }
+
+int dei2i_spectral_fwd(int Cout, int K, const float* W, float* u, float* v, int iterate, float* scratch, float* u_used,
+                       float* v_used, float* scal, float* w_eff, dei2i_stream s) {
+  if (Cout <= 0 || K <= 0 || !W || !u || !v || !scratch || !u_used || !v_used || !scal || !w_eff) return DEI2I_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)s;
+  const int cb = (K + SN_COLS - 1) / SN_COLS;
+  float* t = scratch;                    // K
+  float* sv = scratch + K;               // Cout
+  float* part_t = sv + Cout;             // cb
+  float* part_s = part_t + cb;           // Cout
+  if (iterate) {
+    hipLaunchKernelGGL(sn_wt_u_kernel, dim3(cb), dim3(256), 0, st, W, (const float*)u, Cout, K, t, part_t);
+    hipLaunchKernelGGL(sn_normalize_kernel, dim3((K + 255) / 256 > 64 ? 64 : (K + 255) / 256), dim3(256), 0, st, (const float*)t,
+                       (const float*)part_t, cb, K, v, v_used, scal, 0, 0);
+    hipLaunchKernelGGL(sn_w_v_kernel, dim3(Cout), dim3(256), 0, st, W, (const float*)v_used, (const float*)u, K, sv, part_s, 0);
+    hipLaunchKernelGGL(sn_normalize_kernel, dim3((Cout + 255) / 256 > 64 ? 64 : (Cout + 255) / 256), dim3(256), 0, st,
+                       (const float*)sv, (const float*)part_s, Cout, Cout, u, u_used, scal, 1, 1);
+  } else {
+    hipLaunchKernelGGL(sn_w_v_kernel, dim3(Cout), dim3(256), 0, st, W, (const float*)v, (const float*)u, K, sv, part_s, 1);
+    hipLaunchKernelGGL(sn_eval_sigma_kernel, dim3(((Cout + K + 255) / 256) > 64 ? 64 : (Cout + K + 255) / 256), dim3(256), 0, st,
+                       (const float*)part_s, Cout, (const float*)u, (const float*)v, K, u_used, v_used, scal);
+  }
+  const size_t n = (size_t)Cout * K;
+  hipLaunchKernelGGL(sn_scale_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, W, (const float*)scal, n, w_eff);
+  return (int)hipGetLastError();
+}
+
+int dei2i_spectral_bwd(int Cout, int K, const float* G, const float* w_eff, const float* u_used, const float* v_used,
+                       const float* scal, float* scratch, float* dW, dei2i_stream s) {
+  if (Cout <= 0 || K <= 0 || !G || !w_eff || !u_used || !v_used || !scal || !scratch || !dW) return DEI2I_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)s;
+  const size_t n = (size_t)Cout * K;
+  const int nb = sn_dot_blocks(n);
+  hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(nb), dim3(256), 0, st, G, w_eff, n, scratch);
+  hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, G, (const float*)scratch, nb, scal, u_used, v_used,
+                     Cout, K, dW);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

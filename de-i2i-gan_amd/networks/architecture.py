@@ -124,9 +124,9 @@ class SpectralConv2d(Conv2d):
     (architecture.py:68-72,109-112,238-239,338-341): parameter ``weight_orig``, buffers ``weight_u`` / ``weight_v`` (same
     state_dict keys), effective weight = weight_orig / sigma with sigma = u . (W v), W = weight_orig as a
     (Cout, Cin*k*k) matrix; in training mode every forward first runs one power iteration on (u, v) in place (no grad),
-    in eval mode the stored vectors are used as they are.  The iteration and sigma are a handful of small fp32 torch
-    launches per forward (not fused into the weight-packing kernel yet); gradients flow to weight_orig through sigma by
-    autograd.  Like the reference's old-style hook, ``.weight`` is a derived tensor, so ``init_weights`` -- which writes
+    in eval mode the stored vectors are used as they are.  Iteration, sigma and the scaled weight run as 5 (eval: 3)
+    small HIP launches per forward and 2 per backward (``ops.spectral_weight``, csrc/spectral.hip; dW_orig =
+    (G - sum(G . w_eff) u v^T) / sigma).  Like the reference's old-style hook, ``.weight`` is a derived tensor, so ``init_weights`` -- which writes
     into ``m.weight.data`` -- leaves ``weight_orig`` at nn.Conv2d's default initialisation."""
     EPS = 1e-12
 
@@ -137,7 +137,9 @@ class SpectralConv2d(Conv2d):
         self.register_buffer("weight_v", nn.functional.normalize(torch.randn(w[0].numel()), dim=0, eps=self.EPS))
 
     def _sigma_weight(self, iterate):
-        wmat = self.weight_orig.flatten(1)
+        if self.weight_orig.is_cuda:          # fused kernels (csrc/spectral.hip): 5 / 3 launches forward, 2 backward
+            return ops.spectral_weight(self.weight_orig, self.weight_u, self.weight_v, iterate)
+        wmat = self.weight_orig.flatten(1)    # host tensors (construction / state inspection on the CPU): plain torch
         u, v = self.weight_u, self.weight_v
         if iterate:
             with torch.no_grad():
@@ -149,7 +151,8 @@ class SpectralConv2d(Conv2d):
 
     @property
     def weight(self):
-        return self._sigma_weight(False).detach()
+        with torch.no_grad():
+            return self._sigma_weight(False)
 
     def effective_weight(self):
         w = self._sigma_weight(self.training)

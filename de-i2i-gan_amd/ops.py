@@ -156,6 +156,49 @@ def _grad_target(param, shape, device):
     return t, t.data_ptr(), 0
 
 
+# ---- spectral normalisation of a conv weight (csrc/spectral.hip) --------------------------------------------------
+class _SpectralWeight(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weight_orig, u, v, iterate: bool):
+        _require_gpu(weight_orig, "spectral_weight")
+        w = weight_orig.detach()
+        if w.dtype != torch.float32 or not w.is_contiguous():
+            raise TypeError("spectral_weight expects a contiguous fp32 weight")
+        cout, k = w.shape[0], w[0].numel()
+        lib = _lib_for(w)
+        dev = w.device
+        scratch = torch.empty(lib.dei2i_spectral_scratch_floats(cout, k), dtype=torch.float32, device=dev)
+        u_used = torch.empty(cout, dtype=torch.float32, device=dev)
+        v_used = torch.empty(k, dtype=torch.float32, device=dev)
+        scal = torch.empty(4, dtype=torch.float32, device=dev)
+        w_eff = torch.empty_like(w)
+        L.check(lib.dei2i_spectral_fwd(cout, k, _p(w), _p(u), _p(v), 1 if iterate else 0, _p(scratch), _p(u_used), _p(v_used),
+                                       _p(scal), _p(w_eff), _stream()), "spectral_fwd")
+        if iterate:                      # the buffers were updated in place through raw pointers: bump their cache stamps
+            u._dei2i_epoch = getattr(u, "_dei2i_epoch", 0) + 1
+            v._dei2i_epoch = getattr(v, "_dei2i_epoch", 0) + 1
+        ctx.save_for_backward(w_eff, u_used, v_used, scal)
+        return w_eff
+
+    @staticmethod
+    def backward(ctx, g):
+        w_eff, u_used, v_used, scal = ctx.saved_tensors
+        g = g.contiguous()
+        cout, k = w_eff.shape[0], w_eff[0].numel()
+        lib = _lib_for(w_eff)
+        scratch = torch.empty(256, dtype=torch.float32, device=g.device)
+        dw = torch.empty_like(w_eff)
+        L.check(lib.dei2i_spectral_bwd(cout, k, _p(g), _p(w_eff), _p(u_used), _p(v_used), _p(scal), _p(scratch), _p(dw), _stream()),
+                "spectral_bwd")
+        return dw, None, None, None
+
+
+def spectral_weight(weight_orig, u, v, iterate: bool):
+    """weight_orig / sigma(weight_orig, u, v) with torch.nn.utils.spectral_norm's semantics; ``iterate`` runs one power
+    iteration on the (u, v) buffers in place first (training mode)."""
+    return _SpectralWeight.apply(weight_orig, u, v, bool(iterate))
+
+
 # ---- NoiseInjection's draw (architecture.py:385-389): N(0,1) on the activations' device; tests install a provider ----
 noise_source = None
 

@@ -207,6 +207,17 @@ int dei2i_adam_step(const dei2i_adam_rec* table_dev, int count, int64_t max_n, f
                     float eps, float bias_c1, float bias_c2_sqrt, float grad_scale, float decoupled_decay, dei2i_stream s);
 /* decoupled_decay: AdamW's weight decay (p *= 1 - lr*decay before the Adam update); 0 = torch.optim.Adam */
 
+/* ---- spectral normalisation of a conv weight (--use_spectral; torch.nn.utils.spectral_norm semantics, one power
+ * iteration per training-mode forward) ----  W = weight_orig as a (Cout, K) fp32 matrix, u (Cout) / v (K) the module's
+ * buffers (updated in place when iterate != 0); u_used / v_used receive the vectors sigma was computed with (the backward
+ * pass needs them: later forwards iterate the buffers again); scal: 4 floats (|W^T u|, |W v|, sigma, -); w_eff = W / sigma.
+ * backward: dW = (G - sum(G . w_eff) * u v^T) / sigma.  scratch: dei2i_spectral_scratch_floats(Cout, K) floats. */
+size_t dei2i_spectral_scratch_floats(int Cout, int K);
+int dei2i_spectral_fwd(int Cout, int K, const float* W, float* u, float* v, int iterate, float* scratch, float* u_used,
+                       float* v_used, float* scal, float* w_eff, dei2i_stream s);
+int dei2i_spectral_bwd(int Cout, int K, const float* G, const float* w_eff, const float* u_used, const float* v_used,
+                       const float* scal, float* scratch, float* dW, dei2i_stream s);
+
 /* ---- in-library kernel timing (bench.py roofline leg): HIP events around every launch of one kernel family ---- */
 #define DEI2I_PROF_GATHER_GEMM 0  /* the other conv forward / dgrad kernels: gather GEMM v1 / v2, thin convs */
 #define DEI2I_PROF_WGRAD 1
