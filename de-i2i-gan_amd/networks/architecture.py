@@ -136,26 +136,20 @@ class SpectralConv2d(Conv2d):
         self.register_buffer("weight_u", nn.functional.normalize(torch.randn(cout), dim=0, eps=self.EPS))
         self.register_buffer("weight_v", nn.functional.normalize(torch.randn(w[0].numel()), dim=0, eps=self.EPS))
 
-    def _sigma_weight(self, iterate):
-        if self.weight_orig.is_cuda:          # fused kernels (csrc/spectral.hip): 5 / 3 launches forward, 2 backward
-            return ops.spectral_weight(self.weight_orig, self.weight_u, self.weight_v, iterate)
-        wmat = self.weight_orig.flatten(1)    # host tensors (construction / state inspection on the CPU): plain torch
-        u, v = self.weight_u, self.weight_v
-        if iterate:
-            with torch.no_grad():
-                v.copy_(nn.functional.normalize(torch.mv(wmat.t(), u), dim=0, eps=self.EPS))
-                u.copy_(nn.functional.normalize(torch.mv(wmat, v), dim=0, eps=self.EPS))
-            u, v = u.clone(), v.clone()            # the buffers are updated in place again by the next forward
-        sigma = torch.dot(u, torch.mv(wmat, v))
-        return self.weight_orig / sigma
+    def _inspect_weight(self):
+        """weight_orig / sigma with the stored (u, v), no iteration, plain torch: what ``.weight`` shows (init_weights
+        writes into it, checkpoints and printing may look at it) -- never what a convolution uses."""
+        wmat = self.weight_orig.flatten(1)
+        return self.weight_orig / torch.dot(self.weight_u, torch.mv(wmat, self.weight_v))
 
     @property
     def weight(self):
         with torch.no_grad():
-            return self._sigma_weight(False)
+            return self._inspect_weight()
 
     def effective_weight(self):
-        w = self._sigma_weight(self.training)
+        # the HIP kernels (csrc/spectral.hip); ops.spectral_weight refuses host tensors -- there is no CPU path
+        w = ops.spectral_weight(self.weight_orig, self.weight_u, self.weight_v, self.training)
         w._dei2i_per_call = True          # derived anew per forward: the packed-weight cache keys on this tensor too
         return w, (self.weight_orig, self.weight_u, self.weight_v)
 
