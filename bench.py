@@ -228,7 +228,7 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     line = {
         "metric": (f"paired {args.image_size}x{args.image_size} images/sec (G+D train step)" if args.stage == "defectgan" else
-                   f"{args.image_size}x{args.image_size} images/sec (MAE-GAN pre-training D+G step)"), "value": pairs / elapsed, "unit": "pairs/s",
+                   f"{args.image_size}x{args.image_size} images/sec (MAE-GAN pre-training D+G step)"), "value": pairs / elapsed, "unit": "pairs/s" if args.stage == "defectgan" else "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype if args.dtype != "fp8" else "fp8-e4m3 forward GEMMs of the 3x3 convs + bf16", "data": "synthetic",
