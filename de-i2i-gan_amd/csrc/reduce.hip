@@ -564,7 +564,17 @@ __global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ 
     acc += fmaxf(xv, 0.f) - xv * tv + log1pf(expf(-fabsf(xv)));
   }
   const float s = block_sum_256(acc, smem);
-  if (threadIdx.x == 0) atomicAdd(out, s * inv_n);
+  if (threadIdx.x == 0) out[blockIdx.x] = s;          // partial; loss_finalize_kernel sums them in order
+}
+
+// out[0] = inv_n * sum of the block partials, in index order (deterministic: no atomics, and `out` needs no zero fill)
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ part, int nparts, float inv_n,
+                                                            float* __restrict__ out) {
+  __shared__ float smem[4];
+  float p = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) p += part[i];
+  const float s = block_sum_256(p, smem);
+  if (threadIdx.x == 0) out[0] = s * inv_n;
 }
 
 __global__ void bce_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t, float tconst, size_t n, float inv_n,
@@ -583,7 +593,7 @@ __global__ __launch_bounds__(256) void l1_fwd_kernel(const float* __restrict__ a
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     acc += fabsf(a[i] - (b != nullptr ? b[i] : 0.f));
   const float s = block_sum_256(acc, smem);
-  if (threadIdx.x == 0) atomicAdd(out, s * inv_n);
+  if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 
 __global__ void l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n, float inv_n,
@@ -764,10 +774,17 @@ int dei2i_spade_bwd_apply(int dtype, int N, int H, int W, int C, int up, const v
   return (int)hipGetLastError();
 }
 
+// block partials of the scalar losses: one stream-ordered scratch per process (the losses of a step run on one stream)
+__device__ float g_loss_partials[1024];
+
 int dei2i_bce_logits_fwd(size_t n, const float* x, const float* target, float tconst, float* out, dei2i_stream s) {
   if (n == 0 || !x || !out) return DEI2I_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)s;
-  hipLaunchKernelGGL(bce_fwd_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, st, x, target, tconst, n, 1.f / (float)n, out);
+  float* part = nullptr;
+  if (hipGetSymbolAddress((void**)&part, HIP_SYMBOL(g_loss_partials)) != hipSuccess) return DEI2I_ERR_BAD_ARG;
+  const unsigned nb = grid_for(n, 256, 1024);
+  hipLaunchKernelGGL(bce_fwd_kernel, dim3(nb), dim3(256), 0, st, x, target, tconst, n, 1.f / (float)n, part);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)part, (int)nb, 1.f / (float)n, out);
   return (int)hipGetLastError();
 }
 
@@ -782,7 +799,11 @@ int dei2i_bce_logits_bwd(size_t n, const float* x, const float* target, float tc
 int dei2i_l1_fwd(size_t n, const float* a, const float* b, float* out, dei2i_stream s) {
   if (n == 0 || !a || !out) return DEI2I_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)s;
-  hipLaunchKernelGGL(l1_fwd_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, st, a, b, n, 1.f / (float)n, out);
+  float* part = nullptr;
+  if (hipGetSymbolAddress((void**)&part, HIP_SYMBOL(g_loss_partials)) != hipSuccess) return DEI2I_ERR_BAD_ARG;
+  const unsigned nb = grid_for(n, 256, 1024);
+  hipLaunchKernelGGL(l1_fwd_kernel, dim3(nb), dim3(256), 0, st, a, b, n, 1.f / (float)n, part);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)part, (int)nb, 1.f / (float)n, out);
   return (int)hipGetLastError();
 }
 

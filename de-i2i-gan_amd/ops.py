@@ -700,7 +700,7 @@ class _BceLogits(torch.autograd.Function):
         t = None if target is None else target.detach().contiguous().float().view(-1)
         if t is not None and t.numel() != x.numel():
             raise ValueError("bce_logits: target size mismatch")
-        out = _zero_scalar(x.device)
+        out = torch.empty((), dtype=torch.float32, device=x.device)      # written (not accumulated) by the finalize kernel
         lib = _lib_for(x)
         L.check(lib.dei2i_bce_logits_fwd(x.numel(), _p(x), _p(t), tconst, _p(out), _stream()), "bce_fwd")
         ctx.tconst = tconst
@@ -730,7 +730,7 @@ class _L1(torch.autograd.Function):
         _require_gpu(a, "l1")
         a = a.contiguous().float()
         bb = None if b is None else b.contiguous().float()
-        out = _zero_scalar(a.device)
+        out = torch.empty((), dtype=torch.float32, device=a.device)
         lib = _lib_for(a)
         L.check(lib.dei2i_l1_fwd(a.numel(), _p(a), _p(bb), _p(out), _stream()), "l1_fwd")
         ctx.save_for_backward(a, bb)

@@ -90,16 +90,19 @@ def test_loss_scaling_by_two_doubles_every_gradient_exactly_at_256(pname):
     tr = build(C256, pname)
     G, D = tr.model.netG, tr.model.netD
     bg, labels, df = O.synthetic_batch(2, 256)
-    res = []
+    res, loss_bits = [], []
     for scale in (1.0, 1.0, 2.0):
         zero(D)
-        d_loss(tr, bg, labels, df, scale).backward()
+        dl = d_loss(tr, bg, labels, df, scale)
+        loss_bits.append(float(dl.detach()))
+        dl.backward()
         gd = grads_of(D)
         zero(G)
         saved = {k: v.clone() for k, v in G.state_dict().items()}
         g_loss(tr, bg, labels, df, scale).backward()
         G.load_state_dict(saved)                  # undo the BatchNorm running-stat update of the train-mode passes
         res.append((gd, grads_of(G)))
+    assert loss_bits[0] == loss_bits[1] and loss_bits[2] == 2.0 * loss_bits[0]      # the scalar losses reproduce too
     for net in (0, 1):
         a, b, c2 = res[0][net], res[1][net], res[2][net]
         assert a.keys() == b.keys() == c2.keys() and len(a) > 5
