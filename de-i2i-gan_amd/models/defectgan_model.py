@@ -4,6 +4,7 @@ import os
 
 import torch
 
+from .. import ops
 from ..networks.architecture import MaskToken
 from ..networks.discriminator import DefectGanDiscriminator
 from ..networks.generator import DefectGanGenerator
@@ -181,9 +182,11 @@ class DefectGanModel(BaseModel):
         nm_labels, df_labels = self._get_labels(df_labels)
         self.netG.clear_spade_cache()
         with torch.no_grad():
-            # (--add_noise: the reference draws one noise field per generator call; keep its two calls so that a seeded /
-            #  injected noise source is consumed exactly as the reference consumes it)
-            if self.netG.training or os.environ.get("DEI2I_SPLIT_D") or getattr(self.opt, "add_noise", False):
+            # (--add_noise with an INJECTED noise source -- the parity tests: keep the reference's two calls so that the
+            #  source is consumed exactly as the reference consumes it; with the device RNG one pass over both batches
+            #  draws the same i.i.d. N(0,1) field, just in one call)
+            injected_noise = getattr(self.opt, "add_noise", False) and ops.noise_source is not None
+            if self.netG.training or os.environ.get("DEI2I_SPLIT_D") or injected_noise:
                 fake_defects, _ = self.netG(bg_data, df_labels)
                 fake_normals, _ = self.netG(df_data, nm_labels)
             else:

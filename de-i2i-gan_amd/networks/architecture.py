@@ -149,9 +149,22 @@ class SpectralConv2d(Conv2d):
 
     def effective_weight(self):
         # the HIP kernels (csrc/spectral.hip); ops.spectral_weight refuses host tensors -- there is no CPU path
+        sources = (self.weight_orig, self.weight_u, self.weight_v)
+        frozen = not self.training and not (torch.is_grad_enabled() and self.weight_orig.requires_grad)
+        if frozen:
+            # eval mode, no gradient wanted: nothing iterates (u, v), so w / sigma only changes with the parameters --
+            # keep it (and its packed copies) until a stamp moves (the D step's generator passes, D inside the G step)
+            key = tuple(ops.PackedWeights._stamp(t) for t in sources)
+            hit = self.__dict__.get("_frozen_weight")
+            if hit is None or hit[0] != key:
+                with torch.no_grad():
+                    hit = (key, ops.spectral_weight(self.weight_orig, self.weight_u, self.weight_v, False))
+                self.__dict__["_frozen_weight"] = hit
+            return hit[1], sources
+        self.__dict__.pop("_frozen_weight", None)
         w = ops.spectral_weight(self.weight_orig, self.weight_u, self.weight_v, self.training)
         w._dei2i_per_call = True          # derived anew per forward: the packed-weight cache keys on this tensor too
-        return w, (self.weight_orig, self.weight_u, self.weight_v)
+        return w, sources
 
 
 def make_conv(use_spectral, *args, **kw):
