@@ -80,9 +80,11 @@ SIGNATURES = {
     "dei2i_bce_logits_bwd": (c_int, [c_size_t, _P, _P, c_float, _P, _P, _P]),
     "dei2i_l1_fwd": (c_int, [c_size_t, _P, _P, _P, _P]),
     "dei2i_l1_bwd": (c_int, [c_size_t, _P, _P, _P, _P, _P, _P]),
+    "dei2i_noise_fwd": (c_int, [c_int, c_size_t, c_int, _P, _P, _P, _P, _P]),
+    "dei2i_noise_bwd": (c_int, [c_int, c_size_t, c_int, _P, _P, _P, _P, c_int, _P]),
     "dei2i_spectral_scratch_floats": (c_size_t, [c_int, c_int]),
     "dei2i_spectral_fwd": (c_int, [c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P]),
-    "dei2i_spectral_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dei2i_spectral_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "dei2i_adam_step": (c_int, [_P, c_int, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_float, _P]),
     "dei2i_prof_enable": (c_int, [c_int, c_int]),
     "dei2i_prof_collect": (c_int, [c_int, POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),

@@ -569,12 +569,47 @@ __global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ 
 
 // out[0] = inv_n * sum of the block partials, in index order (deterministic: no atomics, and `out` needs no zero fill)
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ part, int nparts, float inv_n,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, int accumulate) {
   __shared__ float smem[4];
   float p = 0.f;
   for (int i = threadIdx.x; i < nparts; i += 256) p += part[i];
   const float s = block_sum_256(p, smem);
-  if (threadIdx.x == 0) out[0] = s * inv_n;
+  if (threadIdx.x == 0) out[0] = accumulate ? out[0] + s * inv_n : s * inv_n;
+}
+
+// ---- noise injection (architecture.py:374-389 of the reference): out[r][c] = x[r][c] + w * noise[r], one N(0,1) value per
+//      pixel shared by the channels, one scalar weight; dx = dy passes through, dw = sum_r noise[r] * sum_c dy[r][c] ----
+template <typename T>
+__global__ void noise_fwd_kernel(const T* __restrict__ x, const float* __restrict__ noise, const float* __restrict__ w,
+                                 T* __restrict__ out, size_t nvec, int vec_per_row) {
+  constexpr int VEC = Elem<T>::VEC;
+  const float wt = w[0];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+    float v[VEC];
+    Elem<T>::unpack(*reinterpret_cast<const u32x4*>(x + i * VEC), v);
+    const float add = wt * noise[i / (size_t)vec_per_row];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] += add;
+    *reinterpret_cast<u32x4*>(out + i * VEC) = Elem<T>::pack(v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void noise_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ noise, size_t nvec,
+                                                        int vec_per_row, float* __restrict__ part) {
+  constexpr int VEC = Elem<T>::VEC;
+  __shared__ float smem[4];
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+    float v[VEC];
+    Elem<T>::unpack(*reinterpret_cast<const u32x4*>(dy + i * VEC), v);
+    float t = 0.f;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) t += v[e];
+    acc = fmaf(noise[i / (size_t)vec_per_row], t, acc);
+  }
+  const float s = block_sum_256(acc, smem);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;          // loss_finalize_kernel sums the partials in index order
 }
 
 __global__ void bce_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t, float tconst, size_t n, float inv_n,
@@ -784,7 +819,7 @@ int dei2i_bce_logits_fwd(size_t n, const float* x, const float* target, float tc
   if (hipGetSymbolAddress((void**)&part, HIP_SYMBOL(g_loss_partials)) != hipSuccess) return DEI2I_ERR_BAD_ARG;
   const unsigned nb = grid_for(n, 256, 1024);
   hipLaunchKernelGGL(bce_fwd_kernel, dim3(nb), dim3(256), 0, st, x, target, tconst, n, 1.f / (float)n, part);
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)part, (int)nb, 1.f / (float)n, out);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)part, (int)nb, 1.f / (float)n, out, 0);
   return (int)hipGetLastError();
 }
 
@@ -803,7 +838,7 @@ int dei2i_l1_fwd(size_t n, const float* a, const float* b, float* out, dei2i_str
   if (hipGetSymbolAddress((void**)&part, HIP_SYMBOL(g_loss_partials)) != hipSuccess) return DEI2I_ERR_BAD_ARG;
   const unsigned nb = grid_for(n, 256, 1024);
   hipLaunchKernelGGL(l1_fwd_kernel, dim3(nb), dim3(256), 0, st, a, b, n, 1.f / (float)n, part);
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)part, (int)nb, 1.f / (float)n, out);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)part, (int)nb, 1.f / (float)n, out, 0);
   return (int)hipGetLastError();
 }
 
@@ -811,6 +846,35 @@ int dei2i_l1_bwd(size_t n, const float* a, const float* b, const float* gout, fl
   if (n == 0 || !a || !gout) return DEI2I_ERR_BAD_ARG;
   hipLaunchKernelGGL(l1_bwd_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, (hipStream_t)s, a, b, n, 1.f / (float)n, gout,
                      da, db);
+  return (int)hipGetLastError();
+}
+
+int dei2i_noise_fwd(int dtype, size_t rows, int C, const void* x, const float* noise, const float* weight, void* out,
+                    dei2i_stream s) {
+  const int vec = dtype == DT_BF16 ? 8 : 4;
+  if (rows == 0 || C <= 0 || C % vec || !x || !noise || !weight || !out) return DEI2I_ERR_BAD_ARG;
+  const size_t nvec = rows * (size_t)(C / vec);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(noise_fwd_kernel<bf16_t>, dim3(grid_for(nvec, 256, 4096)), dim3(256), 0, (hipStream_t)s,
+                       (const bf16_t*)x, noise, weight, (bf16_t*)out, nvec, C / vec);
+  else
+    hipLaunchKernelGGL(noise_fwd_kernel<float>, dim3(grid_for(nvec, 256, 4096)), dim3(256), 0, (hipStream_t)s,
+                       (const float*)x, noise, weight, (float*)out, nvec, C / vec);
+  return (int)hipGetLastError();
+}
+
+int dei2i_noise_bwd(int dtype, size_t rows, int C, const void* dy, const float* noise, float* partials, float* dweight,
+                    int accumulate, dei2i_stream s) {
+  const int vec = dtype == DT_BF16 ? 8 : 4;
+  if (rows == 0 || C <= 0 || C % vec || !dy || !noise || !partials || !dweight) return DEI2I_ERR_BAD_ARG;
+  const size_t nvec = rows * (size_t)(C / vec);
+  hipStream_t st = (hipStream_t)s;
+  const unsigned nb = grid_for(nvec, 256, 1024);          // `partials`: at least 1024 floats
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(noise_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)dy, noise, nvec, C / vec, partials);
+  else
+    hipLaunchKernelGGL(noise_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dy, noise, nvec, C / vec, partials);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)partials, (int)nb, 1.f, dweight, accumulate);
   return (int)hipGetLastError();
 }
 

@@ -30,34 +30,36 @@ DEI2I_D float sn_block_sum(float v, float* red) {       // 256 threads, fixed or
 }
 
 // t[k] = sum_r W[r][k] u[r]; part[blockIdx.x] = sum over this block's columns of t[k]^2.
-// 64 columns per workgroup, the rows dealt to its four waves (wave g takes rows g, g+4, ...): four times the
-// workgroups of a 256-column strip (K = 2304 is only 9 strips) and every wave still reads 256 contiguous bytes per row.
-__global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* __restrict__ W, const float* __restrict__ u, int Cout, int K,
-                                                      float* __restrict__ t, float* __restrict__ part) {
-  __shared__ float acc4[4][SN_COLS];
-  __shared__ float red[4];
+// 64 columns per workgroup, the rows dealt to its sixteen waves (wave g takes rows g, g+16, ...): K = 2304 is only 36
+// such workgroups, so the launch is bound by each thread's chain of dependent loads -- 16 row groups keep that chain at
+// Cout/16 loads (four independent accumulators), and every wave still reads 256 contiguous bytes per row.
+constexpr int SN_RG = 16;
+__global__ __launch_bounds__(SN_COLS * SN_RG) void sn_wt_u_kernel(const float* __restrict__ W, const float* __restrict__ u, int Cout,
+                                                                  int K, float* __restrict__ t, float* __restrict__ part) {
+  __shared__ float accg[SN_RG][SN_COLS];
   const int col = threadIdx.x & (SN_COLS - 1), g = threadIdx.x / SN_COLS;
   const int k = blockIdx.x * SN_COLS + col;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (k < K) {
     int r = g;
-    for (; r + 12 < Cout; r += 16) {
+    for (; r + 3 * SN_RG < Cout; r += 4 * SN_RG) {
       a0 = fmaf(W[(size_t)r * K + k], u[r], a0);
-      a1 = fmaf(W[(size_t)(r + 4) * K + k], u[r + 4], a1);
-      a2 = fmaf(W[(size_t)(r + 8) * K + k], u[r + 8], a2);
-      a3 = fmaf(W[(size_t)(r + 12) * K + k], u[r + 12], a3);
+      a1 = fmaf(W[(size_t)(r + SN_RG) * K + k], u[r + SN_RG], a1);
+      a2 = fmaf(W[(size_t)(r + 2 * SN_RG) * K + k], u[r + 2 * SN_RG], a2);
+      a3 = fmaf(W[(size_t)(r + 3 * SN_RG) * K + k], u[r + 3 * SN_RG], a3);
     }
-    for (; r < Cout; r += 4) a0 = fmaf(W[(size_t)r * K + k], u[r], a0);
+    for (; r < Cout; r += SN_RG) a0 = fmaf(W[(size_t)r * K + k], u[r], a0);
   }
-  acc4[g][col] = (a0 + a1) + (a2 + a3);
+  accg[g][col] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  float tk = 0.f;
-  if (g == 0) {
-    tk = (acc4[0][col] + acc4[1][col]) + (acc4[2][col] + acc4[3][col]);
+  if (g == 0) {                       // wave 0 holds the block's 64 columns: its wave sum is the block's partial
+    float tk = 0.f;
+#pragma unroll
+    for (int i = 0; i < SN_RG; ++i) tk += accg[i][col];
     if (k < K) t[k] = tk; else tk = 0.f;
+    const float s = wave_sum(tk * tk);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
   }
-  const float s = sn_block_sum(tk * tk, red);
-  if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 
 // out[i] = in[i] / max(sqrt(sum part), eps), written to both destinations; scal[slot] = that norm.  Every workgroup sums
@@ -119,40 +121,74 @@ __global__ __launch_bounds__(256) void sn_eval_sigma_kernel(const float* __restr
   }
 }
 
+// out = W / sigma.  n4 = n / 4 float4 groups, then the (< 4) tail elements.
 __global__ void sn_scale_kernel(const float* __restrict__ W, const float* __restrict__ scal, size_t n, float* __restrict__ out) {
   const float inv = 1.f / scal[2];
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = W[i] * inv;
+  const size_t n4 = n >> 2, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = tid; i < n4; i += stride) {
+    float4 w = reinterpret_cast<const float4*>(W)[i];
+    w.x *= inv; w.y *= inv; w.z *= inv; w.w *= inv;
+    reinterpret_cast<float4*>(out)[i] = w;
+  }
+  for (size_t i = (n4 << 2) + tid; i < n; i += stride) out[i] = W[i] * inv;
 }
 
 // part[block] = sum over the block's elements of G . W_eff   (W_eff = W / sigma, so sum(G.W) = sigma * sum(G.W_eff))
 __global__ __launch_bounds__(256) void sn_bwd_dot_kernel(const float* __restrict__ G, const float* __restrict__ Weff, size_t n,
                                                          float* __restrict__ part) {
   __shared__ float red[4];
-  float a = 0.f;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a = fmaf(G[i], Weff[i], a);
-  const float s = sn_block_sum(a, red);
+  const size_t n4 = n >> 2, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (size_t i = tid; i < n4; i += stride) {
+    const float4 g = reinterpret_cast<const float4*>(G)[i], w = reinterpret_cast<const float4*>(Weff)[i];
+    a0 = fmaf(g.x, w.x, a0); a1 = fmaf(g.y, w.y, a1); a2 = fmaf(g.z, w.z, a2); a3 = fmaf(g.w, w.w, a3);
+  }
+  for (size_t i = (n4 << 2) + tid; i < n; i += stride) a0 = fmaf(G[i], Weff[i], a0);
+  const float s = sn_block_sum((a0 + a1) + (a2 + a3), red);
   if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 
-// dW[r][k] = (G[r][k] - c * u[r] v[k]) / sigma,  c = sum(G . W_eff)
+// dW[r][k] (+)= (G[r][k] - c * u[r] v[k]) / sigma,  c = sum(G . W_eff).  K4: K is a multiple of 4 -> float4 groups that
+// never straddle a row.
+template <bool K4>
 __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restrict__ G, const float* __restrict__ part, int nparts,
                                                            const float* __restrict__ scal, const float* __restrict__ u,
-                                                           const float* __restrict__ v, int Cout, int K, float* __restrict__ dW) {
+                                                           const float* __restrict__ v, int Cout, int K, float* __restrict__ dW,
+                                                           int accumulate) {
   __shared__ float red[4];
   float p = 0.f;
   for (int i = threadIdx.x; i < nparts; i += 256) p += part[i];
   const float c = sn_block_sum(p, red);
   const float inv = 1.f / scal[2];
-  const size_t n = (size_t)Cout * K;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const int r = (int)(i / K), k = (int)(i - (size_t)r * K);
-    dW[i] = (G[i] - c * u[r] * v[k]) * inv;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  if (K4) {
+    const int k4n = K >> 2;
+    const size_t n4 = (size_t)Cout * k4n;
+    for (size_t i = tid; i < n4; i += stride) {
+      const int r = (int)(i / k4n), k4 = (int)(i - (size_t)r * k4n);
+      const float cu = c * u[r];
+      const float4 g = reinterpret_cast<const float4*>(G)[i], vv = reinterpret_cast<const float4*>(v)[k4];
+      float4 o;
+      o.x = (g.x - cu * vv.x) * inv; o.y = (g.y - cu * vv.y) * inv; o.z = (g.z - cu * vv.z) * inv; o.w = (g.w - cu * vv.w) * inv;
+      if (accumulate) {
+        const float4 old = reinterpret_cast<const float4*>(dW)[i];
+        o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+      }
+      reinterpret_cast<float4*>(dW)[i] = o;
+    }
+  } else {
+    const size_t n = (size_t)Cout * K;
+    for (size_t i = tid; i < n; i += stride) {
+      const int r = (int)(i / K), k = (int)(i - (size_t)r * K);
+      const float o = (G[i] - c * u[r] * v[k]) * inv;
+      dW[i] = accumulate ? dW[i] + o : o;
+    }
   }
 }
 
-static inline int sn_dot_blocks(size_t n) {
-  size_t b = n / 4096;
-  return (int)(b < 1 ? 1 : (b > 256 ? 256 : b));
+static inline int sn_dot_blocks(size_t n) {            // >= 2048 elements (two float4 pairs per thread) per workgroup
+  size_t b = n / 2048;
+  return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
 }
 
 }  // namespace dei2i
@@ -161,7 +197,7 @@ using namespace dei2i;
 
 extern "C" {
 
-size_t dei2i_spectral_scratch_floats(int Cout, int K) { return (size_t)K + Cout + (size_t)((K + SN_COLS - 1) / SN_COLS) + Cout + 256; }
+size_t dei2i_spectral_scratch_floats(int Cout, int K) { return (size_t)K + Cout + (size_t)((K + SN_COLS - 1) / SN_COLS) + Cout + 1024; }
 
 int dei2i_spectral_fwd(int Cout, int K, const float* W, float* u, float* v, int iterate, float* scratch, float* u_used,
                        float* v_used, float* scal, float* w_eff, dei2i_stream s) {
@@ -173,7 +209,7 @@ int dei2i_spectral_fwd(int Cout, int K, const float* W, float* u, float* v, int 
   float* part_t = sv + Cout;             // cb
   float* part_s = part_t + cb;           // Cout
   if (iterate) {
-    hipLaunchKernelGGL(sn_wt_u_kernel, dim3(cb), dim3(256), 0, st, W, (const float*)u, Cout, K, t, part_t);
+    hipLaunchKernelGGL(sn_wt_u_kernel, dim3(cb), dim3(SN_COLS * SN_RG), 0, st, W, (const float*)u, Cout, K, t, part_t);
     hipLaunchKernelGGL(sn_normalize_kernel, dim3((K + 255) / 256 > 64 ? 64 : (K + 255) / 256), dim3(256), 0, st, (const float*)t,
                        (const float*)part_t, cb, K, v, v_used, scal, 0, 0);
     hipLaunchKernelGGL(sn_w_v_kernel, dim3(Cout), dim3(256), 0, st, W, (const float*)v_used, (const float*)u, K, sv, part_s, 0);
@@ -185,19 +221,23 @@ int dei2i_spectral_fwd(int Cout, int K, const float* W, float* u, float* v, int 
                        (const float*)part_s, Cout, (const float*)u, (const float*)v, K, u_used, v_used, scal);
   }
   const size_t n = (size_t)Cout * K;
-  hipLaunchKernelGGL(sn_scale_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, W, (const float*)scal, n, w_eff);
+  hipLaunchKernelGGL(sn_scale_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, st, W, (const float*)scal, n, w_eff);
   return (int)hipGetLastError();
 }
 
 int dei2i_spectral_bwd(int Cout, int K, const float* G, const float* w_eff, const float* u_used, const float* v_used,
-                       const float* scal, float* scratch, float* dW, dei2i_stream s) {
+                       const float* scal, float* scratch, float* dW, int accumulate, dei2i_stream s) {
   if (Cout <= 0 || K <= 0 || !G || !w_eff || !u_used || !v_used || !scal || !scratch || !dW) return DEI2I_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)s;
   const size_t n = (size_t)Cout * K;
-  const int nb = sn_dot_blocks(n);
+  const int nb = sn_dot_blocks(n);                 // <= 1024 partials at the head of `scratch`
   hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(nb), dim3(256), 0, st, G, w_eff, n, scratch);
-  hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, G, (const float*)scratch, nb, scal, u_used, v_used,
-                     Cout, K, dW);
+  if (K % 4 == 0)
+    hipLaunchKernelGGL(sn_bwd_apply_kernel<true>, dim3(grid_for(n / 4, 256)), dim3(256), 0, st, G, (const float*)scratch, nb, scal,
+                       u_used, v_used, Cout, K, dW, accumulate);
+  else
+    hipLaunchKernelGGL(sn_bwd_apply_kernel<false>, dim3(grid_for(n, 256)), dim3(256), 0, st, G, (const float*)scratch, nb, scal,
+                       u_used, v_used, Cout, K, dW, accumulate);
   return (int)hipGetLastError();
 }
 

@@ -178,8 +178,8 @@ def _is_batchnorm(norm_layer):
 class NoiseInjection(nn.Module):
     """x + weight * noise with one N(0,1) value per pixel, shared by the channels (architecture.py:374-389, the
     'constant' weight type the blocks use).  Works on the NHWC activations: the noise is drawn as (N,1,H,W) like the
-    reference (device RNG, or ``ops.noise_source`` when a test injects it) and broadcast over the channel axis with plain
-    torch ops -- not fused into the producing conv's epilogue yet."""
+    reference (device RNG, or ``ops.noise_source`` when a test injects it); ``ops.noise_inject`` is one HIP launch forward
+    and a deterministic two-launch reduction for the weight gradient backward (not fused into the conv epilogue yet)."""
 
     def __init__(self):
         super().__init__()
@@ -189,8 +189,7 @@ class NoiseInjection(nn.Module):
         n, h, w, _ = x.shape
         if noise is None:
             noise = ops.draw_noise((n, 1, h, w), x.device)
-        noise = noise.to(device=x.device, dtype=x.dtype).reshape(n, h, w, 1)
-        return x + self.weight.reshape(1, 1, 1, 1).to(x.dtype) * noise
+        return ops.noise_inject(x, self.weight, noise)
 
 
 def _noise(add_noise):

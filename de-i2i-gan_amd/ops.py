@@ -178,6 +178,7 @@ class _SpectralWeight(torch.autograd.Function):
             u._dei2i_epoch = getattr(u, "_dei2i_epoch", 0) + 1
             v._dei2i_epoch = getattr(v, "_dei2i_epoch", 0) + 1
         ctx.save_for_backward(w_eff, u_used, v_used, scal)
+        ctx.param = weight_orig
         return w_eff
 
     @staticmethod
@@ -186,10 +187,11 @@ class _SpectralWeight(torch.autograd.Function):
         g = g.contiguous()
         cout, k = w_eff.shape[0], w_eff[0].numel()
         lib = _lib_for(w_eff)
-        scratch = torch.empty(256, dtype=torch.float32, device=g.device)
-        dw = torch.empty_like(w_eff)
-        L.check(lib.dei2i_spectral_bwd(cout, k, _p(g), _p(w_eff), _p(u_used), _p(v_used), _p(scal), _p(scratch), _p(dw), _stream()),
-                "spectral_bwd")
+        scratch = torch.empty(1024, dtype=torch.float32, device=g.device)
+        # the same parameter's later forwards of this backward pass add into the first one's tensor (see _grad_target)
+        dw, dw_ptr, accumulate = _grad_target(ctx.param, w_eff.shape, g.device)
+        L.check(lib.dei2i_spectral_bwd(cout, k, _p(g), _p(w_eff), _p(u_used), _p(v_used), _p(scal), _p(scratch), c_void_p(dw_ptr),
+                                       accumulate, _stream()), "spectral_bwd")
         return dw, None, None, None
 
 
@@ -207,6 +209,46 @@ def draw_noise(shape, device):
     if noise_source is not None:
         return noise_source(tuple(shape))
     return torch.randn(shape, device=device)
+
+
+class _NoiseInject(torch.autograd.Function):
+    """x + weight * noise on an NHWC activation (one noise value per pixel, one scalar weight): one HIP launch forward;
+    backward hands dy through and reduces dweight = sum(noise * rowsum(dy)) through ordered block partials."""
+
+    @staticmethod
+    def forward(ctx, x, weight, noise):
+        _require_gpu(x, "noise_inject")
+        prec = precision_of(x)
+        x = x.contiguous()
+        rows, c = x.numel() // x.shape[-1], x.shape[-1]
+        noise = noise.detach().to(device=x.device, dtype=torch.float32).contiguous()
+        if noise.numel() != rows:
+            raise ValueError(f"noise_inject: {noise.numel()} noise values for {rows} pixels")
+        w = weight.detach().reshape(1)
+        out = torch.empty_like(x)
+        lib = _lib_for(x)
+        L.check(lib.dei2i_noise_fwd(prec.code, rows, c, _p(x), _p(noise), _p(w), _p(out), _stream()), "noise_fwd")
+        ctx.prec, ctx.wshape, ctx.param = prec, weight.shape, weight
+        ctx.save_for_backward(noise)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (noise,) = ctx.saved_tensors
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dy = dy.contiguous()
+            rows, c = noise.numel(), dy.shape[-1]
+            part = torch.empty(1024, dtype=torch.float32, device=dy.device)
+            dw, dw_ptr, accumulate = _grad_target(ctx.param, ctx.wshape, dy.device)
+            L.check(_lib_for(dy).dei2i_noise_bwd(ctx.prec.code, rows, c, _p(dy), _p(noise), _p(part), c_void_p(dw_ptr), accumulate,
+                                                 _stream()), "noise_bwd")
+        return (dy if ctx.needs_input_grad[0] else None), dw, None
+
+
+def noise_inject(x, weight, noise):
+    """NoiseInjection on an NHWC activation: ``noise`` holds one value per pixel ((N,1,H,W) as the reference draws it)."""
+    return _NoiseInject.apply(x, weight, noise)
 
 
 _const_vecs = {}
@@ -260,8 +302,9 @@ class PackedWeights:
             need_fwd: bool = True, per_call: bool = False):
         # per_call: the weight is DERIVED from the sources anew on every forward and differs between calls whose sources
         # carry the same stamps by the time backward runs (spectral norm: u, v are iterated in place by later forwards)
-        # -- its own address identifies the call
-        key = (tuple(self._stamp(s) for s in sources), prec.code, cins, couts, self._stamp(weight) if per_call else None)
+        # -- its own address identifies the call, and the sources' stamps (moved by those later forwards) must not
+        key = ((), prec.code, cins, couts, self._stamp(weight)) if per_call else \
+            (tuple(self._stamp(s) for s in sources), prec.code, cins, couts, None)
         lib = _lib_for(weight)
         if key != self._key:
             self._key, self.fwd, self.dgrad, self.fp8 = key, None, None, None
@@ -313,6 +356,11 @@ class _Conv2d(torch.autograd.Function):
         lib = _lib_for(x)
         d = _desc(prec, geom, n, h, w, cins, couts)
         per_call = bool(getattr(weight, "_dei2i_per_call", False))
+        if per_call:
+            # a weight derived anew for THIS call (spectral norm in training mode): its packed copies travel with the
+            # call (ctx), not with the module -- the module's single slot would be overwritten by the next call before
+            # this call's backward asks for the dgrad layout
+            cache = PackedWeights()
         use_fp8 = bool(_fp8_forward and prec is BF16 and not per_call and lib.dei2i_conv2d_fp8_supported(byref(d)))
         # trainable weights: a backward pass of this optimizer step will want the dgrad layout too (also when THIS call
         # is the no-grad generator pass of the D step) -> both layouts in one pack launch

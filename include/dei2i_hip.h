@@ -185,14 +185,24 @@ int dei2i_compose_bwd(int dtype, int N, int H, int W, int Cs, const void* raw, c
 int dei2i_nan_guard(int dtype, size_t n, void* x, int* flag, dei2i_stream s);
 
 /* ---- losses (models/base_model.py:68-80), fp32 tensors ---- */
-/* mean( max(x,0) - x*t + log1p(exp(-|x|)) ); target == NULL -> constant `tconst`.  out[0] += loss: the caller hands
- * in a zeroed scalar (the Python side carves them from one pre-zeroed slab: one memset per 256 losses). */
+/* mean( max(x,0) - x*t + log1p(exp(-|x|)) ); target == NULL -> constant `tconst`.  out[0] = loss, summed through ordered
+ * block partials (no atomics: bit-reproducible; `out` needs no zero fill). */
 int dei2i_bce_logits_fwd(size_t n, const float* x, const float* target, float tconst, float* out, dei2i_stream s);
 int dei2i_bce_logits_bwd(size_t n, const float* x, const float* target, float tconst, const float* gout, float* dx,
                          dei2i_stream s);
-/* mean |a - b| ; b == NULL -> 0; out[0] += loss (zeroed by the caller).  backward: da = sign(a-b)*gout/n, db = -da (either may be NULL) */
+/* mean |a - b| ; b == NULL -> 0; out[0] = loss.  backward: da = sign(a-b)*gout/n, db = -da (either may be NULL) */
 int dei2i_l1_fwd(size_t n, const float* a, const float* b, float* out, dei2i_stream s);
 int dei2i_l1_bwd(size_t n, const float* a, const float* b, const float* gout, float* da, float* db, dei2i_stream s);
+
+/* ---- NoiseInjection (models/networks/architecture.py:374-389, the 'constant' weight the blocks use) ----
+ * x, out, dy: NHWC activations viewed as [rows = N*H*W][C] in the compute dtype (C a multiple of 8 for bf16, 4 for fp32);
+ * noise: one fp32 N(0,1) value per row; weight: the module's single fp32 scalar (device pointer).
+ * fwd: out[r][c] = x[r][c] + weight * noise[r].  bwd: dweight[0] = sum_r noise[r] * sum_c dy[r][c] (ordered block partials:
+ * `partials` holds >= 1024 floats of scratch; accumulate != 0 adds into dweight); the activation gradient is dy itself. */
+int dei2i_noise_fwd(int dtype, size_t rows, int C, const void* x, const float* noise, const float* weight, void* out,
+                    dei2i_stream s);
+int dei2i_noise_bwd(int dtype, size_t rows, int C, const void* dy, const float* noise, float* partials, float* dweight,
+                    int accumulate, dei2i_stream s);
 
 /* ---- fused multi-tensor Adam (torch.optim.Adam semantics; trainers/base_trainer.py:75-89) ----
  * table: device array of `count` records {p, g, m, v (fp32*), n (int64)}; one launch updates all. */
@@ -211,12 +221,13 @@ int dei2i_adam_step(const dei2i_adam_rec* table_dev, int count, int64_t max_n, f
  * iteration per training-mode forward) ----  W = weight_orig as a (Cout, K) fp32 matrix, u (Cout) / v (K) the module's
  * buffers (updated in place when iterate != 0); u_used / v_used receive the vectors sigma was computed with (the backward
  * pass needs them: later forwards iterate the buffers again); scal: 4 floats (|W^T u|, |W v|, sigma, -); w_eff = W / sigma.
- * backward: dW = (G - sum(G . w_eff) * u v^T) / sigma.  scratch: dei2i_spectral_scratch_floats(Cout, K) floats. */
+ * backward: dW (+)= (G - sum(G . w_eff) * u v^T) / sigma (accumulate != 0 adds into dW).  scratch:
+ * dei2i_spectral_scratch_floats(Cout, K) floats forward, 1024 floats backward. */
 size_t dei2i_spectral_scratch_floats(int Cout, int K);
 int dei2i_spectral_fwd(int Cout, int K, const float* W, float* u, float* v, int iterate, float* scratch, float* u_used,
                        float* v_used, float* scal, float* w_eff, dei2i_stream s);
 int dei2i_spectral_bwd(int Cout, int K, const float* G, const float* w_eff, const float* u_used, const float* v_used,
-                       const float* scal, float* scratch, float* dW, dei2i_stream s);
+                       const float* scal, float* scratch, float* dW, int accumulate, dei2i_stream s);
 
 /* ---- in-library kernel timing (bench.py roofline leg): HIP events around every launch of one kernel family ---- */
 #define DEI2I_PROF_GATHER_GEMM 0  /* the other conv forward / dgrad kernels: gather GEMM v1 / v2, thin convs */

@@ -305,3 +305,58 @@ def test_fused_adam_matches_oracle():
     for i, p in enumerate(gp):
         assert maxrel(p, S[str(i)]) < 2e-6, i
         assert getattr(p, "_dei2i_epoch", 0) >= 2
+
+
+@pytest.mark.parametrize("shape", [(16, 8, 3, 3), (6, 32, 4, 4), (1, 24, 3, 3), (40, 3, 7, 7), (256, 64, 3, 3)])
+@pytest.mark.parametrize("iterate", [True, False])
+def test_spectral_weight_op(ops, shape, iterate):
+    """ops.spectral_weight (csrc/spectral.hip) against the oracle's restatement of torch.nn.utils.spectral_norm: the
+    iterated buffers, w / sigma, and the weight gradient -- with the parameter used TWICE in one backward pass, so the
+    second node adds into the first one's gradient tensor inside the kernel (K % 4 != 0 cases take the scalar kernel)."""
+    torch.manual_seed(3)
+    w = torch.randn(shape) * 0.2
+    u = F.normalize(torch.randn(shape[0]), dim=0)
+    v = F.normalize(torch.randn(w[0].numel()), dim=0)
+    g1, g2 = torch.randn(shape), torch.randn(shape)
+    # reference in float64 through the oracle (two successive forwards, like two calls of the module in one step)
+    S = {"c.weight_orig": w.double().requires_grad_(True), "c.weight_u": u.double().clone(), "c.weight_v": v.double().clone()}
+    r1 = O.weight_of(S, "c.weight", iterate)
+    r2 = O.weight_of(S, "c.weight", iterate)
+    ((r1 * g1.double()).sum() + (r2 * g2.double()).sum()).backward()
+    wg = torch.nn.Parameter(w.to(dev()))
+    ug, vg = u.to(dev()), v.to(dev())
+    o1 = ops.spectral_weight(wg, ug, vg, iterate)
+    o2 = ops.spectral_weight(wg, ug, vg, iterate)
+    ((o1 * g1.to(dev())).sum() + (o2 * g2.to(dev())).sum()).backward()
+    assert maxrel(o1, r1) < 2e-5 and maxrel(o2, r2) < 2e-5
+    assert maxrel(ug, S["c.weight_u"]) < 2e-5 and maxrel(vg, S["c.weight_v"]) < 2e-5
+    assert maxrel(wg.grad, S["c.weight_orig"].grad) < 5e-5
+
+
+@pytest.mark.parametrize("pname", ["f32", "bf16"])
+def test_noise_inject_op(ops, pname):
+    """ops.noise_inject: x + w * noise (one value per pixel) and its gradients against float64 torch; the weight is used
+    twice in the backward pass (in-kernel accumulation of the second node)."""
+    from de_i2i_gan_amd.ops import BF16, F32
+    prec = BF16 if pname == "bf16" else F32
+    torch.manual_seed(5)
+    n, h, w_, c = 3, 9, 7, 16
+    x1, x2 = torch.randn(n, h, w_, c), torch.randn(n, h, w_, c)
+    nz1, nz2 = torch.randn(n, 1, h, w_), torch.randn(n, 1, h, w_)
+    gy1, gy2 = torch.randn(n, h, w_, c), torch.randn(n, h, w_, c)
+    wt = torch.tensor(0.37).reshape(1, 1, 1, 1)
+    xr1, xr2 = rounded(x1, prec).double().requires_grad_(True), rounded(x2, prec).double().requires_grad_(True)
+    wr = wt.double().requires_grad_(True)
+    y1 = xr1 + wr.reshape(()) * nz1.double().reshape(n, h, w_, 1)
+    y2 = xr2 + wr.reshape(()) * nz2.double().reshape(n, h, w_, 1)
+    gr1, gr2 = rounded(gy1, prec).double(), rounded(gy2, prec).double()
+    ((y1 * gr1).sum() + (y2 * gr2).sum()).backward()
+    wg = torch.nn.Parameter(wt.to(dev()))
+    xg1 = x1.to(dev(), prec.dtype).requires_grad_(True)
+    xg2 = x2.to(dev(), prec.dtype).requires_grad_(True)
+    o1 = ops.noise_inject(xg1, wg, nz1.to(dev()))
+    o2 = ops.noise_inject(xg2, wg, nz2.to(dev()))
+    torch.autograd.backward([o1, o2], [gy1.to(dev(), prec.dtype), gy2.to(dev(), prec.dtype)])
+    assert maxrel(o1, y1) < TOL[pname] and maxrel(o2, y2) < TOL[pname]
+    assert maxrel(xg1.grad, gr1) < 1e-6 and maxrel(xg2.grad, gr2) < 1e-6
+    assert wg.grad.shape == wt.shape and maxrel(wg.grad, wr.grad) < 2e-5
