@@ -251,13 +251,13 @@ def main():
         peak = PEAK_TFLOPS[args.dtype]
         ach = hfl / (hms * 1e-3) / 1e12 if hms > 0 else 0.0
         traffic, traffic_src = None, None
-        pmc = os.path.join(REPO, "profiles", "r01_f_pmc_traffic.json")    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        pmc = os.path.join(REPO, "profiles", "r01_g_pmc_traffic.json")    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
         if args.dtype == "bf16" and args.image_size == 256 and args.batch == 16 and os.path.exists(pmc):
             with open(pmc) as f:
                 t = json.load(f)
             if "halo_conv" in t:
                 traffic = t["halo_conv"]["hbm_bytes_per_launch"]
-                traffic_src = ("profiles/r01_f_pmc_traffic.json (profiles/collect.sh + summarize.py): (2*FETCH_SIZE + WRITE_SIZE)"
+                traffic_src = ("profiles/r01_g_pmc_traffic.json (profiles/collect.sh + summarize.py): (2*FETCH_SIZE + WRITE_SIZE)"
                                "*1024 bytes per halo_conv_kernel launch, separate --pmc passes")
         line["roofline"] = {"bound": "mfma", "kernel": "halo_conv_kernel (stride-1 3x3 conv forward + zero-boundary dgrad; "
                             "the step's dominant kernel, ~30 % of its device time)",
