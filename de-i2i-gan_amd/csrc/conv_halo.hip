@@ -6,7 +6,7 @@
 // (8+th-1) x (32+tw-1) input halo of the current 64-channel slice in LDS (<= 340 pixels x 128 B = 43.5 KB, double
 // buffered); all th*tw taps read their A fragments from that halo at shifted pixel addresses.  Per k-step only the
 // weight tile (BN x 128 B) comes from L2: 16 KB + 4.8 KB of amortised halo for the same 4.2 MFLOP -- 2.3x less
-// operand traffic, which also frees LDS for a 4-stage weight ring (three k-steps of prefetch).
+// operand traffic, which also frees LDS for a 4-stage weight ring (three k-steps of prefetch; the tile sweep found deeper rings no better).
 //
 //   k-step order : 64-channel slice outer, tap inner (weights are packed [Cout][tap][Cs]: k = tap*Cs + slice*64)
 //   LDS          : halo[2] (2 x 44,032 B) | weight ring STAGES x BN x 128 B | halo source-offset table
@@ -29,6 +29,7 @@ __device__ __attribute__((aligned(256))) unsigned char g_zero_page_halo[256];
 extern int g_v2_ablate;
 extern unsigned long long* g_v2_dbg;
 int g_halo_mfma32 = 0;
+int g_halo_bn = 0, g_halo_stages = 0;      // tile-size sweep options (0 = the shipped choice)
 
 typedef __attribute__((address_space(3))) void lds_void_h;
 typedef __attribute__((address_space(1))) const void gbl_void_h;
@@ -67,7 +68,10 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, cons
   constexpr int LB = BN / 64;                       // weight LDS-DMA instructions per wave per stage
   constexpr int B_STAGE = BN * 128;
   constexpr int AHEAD = STAGES - 1;
-  static_assert(TN >= 1 && STAGES >= 3, "tile shape");
+  // A 3-deep ring was tried in the tile sweep: it ran 3 % faster and produced WRONG results in a fraction of the launches
+  // (tests/diag_ring_depth.py) -- with two wave groups in anti-phase a stage is re-issued while the trailing group can still
+  // be reading it.  4 is the minimum the schedule below is correct for.
+  static_assert(TN >= 1 && STAGES >= 4, "tile shape");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned long long kt0 = ablate == 5 ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -410,16 +414,18 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, cons
   }
 }
 
-template <int BN, int STAGES>
+template <int BN, int STAGES, bool FULL = true>      // FULL = false: a sweep instance (tile-size report), default variant only
 static hipError_t launch_halo(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out,
                               int ldc, int act, const float* dequant, hipStream_t st) {
   const int tiles_m = g.N * (g.Ho / HALO_TH) * (g.Wo / HALO_TW);
   const int tiles_n = (ldc + BN - 1) / BN;
   const size_t lds = 2 * (size_t)HALO_BYTES + (size_t)STAGES * BN * 128 + HALO_GROUPS * 8 * sizeof(int);
   auto kern = halo_conv_kernel<BN, STAGES, false, true>;
-  if (g_halo_mfma32) kern = halo_conv_kernel<BN, STAGES, false, false>;     // A/B option: 32x32x16 MFMAs
-  if (g_v2_ablate == 6) kern = halo_conv_kernel<BN, STAGES, true, true>;   // diagnostic build: per-phase cycle stamps
-  if (dequant != nullptr) kern = halo_conv_kernel<BN, STAGES, false, true, true>;   // e4m3 operands
+  if constexpr (FULL) {
+    if (g_halo_mfma32) kern = halo_conv_kernel<BN, STAGES, false, false>;     // A/B option: 32x32x16 MFMAs
+    if (g_v2_ablate == 6) kern = halo_conv_kernel<BN, STAGES, true, true>;   // diagnostic build: per-phase cycle stamps
+    if (dequant != nullptr) kern = halo_conv_kernel<BN, STAGES, false, true, true>;   // e4m3 operands
+  }
   {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -442,6 +448,20 @@ hipError_t halo_conv(const GatherDesc& g, const void* src, const void* wgt, int 
   if ((long long)g.N * g.Hs * g.Ws * g.Cs >= (1ll << 31)) return hipErrorNotSupported;   // 32-bit offset table
   if (ldc < 64 || ldc % 8 != 0) return hipErrorNotSupported;
   const int tiles_m = g.N * (g.Ho / HALO_TH) * (g.Wo / HALO_TW);
+  if (dequant == nullptr && (g_halo_bn != 0 || g_halo_stages != 0)) {
+    // tile-size sweep (options halo_bn / halo_stages; profiles/sweep_tiles.py): output-channel tile width x weight-ring
+    // depth.  LDS = 88,064 B of halo + STAGES x BN x 128 B of ring (+ the offset table): 128x4 = 153.6 KB is the
+    // largest 128-wide one that fits the 160 KB, 64-wide tiles leave room for rings up to 8 deep.
+    const int bn = (g_halo_bn == 64 || ldc < 128) ? 64 : 128;
+    int stg = g_halo_stages != 0 ? g_halo_stages : 4;
+    if (bn == 128 && stg > 4) stg = 4;          // deeper rings do not fit beside a 128-wide tile
+    if (tiles_m * ((ldc + bn - 1) / bn) < num_cu / 2) return hipErrorNotSupported;
+    if (bn == 128 && stg == 4) return launch_halo<128, 4>(g, src, wgt, wrows, bias, out, ldc, act, dequant, st);
+    if (bn == 64 && stg == 4) return launch_halo<64, 4>(g, src, wgt, wrows, bias, out, ldc, act, dequant, st);
+    if (bn == 64 && stg == 6) return launch_halo<64, 6, false>(g, src, wgt, wrows, bias, out, ldc, act, dequant, st);
+    if (bn == 64 && stg == 8) return launch_halo<64, 8, false>(g, src, wgt, wrows, bias, out, ldc, act, dequant, st);
+    return hipErrorInvalidValue;
+  }
   if (ldc >= 128) {
     if (tiles_m * ((ldc + 127) / 128) < num_cu / 2) return hipErrorNotSupported;   // small grids: split-K v1 fills the chip better
     return launch_halo<128, 4>(g, src, wgt, wrows, bias, out, ldc, act, dequant, st);

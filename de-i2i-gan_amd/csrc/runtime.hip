@@ -15,6 +15,7 @@ extern int g_use_wgrad_halo;
 extern int g_use_wgrad_thin;
 extern int g_wt_splits_per_cu;
 extern int g_halo_mfma32;
+extern int g_halo_bn, g_halo_stages;
 extern unsigned long long* g_v2_dbg;
 static int g_cus = 256;
 void set_num_cu_rt(int n) { g_cus = n > 0 ? n : 256; }
@@ -80,6 +81,12 @@ int dei2i_set_option(const char* name, int value) {
   if (std::string(name) == "halo_conv") { set_use_halo(value); return 0; }
   if (std::string(name) == "thin_conv") { set_use_thin(value); return 0; }
   if (std::string(name) == "halo_mfma32") { g_halo_mfma32 = value; return 0; }
+  if (std::string(name) == "halo_bn") { if (value != 0 && value != 64 && value != 128) return DEI2I_ERR_BAD_ARG; g_halo_bn = value; return 0; }
+  if (std::string(name) == "halo_stages") {
+    if (value != 0 && value != 4 && value != 6 && value != 8) return DEI2I_ERR_BAD_ARG;
+    g_halo_stages = value;
+    return 0;
+  }
   if (std::string(name) == "splitk_atomic") { set_splitk_atomic(value); return 0; }
   if (std::string(name) == "wgrad_halo") { g_use_wgrad_halo = value; return 0; }
   if (std::string(name) == "wgrad_thin") { g_use_wgrad_thin = value; return 0; }

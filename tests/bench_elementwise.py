@@ -1,4 +1,4 @@
-"""Micro-benchmark of the HBM-bound kernels at the 256x256 batch-16 activation shapes: microseconds per launch and the
+"""Micro-benchmark of the HBM-bound kernels at the 256x256 batch-16 (or, with --size 512, the 512x512 batch-4) activation shapes: microseconds per launch and the
 achieved fraction of HBM bandwidth on ALGORITHMIC bytes (tensors each kernel must read / write once)."""
 import sys
 from ctypes import byref
@@ -13,8 +13,12 @@ lib = ops._lib_for(torch.zeros(1, device=DEV))
 st = ops._stream()
 p = ops._p
 BF = 0      # dtype code bf16
-N = 16
-only = sys.argv[1] if len(sys.argv) > 1 else ""
+# usage: bench_elementwise.py [name filter] [--size 512]   (--size 512: the batch-4 512x512 generator's activation shapes)
+SIZE = int(sys.argv[sys.argv.index("--size") + 1]) if "--size" in sys.argv else 256
+_args = [a for i, a in enumerate(sys.argv[1:], 1) if a != "--size" and sys.argv[i - 1] != "--size"]
+N = 16 if SIZE == 256 else 4
+only = _args[0] if _args else ""
+SHAPES = ((256, 256, 64), (128, 128, 128), (64, 64, 256)) if SIZE == 256 else ((512, 512, 64), (256, 256, 128), (128, 128, 256), (64, 64, 512))
 
 
 def timeit(name, fn, nbytes, reps=20):
@@ -33,7 +37,7 @@ def timeit(name, fn, nbytes, reps=20):
     print("%-44s %9.1f us  %7.1f MB  %6.2f TB/s  (%4.1f%% of 8 TB/s)" % (name, us, nbytes / 1e6, nbytes / us / 1e6, nbytes / us / 1e6 / 8 * 100), flush=True)
 
 
-for (H, W, C) in ((256, 256, 64), (128, 128, 128), (64, 64, 256)):
+for (H, W, C) in SHAPES:
     tag = "%dx%dx%d" % (H, W, C)
     pix = N * H * W
     T = pix * C * 2                      # bytes of one bf16 activation

@@ -360,3 +360,38 @@ def test_noise_inject_op(ops, pname):
     assert maxrel(o1, y1) < TOL[pname] and maxrel(o2, y2) < TOL[pname]
     assert maxrel(xg1.grad, gr1) < 1e-6 and maxrel(xg2.grad, gr2) < 1e-6
     assert wg.grad.shape == wt.shape and maxrel(wg.grad, wr.grad) < 2e-5
+
+
+def test_halo_conv_tile_variants_bit_identical(ops):
+    """The halo conv's tile options (output-channel width 64 | 128, weight ring 4 / 6 / 8 deep) change the LDS schedule,
+    not the arithmetic: forward and dgrad must come out bit-identical to the shipped tile, launch after launch.  (A
+    3-deep ring failed exactly this -- a race between the two wave groups -- and was removed.)"""
+    from de_i2i_gan_amd import _lib
+    lib = _lib.load()
+    try:
+        for cin, cout, hw, n, up in ((128, 64, 128, 8, False), (256, 128, 64, 16, False), (128, 128, 32, 16, True)):
+            torch.manual_seed(11)
+            geom = ops.ConvGeom(cin, cout, 3, 1, 1, True, up)
+            x = torch.randn(n, hw, hw, cin, device=dev()).bfloat16()
+            w = torch.randn(cout, cin, 3, 3, device=dev()) * 0.05
+            ho = hw * 2 if up else hw
+            gy = torch.randn(n, ho, ho, cout, device=dev()).bfloat16()
+
+            def run():
+                xd = x.detach().requires_grad_(True)
+                y = ops.conv2d(xd, w, None, ops.PackedWeights(), geom, "none")
+                (dx,) = torch.autograd.grad(y, xd, gy)
+                return y.detach().view(torch.int16).clone(), dx.detach().view(torch.int16).clone()
+
+            lib.dei2i_set_option(b"halo_bn", 0)
+            lib.dei2i_set_option(b"halo_stages", 0)
+            y0, d0 = run()
+            for bn, stg in ((0, 0), (64, 4), (64, 6), (64, 8)):
+                lib.dei2i_set_option(b"halo_bn", bn)
+                lib.dei2i_set_option(b"halo_stages", stg)
+                for _ in range(3):
+                    y, d = run()
+                    assert torch.equal(y, y0) and torch.equal(d, d0), (cin, cout, hw, bn, stg)
+    finally:
+        lib.dei2i_set_option(b"halo_bn", 0)
+        lib.dei2i_set_option(b"halo_stages", 0)
