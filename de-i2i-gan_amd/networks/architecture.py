@@ -292,14 +292,14 @@ class SPADE(nn.Module):
         geom = ops.ConvGeom(self.hidden_nc, 2 * self.norm_nc, self.mlp_gamma.kernel_size, 1, self.mlp_gamma.padding, False, False)
         return ops.conv2d(actv, w_gb, b_gb, self._packed_gb, geom, "none", sources=(self.mlp_gamma.weight, self.mlp_beta.weight))
 
-    def forward(self, x, segmap, up=False):
+    def forward(self, x, segmap, up=False, skip=False):
         prec = ops.precision_of(x)
         n, hs, ws, c = x.shape
         h, w = (2 * hs, 2 * ws) if up else (hs, ws)
         class_mode = segmap.shape[2] == 1 and segmap.shape[3] == 1 and h >= 4 and w >= 4
         self._ran_class_mode = class_mode                 # prime() only serves modules that run (norm_s never does)
         if not class_mode:
-            return ops.spade_relu(x, self._gamma_beta(segmap, prec, False, h, w), up, 0)
+            return ops.spade_relu(x, self._gamma_beta(segmap, prec, False, h, w), up, 0, skip=skip)
         # The class table depends only on (label map, this module's weights), not on x: the loss graphs call G several
         # times with the SAME label tensors (defectgan_model.py:185-190), so the table -- with its autograd history,
         # autograd sums the gradients of all its uses -- is computed once per (label tensor, weight state, grad mode).
@@ -312,7 +312,7 @@ class SPADE(nn.Module):
             self._gb_cache[key] = (segmap, gb)          # keep the label tensor alive so its id stays unique
         else:
             gb = hit[1]
-        return ops.spade_relu(x, gb, up, 1)
+        return ops.spade_relu(x, gb, up, 1, skip=skip)
 
     def _table_key(self, segmap, prec):
         params = (self.mlp_shared[0].weight, self.mlp_shared[0].bias, self.mlp_gamma.weight, self.mlp_gamma.bias,
@@ -391,9 +391,11 @@ class NormResBlock(nn.Module):
         self.conv_s = make_conv(use_spectral, f_in, f_out, kernel_size, stride, padding, padding_mode, bias)
 
     def forward(self, x, labels, style_feat=None):
-        h = self.noise_0(self.conv_0(self.norm_0(x, labels)))
+        # norm_0 hands x through (xs) so that the identity branch's gradient is added inside its backward kernel
+        z, xs = self.norm_0(x, labels, skip=True) if x.is_contiguous() else (self.norm_0(x, labels), x)
+        h = self.noise_0(self.conv_0(z))
         h = self.noise_1(self.conv_1(self.norm_1(h, labels)))
-        return ops.add(h, x)
+        return ops.add(h, xs)
 
 
 class MaskToken(nn.Module):

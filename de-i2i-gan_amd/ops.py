@@ -612,10 +612,15 @@ class _AffineAdd(torch.autograd.Function):
 # --------------------------------------------------------------------------------------------------------------
 class _SpadeRelu(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gb, up: bool, gb_mode: int, eps: float):
+    def forward(ctx, x, gb, up: bool, gb_mode: int, eps: float, skip: bool = False):
+        # skip: also hand x through as a second output (the res block's identity branch), so that the gradient arriving
+        # on that branch is added inside the backward-apply kernel instead of by a separate autograd add launch
         _require_gpu(x, "spade_relu")
         prec = precision_of(x)
+        x_in = x
         x, gb = x.contiguous(), gb.contiguous()
+        if skip and (up or x is not x_in):
+            raise ValueError("spade_relu(skip=True) wants a contiguous activation and no upsample")
         n, hs, ws, c = x.shape
         h, w = (hs * 2, ws * 2) if up else (hs, ws)
         lib = _lib_for(x)
@@ -637,11 +642,17 @@ class _SpadeRelu(torch.autograd.Function):
         ctx.prec, ctx.up, ctx.gb_mode = prec, up, gb_mode
         ctx.out_shape = (n, h, w, c)
         ctx.save_for_backward(x, gb, mean, rstd)        # backward recomputes the ReLU mask; the output is not kept
-        return out
+        return (out, x_in) if skip else out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dskip=None):
         x, gb, mean, rstd = ctx.saved_tensors
+        if dout is None:                                 # only the identity branch was used
+            return dskip, None, None, None, None, None
+        if dskip is not None:
+            dskip = dskip.contiguous()
+            if dskip.dtype != x.dtype or dskip.shape != x.shape:
+                raise RuntimeError("spade_relu: identity-branch gradient does not match the activation")
         prec, up, gb_mode = ctx.prec, ctx.up, ctx.gb_mode
         lib = _lib_for(x)
         st = _stream()
@@ -656,13 +667,17 @@ class _SpadeRelu(torch.autograd.Function):
         coef = torch.empty((n, 2, c), dtype=torch.float32, device=dev)
         dx = torch.empty_like(x)
         L.check(lib.dei2i_spade_bwd_apply(prec.code, n, h, w, c, 1 if up else 0, _p(dout), _p(x), _p(mean), _p(rstd), _p(gb), gb_mode,
-                                          _p(partial), chunks, _p(dgb) if gb_mode == 1 else None, _p(coef), None, _p(dx), st),
+                                          _p(partial), chunks, _p(dgb) if gb_mode == 1 else None, _p(coef), _p(dskip), _p(dx), st),
                 "spade_bwd_apply")
-        return dx, dgb, None, None, None
+        return dx, dgb, None, None, None, None
 
 
-def spade_relu(x, gb, up: bool, gb_mode: int, eps: float = 1e-5):
+def spade_relu(x, gb, up: bool, gb_mode: int, eps: float = 1e-5, skip: bool = False):
+    """relu(IN(x) * (1 + gamma) + beta); with ``skip`` -> (that, x): x handed through for the res block's identity add."""
     del _fp8_stash[:]
+    if skip:
+        out, xs = _SpadeRelu.apply(x, gb, bool(up), int(gb_mode), float(eps), True)
+        return _attach_fp8(out), xs
     return _attach_fp8(_SpadeRelu.apply(x, gb, bool(up), int(gb_mode), float(eps)))
 
 

@@ -74,8 +74,9 @@ class record_kinks:
 
             def apply(*a, _orig=orig, _pick=pick):
                 out = _orig(*a)
-                if out.requires_grad:
-                    r = _pick(a, out)
+                first = out[0] if isinstance(out, tuple) else out        # (z, x handed through) of spade_relu(skip=True)
+                if first.requires_grad:
+                    r = _pick(a, first)
                     if r is not None:
                         self.tape.append((r[0], r[1].detach().double().cpu()) + tuple(r[2:]))
                 return out
