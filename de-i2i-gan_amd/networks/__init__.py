@@ -1,17 +1,27 @@
-"""Checkpoint I/O with the reference's file naming and key handling (models/networks/__init__.py:4-23)."""
+"""Checkpoint files of one network, named and filtered like the reference's (models/networks/__init__.py:4-23):
+``<ckpt_dir>/<run name>/<epoch>_net_<label>.pth`` holds the plain ``state_dict``."""
 import torch
 
 
+def _checkpoint_path(opt, run_name, net_label, epoch):
+    return opt.ckpt_dir / run_name / f"{epoch}_net_{net_label}.pth"
+
+
 def save_network(net, net_label, epoch, opt):
-    save_dir = opt.ckpt_dir / opt.name
-    save_dir.mkdir(parents=True, exist_ok=True)
-    torch.save(net.state_dict(), save_dir / f"{epoch}_net_{net_label}.pth")
+    path = _checkpoint_path(opt, opt.name, net_label, epoch)
+    path.parent.mkdir(parents=True, exist_ok=True)
+    torch.save(net.state_dict(), path)
+
+
+def _reference_key(key):
+    # older checkpoints of the reference carry 'spade_' / 'sean_' in their keys; it strips both on load (:21)
+    return key.replace("spade_", "").replace("sean_", "")
 
 
 def load_network(net, net_label, epoch, opt):
-    save_path = opt.ckpt_dir / opt.load_model_name / f"{epoch}_net_{net_label}.pth"
-    weights = torch.load(save_path, map_location="cpu", weights_only=True)
-    # reference: strip 'spade_' / 'sean_' prefixes, drop 'mlp_latent' keys, strict=False (networks/__init__.py:21-22)
-    weights = {k.replace("spade_", "").replace("sean_", ""): v for k, v in weights.items() if "mlp_latent" not in k}
-    net.load_state_dict(weights, strict=False)
+    """Tensors only (``weights_only=True``); 'mlp_latent' entries are dropped and missing / unexpected keys tolerated
+    (``strict=False``) exactly as the reference does (:21-22).  Returns the network on ``opt.device``."""
+    stored = torch.load(_checkpoint_path(opt, opt.load_model_name, net_label, epoch), map_location="cpu", weights_only=True)
+    state = {_reference_key(k): v for k, v in stored.items() if "mlp_latent" not in k}
+    net.load_state_dict(state, strict=False)
     return net.to(opt.device, non_blocking=True)

@@ -1,12 +1,47 @@
-"""BaseNetwork -- same surface as the reference (models/networks/base_network.py:5-65)."""
+"""BaseNetwork -- the surface the reference's networks share (models/networks/base_network.py:5-65): ``device``,
+``print_network``, ``init_weights(init_type, gain)``, ``update_per_epoch(epoch)``."""
 import torch.nn as nn
 from torch.nn import init
 
+# init_type -> filler of a Conv* / Linear* weight (the reference's choices, base_network.py:36-51)
+_WEIGHT_FILL = {
+    "normal": lambda w, gain: init.normal_(w, 0.0, gain),
+    "xavier": lambda w, gain: init.xavier_normal_(w, gain=gain),
+    "xavier_uniform": lambda w, gain: init.xavier_uniform_(w, gain=1.0),
+    "kaiming": lambda w, gain: init.kaiming_normal_(w, a=0, mode="fan_in"),
+    "orthogonal": lambda w, gain: init.orthogonal_(w, gain=gain),
+}
+
+
+def _clear_bias(module):
+    bias = getattr(module, "bias", None)
+    if bias is not None:
+        init.constant_(bias.data, 0.0)
+
+
+def _init_module(module, init_type, gain):
+    """One module of the tree, chosen by class NAME like the reference does (so wrappers and subclasses whose names
+    contain 'Conv' / 'Linear' / 'BatchNorm2d' are caught the same way): BatchNorm2d weight ~ N(1, gain), Conv* / Linear*
+    weight by ``init_type``, every bias 0."""
+    kind = type(module).__name__
+    if "BatchNorm2d" in kind:
+        if getattr(module, "weight", None) is not None:
+            init.normal_(module.weight.data, 1.0, gain)
+        _clear_bias(module)
+        return
+    if not (("Conv" in kind or "Linear" in kind) and hasattr(module, "weight")):
+        return
+    if init_type == "none":
+        module.reset_parameters()
+    else:
+        fill = _WEIGHT_FILL.get(init_type)
+        if fill is None:
+            raise NotImplementedError("initialization method [%s] is not implemented" % init_type)
+        fill(module.weight.data, gain)
+    _clear_bias(module)
+
 
 class BaseNetwork(nn.Module):
-    def __init__(self):
-        super().__init__()
-
     @staticmethod
     def modify_commandline_options(parser, is_train):
         return parser
@@ -16,44 +51,17 @@ class BaseNetwork(nn.Module):
         return next(self.parameters()).device
 
     def print_network(self):
-        num_params = sum(p.numel() for p in self.parameters())
-        print("Network [%s] was created. Total number of parameters: %.1f million. "
-              "To see the architecture, do print(network)." % (type(self).__name__, num_params / 1000000))
+        millions = sum(p.numel() for p in self.parameters()) / 1e6
+        print(f"Network [{type(self).__name__}] was created. Total number of parameters: {millions:.1f} million. "
+              "To see the architecture, do print(network).")
 
     def init_weights(self, init_type="normal", gain=0.02):
-        """Class-name-substring dispatch exactly as the reference does it (base_network.py:27-56): BatchNorm2d
-        weight ~ N(1, gain), bias 0; Conv*/Linear* weights by `init_type`, bias 0."""
-
-        def init_func(m):
-            classname = m.__class__.__name__
-            if classname.find("BatchNorm2d") != -1:
-                if hasattr(m, "weight") and m.weight is not None:
-                    init.normal_(m.weight.data, 1.0, gain)
-                if hasattr(m, "bias") and m.bias is not None:
-                    init.constant_(m.bias.data, 0.0)
-            elif hasattr(m, "weight") and (classname.find("Conv") != -1 or classname.find("Linear") != -1):
-                if init_type == "normal":
-                    init.normal_(m.weight.data, 0.0, gain)
-                elif init_type == "xavier":
-                    init.xavier_normal_(m.weight.data, gain=gain)
-                elif init_type == "xavier_uniform":
-                    init.xavier_uniform_(m.weight.data, gain=1.0)
-                elif init_type == "kaiming":
-                    init.kaiming_normal_(m.weight.data, a=0, mode="fan_in")
-                elif init_type == "orthogonal":
-                    init.orthogonal_(m.weight.data, gain=gain)
-                elif init_type == "none":
-                    m.reset_parameters()
-                else:
-                    raise NotImplementedError("initialization method [%s] is not implemented" % init_type)
-                if hasattr(m, "bias") and m.bias is not None:
-                    init.constant_(m.bias.data, 0.0)
-
-        self.apply(init_func)
-        for m in self.children():
-            if hasattr(m, "init_weights"):
-                m.init_weights(init_type, gain)
+        # whole tree first, then child networks that bring their own init_weights (base_network.py:27-61) -- the order
+        # fixes the order of the RNG draws
+        self.apply(lambda m: _init_module(m, init_type, gain))
+        for child in self.children():
+            if hasattr(child, "init_weights"):
+                child.init_weights(init_type, gain)
 
     def update_per_epoch(self, epoch):
-        """update network per epoch"""
-        pass
+        """hook the trainers call once per epoch; nothing to do for the SPADE generator / discriminator"""

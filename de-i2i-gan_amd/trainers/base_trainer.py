@@ -10,37 +10,29 @@ from ..models import create_model
 from ..optim import FusedAdam
 
 
+# opt.optimizer -> keyword arguments of the fused optimizer (the reference builds torch.optim.Adam(betas=(0.5, 0.999)) /
+# torch.optim.AdamW(betas=(0.9, 0.95)) with AdamW's default weight decay: trainers/base_trainer.py:75-80)
+_OPTIMIZER_ARGS = {
+    "adam": {"betas": (0.5, 0.999)},
+    "adamw": {"betas": (0.9, 0.95), "weight_decay": 1e-2},
+}
+_STEP_LR_STAGES = 4          # 'step' schedule: lr_decay is reached after four equal stages (base_trainer.py:94-98)
+
+
 class BaseTrainer:
+    """Same attributes and resume rules as the reference's BaseTrainer (trainers/base_trainer.py:12-131): ``model``,
+    ``losses`` / ``dis_outputs`` (dict of lists), ``iters`` / ``first_epoch`` (restored from ``iter.txt`` when continuing),
+    ``optimizers`` / ``schedulers`` keyed by network name; the schedulers are stepped ``first_epoch`` times at construction
+    like the reference does."""
+
     def __init__(self, opt):
         self.opt = opt
         self.model = create_model(opt)
-        if opt.continue_training:
-            self.model.load("latest")
-        elif opt.load_model_name is not None:
-            self.model.load(opt.which_epoch)
-        else:
-            self.model.init_weights()
-
-        self.losses = defaultdict(list)
-        self.dis_outputs = defaultdict(list)
+        self._restore_or_init_weights(opt)
+        self.losses, self.dis_outputs = defaultdict(list), defaultdict(list)
         if opt.phase == "val":
-            self.metrics = dict()
-
-        self.iter_record_path = opt.ckpt_dir / opt.name / "iter.txt"
-        self.first_epoch = 1
-        self.iters = 0
-        assert hasattr(self.opt, "iters_per_epoch"), "opt must have attribute {iters_per_epoch}, " \
-                                                     "it can be calculated by length of loader"
-        if opt.continue_training:
-            self.first_epoch, self.iters = np.loadtxt(self.iter_record_path, delimiter=",", dtype=int)
-        if self.opt.num_epochs == -1:
-            self.opt.num_epochs = math.ceil(self.opt.num_iters / (self.opt.iters_per_epoch + 1e-12))
-        self.opt.num_iters = self.opt.num_epochs * self.opt.iters_per_epoch
-        assert self.first_epoch < self.opt.num_epochs, f"first_epoch {self.first_epoch} should not larger than " \
-                                                       f"num_epochs {self.opt.num_epochs}"
-        assert self.iters < self.opt.num_iters, f"iters {self.iters} should not larger than num_iters {self.opt.num_iters}"
-        self.opt.first_epoch = self.first_epoch
-
+            self.metrics = {}
+        self._resume_progress(opt)
         self._init_lr(opt)
         self._create_optimizer(opt)
         self._create_scheduler(opt)
@@ -49,54 +41,61 @@ class BaseTrainer:
         self.defer_loss_sync = bool(getattr(opt, "defer_loss_sync", False))
         self._pending = []
 
+    def _restore_or_init_weights(self, opt):
+        if opt.continue_training:
+            self.model.load("latest")
+        elif opt.load_model_name is not None:
+            self.model.load(opt.which_epoch)
+        else:
+            self.model.init_weights()
+
+    def _resume_progress(self, opt):
+        """Epoch / iteration counters and the derived run length (num_epochs == -1 means 'from num_iters')."""
+        if not hasattr(opt, "iters_per_epoch"):
+            raise AssertionError("opt must have attribute {iters_per_epoch}, it can be calculated by length of loader")
+        self.iter_record_path = opt.ckpt_dir / opt.name / "iter.txt"
+        self.first_epoch, self.iters = 1, 0
+        if opt.continue_training:
+            self.first_epoch, self.iters = np.loadtxt(self.iter_record_path, delimiter=",", dtype=int)
+        if opt.num_epochs == -1:
+            opt.num_epochs = math.ceil(opt.num_iters / (opt.iters_per_epoch + 1e-12))
+        opt.num_iters = opt.num_epochs * opt.iters_per_epoch
+        if not self.first_epoch < opt.num_epochs:
+            raise AssertionError(f"first_epoch {self.first_epoch} should not larger than num_epochs {opt.num_epochs}")
+        if not self.iters < opt.num_iters:
+            raise AssertionError(f"iters {self.iters} should not larger than num_iters {opt.num_iters}")
+        opt.first_epoch = self.first_epoch
+
     def _init_lr(self, opt):
         self.lr = opt.lr[0]
 
+    def _lr_of(self, network_name):
+        return self.lr[network_name] if isinstance(self.lr, dict) else self.lr
+
     def _create_optimizer(self, opt):
-        assert isinstance(self.lr, (int, float, dict)), "type of lr should be scalar or dict"
-        optim_args = dict()
-        if opt.optimizer == "adam":
-            optim_cls = FusedAdam                       # torch.optim.Adam(betas=(0.5, 0.999)) in the reference (:75-77)
-            optim_args["betas"] = (0.5, 0.999)
-        elif opt.optimizer == "adamw":
-            optim_cls = FusedAdam                       # torch.optim.AdamW(betas=(0.9, 0.95)) in the reference (:78-80)
-            optim_args["betas"] = (0.9, 0.95)
-            optim_args["weight_decay"] = 1e-2           # torch.optim.AdamW's default, which the reference relies on
-        elif opt.optimizer in ("sgd", "rmsprop"):
+        if not isinstance(self.lr, (int, float, dict)):
+            raise AssertionError("type of lr should be scalar or dict")
+        if opt.optimizer in ("sgd", "rmsprop"):
             raise NotImplementedError(f"optimizer [{opt.optimizer}]: only 'adam' / 'adamw' have a fused kernel")
-        else:
+        if opt.optimizer not in _OPTIMIZER_ARGS:
             raise NameError(f"optimizer named {opt.optimizer} not defined")
-        self.optimizers = {}
-        for network_name, network in self.model.networks.items():
-            optim_args["lr"] = self.lr[network_name] if isinstance(self.lr, dict) else self.lr
-            self.optimizers[network_name] = optim_cls(network.parameters(), **optim_args)
+        self.optimizers = {name: FusedAdam(net.parameters(), lr=self._lr_of(name), **_OPTIMIZER_ARGS[opt.optimizer])
+                           for name, net in self.model.networks.items()}
+
+    def _scheduler_for(self, opt, name, optimizer):
+        kind = opt.scheduler
+        if kind == "step":
+            return optim.lr_scheduler.StepLR(optimizer, step_size=opt.num_epochs // _STEP_LR_STAGES,
+                                             gamma=opt.lr_decay ** (1 / _STEP_LR_STAGES))
+        if kind == "exp":
+            return optim.lr_scheduler.ExponentialLR(optimizer, gamma=opt.lr_decay ** (1 / opt.num_epochs))
+        if kind == "cos":                          # anneals to lr * lr_decay over the run (base_trainer.py:103-111)
+            return optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=opt.num_epochs, eta_min=self._lr_of(name) * opt.lr_decay)
+        raise NameError(f"scheduler named {kind} not defined")
 
     def _create_scheduler(self, opt):
-        sched_args = dict()
-        ext_args = defaultdict(dict)
-        if opt.scheduler == "step":
-            sched_cls = optim.lr_scheduler.StepLR
-            step_cnt = 4
-            sched_args["step_size"] = opt.num_epochs // step_cnt
-            sched_args["gamma"] = opt.lr_decay ** (1 / step_cnt)
-        elif opt.scheduler == "exp":
-            sched_cls = optim.lr_scheduler.ExponentialLR
-            sched_args["gamma"] = opt.lr_decay ** (1 / opt.num_epochs)
-        elif opt.scheduler == "cos":
-            sched_cls = optim.lr_scheduler.CosineAnnealingLR
-            sched_args["T_max"] = opt.num_epochs
-        else:
-            raise NameError(f"scheduler named {opt.scheduler} not defined")
-        if opt.scheduler == "cos":
-            for network_name in self.model.networks:
-                base = self.lr[network_name] if isinstance(self.lr, dict) else self.lr
-                ext_args["eta_min"][network_name] = base * opt.lr_decay
-        self.schedulers = dict()
-        for model_name, optimizer in self.optimizers.items():
-            for key, value in ext_args.items():
-                sched_args[key] = value[model_name]
-            self.schedulers[model_name] = sched_cls(optimizer, **sched_args)
-        for _ in range(self.first_epoch):
+        self.schedulers = {name: self._scheduler_for(opt, name, o) for name, o in self.optimizers.items()}
+        for _ in range(self.first_epoch):          # the reference fast-forwards to first_epoch (>= 1) at construction
             for scheduler in self.schedulers.values():
                 scheduler.step()
 
@@ -120,5 +119,5 @@ class BaseTrainer:
             self._pending = []
 
     def _update_per_epoch(self, epoch=None):
-        for model_name in self.schedulers.keys():
-            self.schedulers[model_name].step()
+        for scheduler in self.schedulers.values():
+            scheduler.step()
