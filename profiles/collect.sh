@@ -17,3 +17,8 @@ echo "[collect] FETCH_SIZE pass done"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$root/gpurun_out/pmc_write_$tag" -o runc -- python3 "$root/bench.py" --steps 2 --warmup 1 \
     --no-cpu-baseline --no-roofline > "$root/gpurun_out/pmc_write_$tag.log" 2>&1
 echo "[collect] WRITE_SIZE pass done"
+# 4th pass: MFMA pipe occupancy per dispatch (SQ_VALU_MFMA_BUSY_CYCLES summed over all SIMDs; GRBM_GUI_ACTIVE = GPU-busy cycles)
+cd /tmp
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$root/gpurun_out/pmc_mfma_$tag" -o runc -- python3 "$root/bench.py" --steps 2 --warmup 1 \
+    --no-cpu-baseline --no-roofline > "$root/gpurun_out/pmc_mfma_$tag.log" 2>&1
+echo "[collect] MFMA busy pass done"
