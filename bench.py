@@ -259,10 +259,16 @@ def main():
                 traffic = t["halo_conv"]["hbm_bytes_per_launch"]
                 traffic_src = ("profiles/r01_g_pmc_traffic.json (profiles/collect.sh + summarize.py): (2*FETCH_SIZE + WRITE_SIZE)"
                                "*1024 bytes per halo_conv_kernel launch, separate --pmc passes")
+        mfma_pmc = None
+        pmc2 = os.path.join(REPO, "profiles", "r01_g_pmc_mfma.json")          # rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES pass
+        if args.dtype == "bf16" and args.image_size == 256 and args.batch == 16 and os.path.exists(pmc2):
+            with open(pmc2) as f:
+                mfma_pmc = json.load(f).get("halo_conv", {}).get("mfma_busy_frac")
         line["roofline"] = {"bound": "mfma", "kernel": "halo_conv_kernel (stride-1 3x3 conv forward + zero-boundary dgrad; "
                             "the step's dominant kernel, ~30 % of its device time)",
                             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                             "traffic_source": traffic_src,
+                            "mfma_busy_frac_pmc": mfma_pmc,      # same kernel, counters of a separate profiled run (profiles/)
                             "launches_per_step": hn / args.steps, "avg_launch_ms": hms / max(hn, 1),
                             "flops_per_launch": hfl / max(hn, 1),
                             "all_conv_fwd_dgrad_kernels": {"achieved": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
