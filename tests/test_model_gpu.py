@@ -11,7 +11,7 @@ Tolerances
   Quantities behind an Adam update use the noise floors recorded with the goldens (Adam's first steps are sign-like);
   in addition the t0 golden's G step sits behind a D update that leaves a LeakyReLU pre-activation of the 2x2 final D
   feature map within fp32 rounding of 0 for `fake_defects`, so the golden G grad norms are only matched to 15%
-  (diagnosed with tests/diag_gstep.py: with identical D inputs the HIP gradient equals the fp64 oracle to 3e-6)."""
+  (diagnosed with tools/diag_gstep.py: with identical D inputs the HIP gradient equals the fp64 oracle to 3e-6)."""
 import functools
 
 import numpy as np
@@ -185,7 +185,7 @@ def test_two_train_steps_match_reference_goldens(name, pname):
         got = [L["gan"]["D"][-1], L["clf"]["D"][-1], L["gan"]["G"][-1], L["clf"]["G"][-1], L["aux"]["rec"][-1],
                L["aux"]["cyc"][-1], L["aux"]["con"][-1]]
         # step 2 sits behind two sign-like Adam updates; in bf16 the formula-filled nets are chaotic on top of that (a
-        # one-ulp difference grows ~4x per res-block layer, tests/diag_first_use.py): measured 0.05..0.22 run to run and
+        # one-ulp difference grows ~4x per res-block layer, tools/diag_first_use.py): measured 0.05..0.22 run to run and
         # kernel to kernel, so only a coarse bound is meaningful there -- f32 keeps the recorded noise floor
         tol = ltol if it == 0 else max(c["tol_step2"], 2e-2 if pname == "f32" else 0.4)
         assert maxrel(np.array(got), arr["losses"][it]) < tol, (it, got, arr["losses"][it].tolist())
@@ -202,7 +202,7 @@ def test_two_train_steps_match_reference_goldens(name, pname):
                 assert maxrel(sdg[k], arr["bn::" + k]) < c.get("tol_running", 5e-2), k
             elif k.startswith(("stem.", "enc_blk.0.", "enc_blk.1.")):
                 # bf16: the formula-filled nets are chaotic -- a one-ulp difference grows ~4x per res-block layer
-                # (tests/diag_first_use.py t1 bf16: 1e-4 -> 3e-2 over five layers, run to run) -- so the 2^-9 activation
+                # (tools/diag_first_use.py t1 bf16: 1e-4 -> 3e-2 over five layers, run to run) -- so the 2^-9 activation
                 # rounding swamps the deep res-block statistics; only the first three BatchNorms are comparable
                 # (measured <= 0.09).  test_bf16_tracks_f32_with_reference_init covers the realistic case.
                 assert maxrel(sdg[k], arr["bn::" + k]) < 0.2, k

@@ -3,7 +3,7 @@ import sys
 from pathlib import Path
 import numpy as np
 import torch
-sys.path.insert(0, str(Path(__file__).resolve().parents[1])); sys.path.insert(0, str(Path(__file__).resolve().parent))
+sys.path.insert(0, str(Path(__file__).resolve().parents[1])); sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tests"))
 from helpers import formula_fill, load_golden, make_opt
 from de_i2i_gan_amd.trainers.defectgan_trainer import DefectGanTrainer
 name = sys.argv[1] if len(sys.argv) > 1 else "t1_img64_b4"

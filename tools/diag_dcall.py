@@ -2,7 +2,7 @@
 import sys
 from pathlib import Path
 import torch
-sys.path.insert(0, str(Path(__file__).resolve().parents[1])); sys.path.insert(0, str(Path(__file__).resolve().parent))
+sys.path.insert(0, str(Path(__file__).resolve().parents[1])); sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tests"))
 from helpers import formula_fill, make_opt
 from oracle import defectgan_oracle as O
 from de_i2i_gan_amd import ops

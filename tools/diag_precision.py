@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
-sys.path.insert(0, str(Path(__file__).resolve().parent))
+sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tests"))
 from helpers import formula_fill, make_opt  # noqa: E402
 from oracle import defectgan_oracle as O  # noqa: E402
 
