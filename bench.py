@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=INT",
                     help="library option for A/B runs on one box, e.g. halo_conv=0 (dei2i_set_option)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child process of the default run
+    ap.add_argument("--spawn-selftest", default=None, help=argparse.SUPPRESS)             # tests: rendezvous of the spawned ranks over gloo, no GPU
     return ap.parse_args()
 
 
@@ -144,13 +145,55 @@ def cpu_baseline_bounded(limit_s=240):
                 "sample": "oracle run exceeded the %d s wall-clock limit on this host and was stopped" % limit_s}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` invoked directly (no launcher set WORLD_SIZE): start the N rank processes -- one per
+    GPU -- as CHILDREN of this process, which itself never touches the GPU, hand each the torch.distributed.run
+    environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT), and return the worst exit code.
+    Rank 0 prints the one JSON line on the shared stdout."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc, live = 0, list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:               # a rank died: its peers would wait in a collective forever
+                    q.terminate()
+    return rc
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline()))
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     import torch
     import torch.distributed as dist
+    if args.spawn_selftest:                  # CPU test of the launcher: the ranks find each other and agree on a sum
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(os.environ["RANK"]) + 1.0])
+        dist.all_reduce(t)
+        with open(f"{args.spawn_selftest}.{os.environ['RANK']}", "w") as f:
+            f.write("%s %s %s %s %g" % (os.environ["RANK"], os.environ["LOCAL_RANK"], os.environ["WORLD_SIZE"], os.environ["MASTER_ADDR"], t.item()))
+        dist.destroy_process_group()
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -180,8 +223,7 @@ def main():
     else:
         tr = DefectGanTrainer(opt)
         step = lambda: tr.step(bg, lab, df)                  # noqa: E731
-    if world > 1:
-        attach_ddp(tr)
+    red = attach_ddp(tr, measure=True) if world > 1 else None
     bg, lab, df = synthetic_batch(args.batch, args.image_size, seed=7 + rank)
     bg, lab, df = bg.to(device), lab.to(device), df.to(device)
 
@@ -196,6 +238,8 @@ def main():
         step()
     lib = _lib.load()
     sync()
+    if red is not None:
+        red.overlap_report()                          # drop the warm-up steps' events
     if not args.no_roofline:
         for fid in (_lib.PROF_GATHER_GEMM, _lib.PROF_WGRAD, _lib.PROF_HALO_CONV):
             lib.dei2i_prof_enable(fid, 1)
@@ -211,6 +255,7 @@ def main():
             _lib.check(lib.dei2i_prof_collect(fid, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)), "prof_collect")
             fam[name] = (n.value, ms.value, fl.value)
             lib.dei2i_prof_enable(fid, 0)
+    ddp = red.overlap_report() if red is not None else None
     if hasattr(tr, "flush_losses"):
         tr.flush_losses()
     if rank == 0:
@@ -279,6 +324,12 @@ def main():
                         "step_mfma_util": conv_flops_step / (ms_per_step * 1e-3) / (peak * 1e12),
                         "wgrad_tflops": wfl / (wms * 1e-3) / 1e12 if wms > 0 else 0.0,
                         "conv_kernel_time_frac_of_step": (ms + wms) / args.steps / ms_per_step}
+    if ddp is not None:
+        # rank 0's view: time the gradient all-reduces occupied the side stream per backward pass, and the part that ran
+        # after backward's last kernel (the optimizer waits for it) -- stream events, measured inside the timed region
+        ddp.update({"collectives_per_step": red.stats["collectives"] / (args.steps + args.warmup),
+                    "allreduce_mb_per_step": red.stats["bytes"] / (args.steps + args.warmup) / 1e6})
+        line["ddp"] = ddp
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_bounded()
     print(json.dumps(line))

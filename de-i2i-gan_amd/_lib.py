@@ -88,6 +88,9 @@ SIGNATURES = {
     "dei2i_adam_step": (c_int, [_P, c_int, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_float, _P]),
     "dei2i_prof_enable": (c_int, [c_int, c_int]),
     "dei2i_prof_collect": (c_int, [c_int, POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),
+    "dei2i_launch_counts": (c_int, [POINTER(c_int64), c_int]),
+    "dei2i_launch_counts_reset": (None, []),
+    "dei2i_kernel_name": (c_char_p, [c_int]),
 }
 
 _lib = None
@@ -113,6 +116,17 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def launch_counts(reset=False):
+    """{kernel family name: host-side launch count since the last reset} of the MFMA kernels (dei2i_launch_counts)."""
+    lib = load()
+    buf = (c_int64 * 32)()
+    n = lib.dei2i_launch_counts(buf, 32)
+    out = {lib.dei2i_kernel_name(i).decode(): int(buf[i]) for i in range(n)}
+    if reset:
+        lib.dei2i_launch_counts_reset()
+    return out
 
 
 def check(rc, what=""):

@@ -585,6 +585,7 @@ static hipError_t launch_gg(const DescPack& pack, const void* src, const void* w
     if (e != hipSuccess) return e;
     attr_done = true;
   }
+  count_launch(K_GATHER_V1);
   prof_begin(PROF_GATHER_GEMM, flops, st);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, pack, (const T*)src, (const T*)wgt, wrows, bias, (T*)out,
                      zs > 1 ? ws : (float*)nullptr, ldc, act, tiles_n, kps, slab_rows);
@@ -724,6 +725,7 @@ static hipError_t launch_wg(const GatherDesc& g, const void* src, const void* dy
     attr_done = true;
   }
   if (slabs) *nsplit_out = zs;
+  count_launch(K_WGRAD_V1);
   prof_begin(PROF_WGRAD, 2.0 * (double)g.M * (double)(g.th * g.tw) * (double)g.Clog * (double)co_rows, st);
   hipLaunchKernelGGL(kern, dim3(tiles, 1, zs), dim3(256), lds, st, g, (const T*)src, (const T*)dy, co_rows, ldy, dw,
                      tiles_k, cps, slabs ? slab_elems : 0ll);

@@ -288,6 +288,7 @@ static hipError_t launch_v2(const DescPack& pack, const void* src, const void* w
     if (e != hipSuccess) return e;
     attr_done = true;
   }
+  count_launch(K_GATHER_V2);
   prof_begin(PROF_GATHER_GEMM, flops, st);
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, pack.n, zs), dim3(512), lds, st, pack, (const bf16_t*)src,
                      (const bf16_t*)wgt, wrows, bias, (bf16_t*)out, zs > 1 ? ws : (float*)nullptr, ldc, act, tiles_n, kps, g_v2_ablate, g_v2_dbg);

@@ -431,6 +431,7 @@ static hipError_t launch_halo(const GatherDesc& g, const void* src, const void* 
     if (e != hipSuccess) return e;
   }
   // (fp8: g describes byte pairs, so Clog is half the channel count)
+  count_launch(dequant != nullptr ? K_HALO_CONV_FP8 : K_HALO_CONV);
   prof_begin(PROF_HALO_CONV, (dequant != nullptr ? 4.0 : 2.0) * (double)g.M * (double)(g.th * g.tw) * (double)g.Clog * (double)wrows, st);
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, st, g, (const bf16_t*)src, (const bf16_t*)wgt, wrows, bias,
                      (bf16_t*)out, ldc, act, tiles_n, g_v2_ablate == 6 ? 5 : g_v2_ablate, g_v2_dbg, dequant);

@@ -29,6 +29,11 @@ struct ProfState {
 };
 static ProfState g_prof[PROF_FAMILIES];
 
+static long long g_launches[K_COUNT];
+void count_launch(int kid) { g_launches[kid]++; }
+static const char* const g_kernel_names[K_COUNT] = {"gather_v1", "gather_v2", "halo_conv", "halo_conv_fp8", "thin_cin", "thin_cout",
+                                                    "wgrad_v1", "wgrad_v2", "wgrad_halo", "wgrad_thin"};
+
 void prof_begin(int family, double flops, hipStream_t st) {
   ProfState& p = g_prof[family];
   if (!p.on) return;
@@ -96,6 +101,13 @@ int dei2i_set_option(const char* name, int value) {
 }
 
 int dei2i_set_debug_buffer(void* p) { g_v2_dbg = (unsigned long long*)p; return 0; }
+
+int dei2i_launch_counts(int64_t* out, int n) {
+  for (int i = 0; i < n && i < K_COUNT; ++i) out[i] = (int64_t)g_launches[i];
+  return K_COUNT;
+}
+void dei2i_launch_counts_reset(void) { for (int i = 0; i < K_COUNT; ++i) g_launches[i] = 0; }
+const char* dei2i_kernel_name(int kid) { return kid >= 0 && kid < K_COUNT ? g_kernel_names[kid] : nullptr; }
 
 int dei2i_prof_enable(int family, int on) {
   if (family < 0 || family >= PROF_FAMILIES) return DEI2I_ERR_BAD_ARG;

@@ -191,6 +191,7 @@ static hipError_t launch_thin(const GatherDesc& g, const void* src, const void* 
     if (e != hipSuccess) return e;
     lds_set = lds;
   }
+  count_launch(K_THIN_CIN);
   prof_begin(PROF_GATHER_GEMM, 2.0 * (double)g.M * (double)(g.th * g.tw) * (double)g.Clog * (double)wrows, st);
   hipLaunchKernelGGL(kern, dim3(std::min(ntiles, num_cu)), dim3(512), lds, st, g, (const bf16_t*)src, (const bf16_t*)wgt, wrows, bias,
                      (bf16_t*)out, ldc, act, ntiles, halo_bytes);
@@ -359,6 +360,7 @@ hipError_t thin_cout_conv(const GatherDesc& g, const void* src, const void* wgt,
     if (e != hipSuccess) return e;
     lds_set = lds;
   }
+  count_launch(K_THIN_COUT);
   prof_begin(PROF_GATHER_GEMM, 2.0 * (double)g.M * (double)(g.th * g.tw) * (double)g.Clog * (double)wrows, st);
   hipLaunchKernelGGL(thin_cout_conv_kernel, dim3(std::min(ntiles, num_cu)), dim3(512), lds, st, g, (const bf16_t*)src,
                      (const bf16_t*)wgt, wrows, bias, (bf16_t*)out, ldc, act, ntiles, halo_bytes, nbuf);

@@ -216,6 +216,7 @@ static hipError_t launch_wgrad_halo(const GatherDesc& g, const void* src, const 
     if (e != hipSuccess) return e;
     attr_done = true;
   }
+  count_launch(K_WGRAD_HALO);
   prof_begin(PROF_WGRAD, 2.0 * (double)g.M * 9.0 * (double)g.Clog * (double)co_rows, st);
   hipLaunchKernelGGL(kern, dim3(zs, combos), dim3(512), lds, st, g, (const bf16_t*)src, (const bf16_t*)dy, co_rows, ldy, slabs,
                      nslices, tps, slab_elems);

@@ -197,6 +197,7 @@ hipError_t wgrad_thin(const GatherDesc& g, const void* src, const void* dy, int 
     if (e != hipSuccess) return e;
     attr_done = true;
   }
+  count_launch(K_WGRAD_THIN);
   prof_begin(PROF_WGRAD, 2.0 * (double)g.M * 49.0 * (double)g.Clog * (double)co_rows, st);
   hipLaunchKernelGGL(kern, dim3(zs), dim3(512), lds, st, g, (const bf16_t*)src, (const bf16_t*)dy, co_rows, ldy, slabs, tps,
                      slab_elems);

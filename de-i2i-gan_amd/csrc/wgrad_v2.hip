@@ -236,6 +236,7 @@ hipError_t wgrad_v2(const GatherDesc& g, const void* src, const void* dy, int co
   if (splits < 1) return hipErrorNotSupported;
   const int cps = (nchunks + splits - 1) / splits;
   const int zs = (nchunks + cps - 1) / cps;
+  count_launch(K_WGRAD_V2);
   prof_begin(PROF_WGRAD, 2.0 * (double)g.M * (double)(g.th * g.tw) * (double)g.Clog * (double)co_rows, st);
   if (BM == 256) {
     const size_t lds = 3 * (size_t)(64 * 512 + 64 * 256);

@@ -7,6 +7,7 @@ parameters, gradients, state_dict), as in the reference.  Every op requires a GP
 from __future__ import annotations
 
 import ctypes
+import weakref
 from ctypes import byref, c_int, c_void_p
 from dataclasses import dataclass
 from typing import Optional
@@ -133,12 +134,15 @@ def _workspace(device, nbytes: int, slot: str = "splitk") -> torch.Tensor:
 # ---- in-place accumulation of parameter gradients within one backward pass --------------------------------------
 # The G step applies every generator layer four times (defectgan_model.py:185-190), so autograd would receive four
 # gradients per parameter and sum them with one add kernel each (171 launches per step).  Instead the first backward
-# node of a parameter in a pass returns a fresh gradient tensor and remembers its address under the pass's graph-task
-# id; the later nodes of the same pass add into that memory inside their own kernels (wgrad reduce, BatchNorm
-# finalize) and return None -- autograd treats an undefined gradient as "no contribution" and still runs the
-# parameter's AccumulateGrad (and its post-accumulate hooks: the data-parallel reducer) once, after its last node.
-# The tensor is kept alive by autograd's input buffer until then; only its address is stored here, so AccumulateGrad
-# can still steal it (no copy).  Non-leaf weights (concatenated gamma|beta) are not tracked.
+# node of a parameter in a pass returns a fresh gradient tensor and remembers it under the pass's graph-task id; the
+# later nodes of the same pass add into that memory inside their own kernels (wgrad reduce, BatchNorm finalize) and
+# return None -- autograd treats an undefined gradient as "no contribution" and still runs the parameter's
+# AccumulateGrad (and its post-accumulate hooks: the data-parallel reducer) once, after its last node.
+# Only a WEAK reference is kept: the tensor lives exactly as long as autograd's input buffer holds it, so
+# AccumulateGrad can still steal it (no copy), and a later node that finds the reference dead -- the engine dropped
+# the gradient (torch.autograd.grad(inputs=[activation]): the accumulator is not executed) or replaced it by an
+# out-of-place sum with another op's contribution -- simply returns a fresh tensor of its own, which is always correct.
+# Non-leaf weights (concatenated gamma|beta) are not tracked.
 _grad_slots = {}
 
 
@@ -149,11 +153,22 @@ def _grad_target(param, shape, device):
     if key is not None:
         slot = _grad_slots.get(key)
         if slot is not None and slot[0] == tid and slot[2] == tuple(shape):
-            return None, slot[1], 1
+            first = slot[1]()
+            if first is not None:                       # still the tensor in autograd's input buffer
+                return None, first.data_ptr(), 1
     t = torch.empty(shape, dtype=torch.float32, device=device)
     if key is not None:
-        _grad_slots[key] = (tid, t.data_ptr(), tuple(shape))
+        _grad_slots[key] = (tid, weakref.ref(t), tuple(shape))
     return t, t.data_ptr(), 0
+
+
+def _wants_grad(ctx, idx: int) -> bool:
+    """needs_input_grad[idx], and the engine will actually consume that gradient in this pass (False for a parameter
+    under torch.autograd.grad(inputs=[something else]): its wgrad would be computed and dropped)."""
+    if not ctx.needs_input_grad[idx]:
+        return False
+    node = ctx.next_functions[idx][0]
+    return node is None or torch._C._will_engine_execute_node(node)
 
 
 # ---- spectral normalisation of a conv weight (csrc/spectral.hip) --------------------------------------------------
@@ -236,7 +251,7 @@ class _NoiseInject(torch.autograd.Function):
     def backward(ctx, dy):
         (noise,) = ctx.saved_tensors
         dw = None
-        if ctx.needs_input_grad[1]:
+        if _wants_grad(ctx, 1):
             dy = dy.contiguous()
             rows, c = noise.numel(), dy.shape[-1]
             part = torch.empty(1024, dtype=torch.float32, device=dy.device)
@@ -420,14 +435,14 @@ class _Conv2d(torch.autograd.Function):
                 ext = _workspace(x.device, n * oh.value * ow.value * cins * x.element_size(), slot="dgrad_frame")
             L.check(lib.dei2i_conv2d_dgrad_input(byref(d), _p(g), _p(wd), _p(ext), _p(dx), _p(ws), ws.numel() * 4, st),
                     "conv2d_dgrad_input")
-        if ctx.needs_input_grad[1]:
+        if _wants_grad(ctx, 1):
             packed = lib.dei2i_wgrad_slab_elems(byref(d))
             # partial slabs: up to 64, or as many as fit 96 MB (a (co, ci, 9-tap) register block per CU is 256 x 295 KB)
             scratch = _workspace(x.device, max(packed * 4, min(max(packed * 4 * 64, 96 << 20), 512 << 20)), slot="wgrad")
             dw, dw_ptr, accumulate = _grad_target(weight, weight.shape, x.device)
             L.check(lib.dei2i_conv2d_wgrad_oihw(byref(d), _p(x), _p(g), _p(scratch), scratch.numel(), c_void_p(dw_ptr), accumulate,
                                                 st), "conv2d_wgrad")
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if ctx.has_bias and _wants_grad(ctx, 2):
             dbf = torch.empty(couts, dtype=torch.float32, device=x.device)
             rows = g.numel() // couts
             part = torch.empty(lib.dei2i_colsum_blocks(rows) * couts, dtype=torch.float32, device=x.device)
@@ -519,20 +534,36 @@ class _BatchNormAct(torch.autograd.Function):
         a = torch.empty(c, dtype=torch.float32, device=dev)
         b = torch.empty(c, dtype=torch.float32, device=dev)
         w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        nf = w32.numel()
+        if nf > c or running_mean.numel() != nf or running_var.numel() != nf:
+            raise ValueError(f"batchnorm_act: {nf} features for a {c}-channel activation")
+        rm, rv = running_mean, running_var
+        if nf < c:
+            # the channel stride is padded to a 16-byte vector (c > num_features: widths that are no multiple of 8 / 4): the
+            # kernels index every per-channel vector up to c, so hand them padded copies -- weight = bias = 0 makes the
+            # padded channels' a = b = 0 (their activations stay zero) -- and copy the live running statistics back
+            def _padded(v, fill):
+                o = torch.full((c,), fill, dtype=torch.float32, device=dev)
+                o[:nf] = v.detach()
+                return o
+            w32, b32, rm, rv = _padded(w32, 0.0), _padded(b32, 0.0), _padded(running_mean, 0.0), _padded(running_var, 1.0)
         if training:
             chunks = lib.dei2i_moments_chunks(h * w)
             partial = torch.empty((n, chunks, 2, c), dtype=torch.float32, device=dev)
             mean = torch.empty(c, dtype=torch.float32, device=dev)
             rstd = torch.empty(c, dtype=torch.float32, device=dev)
             L.check(lib.dei2i_moments_partial(prec.code, n, h * w, c, _p(y), _p(partial), st), "moments_partial")
-            L.check(lib.dei2i_bn_finalize_train(n, h * w, c, _p(partial), _p(w32), _p(b32), _p(running_mean), _p(running_var),
+            L.check(lib.dei2i_bn_finalize_train(n, h * w, c, _p(partial), _p(w32), _p(b32), _p(rm), _p(rv),
                                                 momentum, eps, _p(mean), _p(rstd), _p(a), _p(b), _p(num_batches_tracked), st),
                     "bn_finalize_train")
+            if nf < c:
+                running_mean.copy_(rm[:nf])
+                running_var.copy_(rv[:nf])
         else:
-            L.check(lib.dei2i_bn_finalize_eval(c, _p(w32), _p(b32), _p(running_mean), _p(running_var), eps, _p(a), _p(b), st),
+            L.check(lib.dei2i_bn_finalize_eval(c, _p(w32), _p(b32), _p(rm), _p(rv), eps, _p(a), _p(b), st),
                     "bn_finalize_eval")
-            mean = running_mean.detach().clone()
-            rstd = torch.rsqrt(running_var.detach() + eps)
+            mean = rm.detach().clone()
+            rstd = torch.rsqrt(rv.detach() + eps)
         out = torch.empty_like(y)
         if res is not None:
             res = res.contiguous()
@@ -542,7 +573,7 @@ class _BatchNormAct(torch.autograd.Function):
         if xq is not None:
             _fp8_stash.append(xq)
         ctx.prec, ctx.act, ctx.training, ctx.has_res = prec, act, training, res is not None
-        ctx.params = (weight, bias)
+        ctx.params, ctx.nf = (weight, bias), nf
         ctx.save_for_backward(y, a, b, mean, rstd)
         return out
 
@@ -560,19 +591,31 @@ class _BatchNormAct(torch.autograd.Function):
         L.check(lib.dei2i_bn_bwd_partial(prec.code, pixels, c, _p(dout), _p(y), _p(a), _p(b), _p(mean), _p(rstd), ctx.act,
                                          _p(partial), st), "bn_bwd_partial")
         weight, bias = ctx.params
-        dweight, dw_ptr, acc_w = _grad_target(weight, (c,), y.device)
-        dbias, db_ptr, acc_b = _grad_target(bias, (c,), y.device)
+        padded = ctx.nf < c               # padded channel stride: c-sized scratch vectors, sliced to num_features below
+        if padded:
+            tmp_wb = torch.empty((2, c), dtype=torch.float32, device=y.device)
+            dweight = dbias = None
+            dw_ptr, db_ptr, acc_w, acc_b = tmp_wb.data_ptr(), tmp_wb.data_ptr() + 4 * c, 0, 0
+        else:
+            dweight, dw_ptr, acc_w = _grad_target(weight, (c,), y.device)
+            dbias, db_ptr, acc_b = _grad_target(bias, (c,), y.device)
         acc_ptrs = (None, None)
         if acc_w or acc_b:            # the kernel needs this call's own sums as well: they go to scratch vectors
-            if not (acc_w and acc_b):                      # (cannot happen for an nn.BatchNorm2d; keep the pair in step)
-                raise RuntimeError("batchnorm weight and bias gradients out of step")
-            acc_ptrs = (c_void_p(dw_ptr), c_void_p(db_ptr))
-            tmp = torch.empty((2, c), dtype=torch.float32, device=y.device)
-            dw_ptr, db_ptr = tmp.data_ptr(), tmp.data_ptr() + 4 * c
+            if not (acc_w and acc_b):
+                # one of the pair lost its first gradient tensor (see _grad_target): give both a fresh tensor
+                dweight = torch.empty((c,), dtype=torch.float32, device=y.device)
+                dbias = torch.empty((c,), dtype=torch.float32, device=y.device)
+                dw_ptr, db_ptr, acc_w, acc_b = dweight.data_ptr(), dbias.data_ptr(), 0, 0
+            else:
+                acc_ptrs = (c_void_p(dw_ptr), c_void_p(db_ptr))
+                tmp = torch.empty((2, c), dtype=torch.float32, device=y.device)
+                dw_ptr, db_ptr = tmp.data_ptr(), tmp.data_ptr() + 4 * c
         dy = torch.empty_like(y)
         L.check(lib.dei2i_bn_bwd_apply(prec.code, pixels, c, _p(dout), _p(y), _p(a), _p(b), _p(mean), _p(rstd), ctx.act,
                                        1 if ctx.training else 0, _p(partial), chunks, c_void_p(dw_ptr), c_void_p(db_ptr),
                                        acc_ptrs[0], acc_ptrs[1], _p(dy), st), "bn_bwd_apply")
+        if padded:
+            dweight, dbias = tmp_wb[0, :ctx.nf].clone(), tmp_wb[1, :ctx.nf].clone()
         return dy, dweight, dbias, (dout if ctx.has_res else None), None, None, None, None, None, None, None
 
 

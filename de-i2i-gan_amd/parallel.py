@@ -16,6 +16,10 @@ MI355X node (8 GPUs, point-to-point xGMI, no switch):
   ``norm_s`` / ``conv_s``; all of D during the G step) simply never enter a collective.
 * BatchNorm statistics stay local (per-shard), like torch DDP without SyncBN; ``broadcast_buffers`` copies rank 0's
   running stats to every rank (torch DDP ``broadcast_buffers`` semantics) -- parity definition in SURVEY.md 8e.
+* ``attach_ddp`` broadcasts rank 0's parameters and buffers (spectral-norm u / v included) once, one flat message per
+  network, like torch DDP does at construction: replicas start identical whatever each rank's seed or checkpoint was.
+* ``measure=True`` brackets every collective with events on the side stream and marks the end of backward on the compute
+  stream; ``overlap_report()`` then says how much of the exchange ran under backward kernels (bench.py prints it).
 """
 from __future__ import annotations
 
@@ -27,7 +31,7 @@ import torch.distributed as dist
 
 class GradReducer:
     def __init__(self, process_group=None, bucket_bytes: int = 16 << 20, direct_bytes: int = 4 << 20, overlap: bool = True,
-                 force_collectives: bool = False):
+                 force_collectives: bool = False, measure: bool = False):
         if not dist.is_initialized():
             raise RuntimeError("GradReducer needs an initialised torch.distributed process group")
         self.pg = process_group
@@ -40,6 +44,10 @@ class GradReducer:
         self._bucket_nbytes = 0
         self._inflight = []          # (work, flat, [grads]) to finish in reduce()
         self.stats = {"collectives": 0, "bytes": 0}
+        self.measure = measure
+        self._spans = []             # measure: (start event, end event) of every collective, on the side stream
+        self._bwd_done = []          # measure: compute-stream event at the entry of reduce() = backward's last kernel
+        self._span_marks = []        # index into _spans at each reduce() call
 
     # ---- wiring ------------------------------------------------------------------------------------------
     def attach(self, net: torch.nn.Module) -> None:
@@ -91,6 +99,9 @@ class GradReducer:
         else:
             ctx = _NullCtx()
         with ctx:
+            if self.measure and side is not None:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(side)
             if flat:
                 buf = torch.cat([g.reshape(-1) for g in grads])
                 for g in grads:
@@ -101,6 +112,11 @@ class GradReducer:
                 if side is not None:
                     buf.record_stream(side)
             work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            if self.measure and side is not None:
+                work.wait()                       # stream-ordered on the side stream (no host block for NCCL work)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record(side)
+                self._spans.append((e0, e1))
         self.stats["collectives"] += 1
         self.stats["bytes"] += buf.numel() * buf.element_size()
         self._inflight.append((work, buf if flat else None, grads))
@@ -111,6 +127,10 @@ class GradReducer:
         over ranks.  Use ``FusedAdam.grad_scale = 1/world`` (set by ``attach_ddp``) for the average."""
         if not self.active:
             return
+        if self.measure and torch.cuda.is_available():
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream())
+            self._bwd_done.append(ev)
         if id(net) not in self._attached or not self.overlap:
             for p in net.parameters():                      # no-overlap path: same bucketing, issued now
                 if p.grad is not None:
@@ -131,6 +151,45 @@ class GradReducer:
         for dev, side in self._side.items():
             torch.cuda.current_stream(dev).wait_stream(side)    # optimizer kernels run after the reduced grads land
         self._inflight = []
+        if self.measure:
+            self._span_marks.append(len(self._spans))
+
+    def overlap_report(self):
+        """(measure=True; call after a device synchronise)  Per optimizer step: time the collectives occupied the side
+        stream, and the part of it that ran AFTER backward's last kernel (exposed: the optimizer waits for it)."""
+        if not self._bwd_done:
+            return None
+        comm = exposed = 0.0
+        lo = 0
+        for ev, hi in zip(self._bwd_done, self._span_marks):
+            for e0, e1 in self._spans[lo:hi]:
+                comm += e0.elapsed_time(e1)
+            if hi > lo:
+                exposed += max(0.0, ev.elapsed_time(self._spans[hi - 1][1]))
+            lo = hi
+        n = len(self._bwd_done)
+        self._spans, self._bwd_done, self._span_marks = [], [], []
+        return {"backward_passes": n, "comm_ms_per_pass": comm / n, "exposed_ms_per_pass": exposed / n,
+                "overlap_frac": (1.0 - exposed / comm) if comm > 0 else None}
+
+    def broadcast_parameters(self, net: torch.nn.Module, src: int = 0) -> None:
+        """Rank ``src``'s parameters and buffers to every rank, one flat message per dtype (torch DDP does this when it
+        wraps a module).  Parameters are written through ``.data`` and stamped so that packed weight copies refresh."""
+        if self.world <= 1:
+            return
+        with torch.no_grad():
+            tensors = [p.data for p in net.parameters()] + [b for b in net.buffers()]
+            for dt in sorted({t.dtype for t in tensors}, key=str):
+                group = [t for t in tensors if t.dtype == dt]
+                flat = torch.cat([t.reshape(-1) for t in group])
+                dist.broadcast(flat, src=src, group=self.pg)
+                off = 0
+                for t in group:
+                    n = t.numel()
+                    t.copy_(flat[off:off + n].view_as(t))
+                    off += n
+            for p in list(net.parameters()) + list(net.buffers()):
+                p._dei2i_epoch = getattr(p, "_dei2i_epoch", 0) + 1
 
     def broadcast_buffers(self, net: torch.nn.Module, src: int = 0) -> None:
         bufs = [b for b in net.buffers() if b.is_floating_point()]
@@ -159,9 +218,11 @@ def attach_ddp(trainer, process_group=None, **kw) -> GradReducer:
     red = GradReducer(process_group, **kw)
     for name, net in trainer.model.networks.items():
         red.attach(net)
+        red.broadcast_parameters(net)
         trainer.optimizers[name].grad_scale = 1.0 / red.world
     mask_token = getattr(trainer.model, "mask_token", None)         # MAE stage: trained by the generator's optimizer
     if isinstance(mask_token, torch.nn.Module):
         red.attach(mask_token)
+        red.broadcast_parameters(mask_token)
     trainer.reducer = red
     return red

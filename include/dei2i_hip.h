@@ -237,6 +237,14 @@ int dei2i_prof_enable(int family, int on);
 /* synchronises the recorded events; returns launches, total ms and total algorithmic FLOPs since enable */
 int dei2i_prof_collect(int family, int64_t* launches, double* total_ms, double* total_flops);
 
+/* ---- which kernel served a call: host-side launch counters per MFMA kernel family (tests assert the family, so a
+ * fall-through from a tuned kernel to the generic GEMM cannot pass unnoticed).  dei2i_launch_counts copies up to n
+ * counters and returns how many families exist; dei2i_kernel_name(i) names family i ("halo_conv", "gather_v2",
+ * "gather_v1", "thin_cin", "thin_cout", "wgrad_halo", "wgrad_v2", "wgrad_v1", "wgrad_thin", "halo_conv_fp8"). */
+int dei2i_launch_counts(int64_t* out, int n);
+void dei2i_launch_counts_reset(void);
+const char* dei2i_kernel_name(int kid);
+
 #ifdef __cplusplus
 }
 #endif

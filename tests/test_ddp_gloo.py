@@ -56,6 +56,16 @@ def _worker(rank, world, port, name, out_dir, overlap):
     red = GradReducer(bucket_bytes=1 << 14, direct_bytes=1 << 12, overlap=overlap)     # tiny thresholds: exercise both paths
     red.attach(G)
     red.attach(D)
+    if rank != 0:
+        # a replica that was seeded / resumed differently: attach_ddp's broadcast must bring it back to rank 0's state
+        with torch.no_grad():
+            for t in list(G.parameters()) + list(D.parameters()) + [b for b in G.buffers() if b.is_floating_point()]:
+                t.add_(0.37)
+            for b in G.buffers():
+                if not b.is_floating_point():
+                    b.add_(5)
+    red.broadcast_parameters(G)
+    red.broadcast_parameters(D)
     SG, SD = G.state(), D.state()
     stG, stD = O.AdamState(), O.AdamState()
     w = cfg.loss_weight

@@ -8,9 +8,12 @@ reference's functions that hold at any size:
     whenever the kernels are deterministic (power-of-two scaling commutes with rounding);
   * the batch-mean losses make the D gradient of a batch the mean of its micro-batch gradients (the identity the
     data-parallel all-reduce rests on, SURVEY.md section 8e);
-  * the analytic gradient must predict a finite difference of the loss along a direction (exact-f32 mode), which pins
-    dgrad + wgrad of every kernel family the full-size shapes select (halo conv, thin convs, split-K wgrad, ...), none
-    of which the tiny golden configurations reach;
+  * the analytic gradient must predict a finite difference of the loss along a direction (exact-f32 mode).  f32 mode
+    dispatches ONLY the generic exact-f32 GEMMs (gather_gemm_kernel<float>, wgrad_kernel<float>), so this pins the
+    full-size loss graphs, the normalisation / SPADE / loss / fold kernels and the generic GEMM's geometry at the
+    full-size shapes -- NOT the bf16-only kernel families (halo conv, gather v2, thin convs, halo / v2 / thin wgrads):
+    those are pinned against the oracle at the exact hot shapes, with the serving kernel asserted, in
+    tests/test_hot_shapes_gpu.py, and bf16-vs-f32 at 256x256 / batch 16 there as well;
   * two runs of the same step give the same bits (no atomics on the data path).
 
 The golden-pinned small cases live in test_model_gpu.py; the op-level kernels against torch references in

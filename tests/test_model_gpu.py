@@ -278,6 +278,7 @@ def test_ddp_reducer_on_gpu_single_rank_rccl():
 @pytest.mark.parametrize("c", [
     dict(image_size=80, batch=3, num_layers=3, ngf=16, ndf=16, hidden_nc=32),      # 80 = 5*16: no 8x32 tiling anywhere
     dict(image_size=48, batch=1, num_layers=2, ngf=24, ndf=8, hidden_nc=8),        # batch 1, channel counts off the 16s
+    dict(image_size=32, batch=2, num_layers=3, ngf=12, ndf=12, hidden_nc=8),       # BatchNorm widths below the padded channel stride (12 -> 16 in bf16)
 ])
 def test_ragged_sizes_forward_matches_oracle(c):
     """Generator / Discriminator modules on shapes the tile-aligned kernels refuse (image sides that are not multiples of
@@ -307,10 +308,11 @@ def test_ragged_sizes_forward_matches_oracle(c):
             check_fwd(got, ref, pname, 0.3)          # bf16 on the formula-filled nets: measured up to 0.22 rms at batch 1
 
 
-def test_odd_batch_and_channel_counts_step_matches_oracle():
+@pytest.mark.parametrize("ngf", [24, 6])        # 6: every BatchNorm width (6, 12, 24) has a padded channel stride in f32 mode too (6 -> 8)
+def test_odd_batch_and_channel_counts_step_matches_oracle(ngf):
     """One D step and one G step on a power-of-two image with batch 3 and channel counts that are not multiples of 16
     (f32 mode): step-1 losses 1e-4, D gradients 1e-3 (D's loss graph has no near-tie branches on this seed)."""
-    c = dict(image_size=32, batch=3, num_layers=3, ngf=24, ndf=8, hidden_nc=8)
+    c = dict(image_size=32, batch=3, num_layers=3, ngf=ngf, ndf=8, hidden_nc=8)
     cfg = O.Cfg(image_size=c["image_size"], ngf=c["ngf"], ndf=c["ndf"], num_layers=c["num_layers"], hidden_nc=c["hidden_nc"])
     bg, labels, df = O.synthetic_batch(c["batch"], c["image_size"])
     tr = build(c, "f32")

@@ -134,11 +134,14 @@ def test_conv2d_fwd_bwd(ops, pname, case, request):
 
 
 @pytest.mark.parametrize("pname", ["f32", "bf16"])
-@pytest.mark.parametrize("training,act,with_res", [(True, "leaky_relu", False), (True, "none", True), (False, "leaky_relu", False)])
-def test_batchnorm_act(ops, pname, training, act, with_res):
+@pytest.mark.parametrize("training,act,with_res,C", [(True, "leaky_relu", False, 16), (True, "none", True, 16), (False, "leaky_relu", False, 16),
+                                                     # num_features below the padded channel stride (6 -> 8 in both modes): the
+                                                     # per-channel vectors are shorter than the activation's channel dimension
+                                                     (True, "leaky_relu", False, 6), (False, "none", True, 6)])
+def test_batchnorm_act(ops, pname, training, act, with_res, C):
     prec = ops.get_precision(pname)
     torch.manual_seed(3)
-    N, C, H, W = 3, 16, 10, 12
+    N, H, W = 3, 10, 12
     y = torch.randn(N, C, H, W) * 1.7 + 0.4
     res = torch.randn(N, C, H, W) if with_res else None
     S = {"bn.weight": (1 + 0.2 * torch.randn(C)).double().requires_grad_(True), "bn.bias": (0.1 * torch.randn(C)).double().requires_grad_(True),
@@ -164,7 +167,9 @@ def test_batchnorm_act(ops, pname, training, act, with_res):
     out = ops.batchnorm_act(yg, wg, bg, rm, rv, training, act, resg)
     tol = TOL[pname]
     assert maxrel(ops.to_nchw(out, C), out_ref) < tol
-    out.backward(nhwc_ref(g, C).to(dev()).to(prec.dtype))
+    assert out.shape[-1] == prec.pad(C) and (prec.pad(C) == C or float(out[..., C:].abs().max()) == 0.0)     # padding stays zero
+    out.backward(nhwc_ref(g, prec.pad(C)).to(dev()).to(prec.dtype))
+    assert wg.grad.shape == (C,) and bg.grad.shape == (C,) and rm.shape == (C,)
     assert maxrel(ops.to_nchw(yg.grad, C), grads[0]) < tol * 2
     assert maxrel(wg.grad, grads[1]) < tol * 2
     assert maxrel(bg.grad, grads[2]) < tol * 2
@@ -439,3 +444,41 @@ def test_spade_relu_skip_branch(ops, pname, class_mode):
     assert maxrel(dx1, dx0) < (1e-6 if pname == "f32" else 1e-2)
     for a, b in zip(pg1, pg0):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("pname", ["f32", "bf16"])
+def test_weight_used_twice_activation_gradient_only_and_with_foreign_contribution(ops, pname):
+    """A conv weight applied twice in one graph (the G step applies every generator layer four times): the second
+    backward node adds into the first node's gradient tensor (ops._grad_target).  (a) torch.autograd.grad(inputs=[x]) --
+    the engine never runs the weight's AccumulateGrad and drops the first node's tensor, so a later node must not write
+    into it; (b) a full backward where an op outside this library contributes to the same parameter too.  Both against
+    the oracle's conv in float64 on the rounded operands."""
+    prec = ops.get_precision(pname)
+    torch.manual_seed(21)
+    N, C, H, W = 2, 16, 12, 16
+    x = torch.randn(N, C, H, W)
+    w = torch.randn(C, C, 3, 3) * math.sqrt(2.0 / (C * 9))
+    gy = torch.randn(N, C, H, W)
+    xr, wr = rounded(x, prec).double().requires_grad_(True), rounded(w, prec).double().requires_grad_(True)
+    h_ref = O.conv2d(xr, wr, stride=1, pad=1, mode="reflect")
+    y_ref = O.conv2d(h_ref, wr, stride=1, pad=1, mode="reflect")
+    gx_ref, gw_ref = torch.autograd.grad(y_ref, [xr, wr], rounded(gy, prec).double())
+    geom = ops.ConvGeom(C, C, 3, 1, 1, True, False)
+    wg = torch.nn.Parameter(w.to(dev()))
+    cache = ops.PackedWeights()
+    gyh = nhwc_ref(gy, C).to(dev()).to(prec.dtype)
+    tol = TOL[pname] * 2            # the intermediate activation is rounded once more than in the reference
+
+    def graph():
+        xg = x.to(dev()).requires_grad_(True)
+        y = ops.conv2d(ops.conv2d(ops.to_nhwc(xg, prec), wg, None, cache, geom), wg, None, cache, geom)
+        return xg, y
+
+    xg, y = graph()
+    (gx,) = torch.autograd.grad(y, [xg], gyh)                       # (a): nothing may be written for the weight
+    canary = torch.zeros(1 << 20, device=dev())                     # would-be victim of a write into freed memory
+    torch.cuda.synchronize()
+    assert maxrel(gx, gx_ref) < tol and float(canary.abs().max()) == 0.0 and wg.grad is None
+    xg, y = graph()                                                 # (b): a foreign contribution to the same parameter
+    torch.autograd.backward([y, (wg * 3.0).sum()], [gyh, torch.ones((), device=dev())])
+    assert maxrel(wg.grad, gw_ref + 3.0) < tol and maxrel(xg.grad, gx_ref) < tol
