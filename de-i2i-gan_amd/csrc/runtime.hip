@@ -23,6 +23,8 @@ int num_cu() { return g_cus; }
 
 struct ProfState {
   bool on = false;
+  bool events = true;          // false: count launches and FLOPs only (no HIP events: nothing is added to the stream)
+  size_t counted = 0;
   std::vector<hipEvent_t> starts, stops;
   size_t used = 0;
   double flops = 0.0;
@@ -37,6 +39,8 @@ static const char* const g_kernel_names[K_COUNT] = {"gather_v1", "gather_v2", "h
 void prof_begin(int family, double flops, hipStream_t st) {
   ProfState& p = g_prof[family];
   if (!p.on) return;
+  p.counted++;
+  if (!p.events) { p.flops += flops; return; }
   if (p.used == p.starts.size()) {
     hipEvent_t a, b;
     hipEventCreate(&a);
@@ -50,7 +54,7 @@ void prof_begin(int family, double flops, hipStream_t st) {
 
 void prof_end(int family, hipStream_t st) {
   ProfState& p = g_prof[family];
-  if (!p.on) return;
+  if (!p.on || !p.events) return;
   hipEventRecord(p.stops[p.used], st);
   p.used++;
 }
@@ -113,7 +117,9 @@ int dei2i_prof_enable(int family, int on) {
   if (family < 0 || family >= PROF_FAMILIES) return DEI2I_ERR_BAD_ARG;
   ProfState& p = g_prof[family];
   p.on = on != 0;
+  p.events = on != 2;
   p.used = 0;
+  p.counted = 0;
   p.flops = 0.0;
   return 0;
 }
@@ -130,10 +136,11 @@ int dei2i_prof_collect(int family, int64_t* launches, double* total_ms, double* 
     if (e != hipSuccess) return (int)e;
     ms += t;
   }
-  if (launches) *launches = (int64_t)p.used;
+  if (launches) *launches = (int64_t)p.counted;
   if (total_ms) *total_ms = ms;
   if (total_flops) *total_flops = p.flops;
   p.used = 0;
+  p.counted = 0;
   p.flops = 0.0;
   return 0;
 }

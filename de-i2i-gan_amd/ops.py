@@ -168,7 +168,13 @@ def _wants_grad(ctx, idx: int) -> bool:
     if not ctx.needs_input_grad[idx]:
         return False
     node = ctx.next_functions[idx][0]
-    return node is None or torch._C._will_engine_execute_node(node)
+    if node is None:
+        return True
+    try:
+        return bool(torch._C._will_engine_execute_node(node))
+    except RuntimeError:
+        # torch refuses the query for a LEAF that torch.autograd.grad(inputs=[that leaf]) captures -- its gradient is wanted
+        return True
 
 
 # ---- spectral normalisation of a conv weight (csrc/spectral.hip) --------------------------------------------------
@@ -423,7 +429,7 @@ class _Conv2d(torch.autograd.Function):
         else:
             g = dy
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
+        if _wants_grad(ctx, 0):
             _, wd = ctx.cache.get(weight, ctx.sources, prec, geom, cins, couts, need_dgrad=True, need_fwd=False,
                                   per_call=ctx.per_call)
             ws = _workspace(x.device, lib.dei2i_conv2d_workspace_bytes(byref(d)))

@@ -233,6 +233,8 @@ int dei2i_spectral_bwd(int Cout, int K, const float* G, const float* w_eff, cons
 #define DEI2I_PROF_GATHER_GEMM 0  /* the other conv forward / dgrad kernels: gather GEMM v1 / v2, thin convs */
 #define DEI2I_PROF_WGRAD 1
 #define DEI2I_PROF_HALO_CONV 2   /* halo_conv_kernel alone (its launches are not part of family 0) */
+/* on = 1: HIP events around every launch of the family + FLOP count; on = 2: launch and FLOP count only (no events: the
+ * stream sees nothing extra, total_ms reads 0); on = 0: off */
 int dei2i_prof_enable(int family, int on);
 /* synchronises the recorded events; returns launches, total ms and total algorithmic FLOPs since enable */
 int dei2i_prof_collect(int family, int64_t* launches, double* total_ms, double* total_flops);

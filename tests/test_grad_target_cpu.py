@@ -80,3 +80,12 @@ def test_foreign_contribution_to_the_same_parameter():
     x = torch.randn(5, requires_grad=True)
     (_Mul.apply(_Mul.apply(x, w), w).sum() + (w * 3).sum()).backward()
     assert torch.allclose(w.grad, (2 * x * w).detach() + 3)
+
+
+def test_leaf_captured_by_autograd_grad_is_wanted():
+    _Mul.log.clear()
+    w = torch.nn.Parameter(torch.randn(5))
+    x = torch.randn(5, requires_grad=True)
+    (gw,) = torch.autograd.grad(_Mul.apply(_Mul.apply(x, w), w).sum(), [w])
+    assert "skipped" not in _Mul.log
+    assert torch.allclose(gw, (2 * x * w).detach())
