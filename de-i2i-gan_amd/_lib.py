@@ -19,6 +19,11 @@ class ConvDesc(Structure):
                 ("pad_mode", c_int), ("up", c_int)]
 
 
+class ProDesc(Structure):
+    """struct dei2i_pro: operand-path normalisation of a conv's input (fused conv + norm + act)"""
+    _fields_ = [("A", c_void_p), ("B", c_void_p), ("n_stride", c_int), ("slope", c_float), ("ring", c_void_p)]
+
+
 class AdamRec(Structure):
     """struct dei2i_adam_rec"""
     _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_int64)]
@@ -26,6 +31,7 @@ class AdamRec(Structure):
 
 _P = c_void_p
 _CD = POINTER(ConvDesc)
+_PD = POINTER(ProDesc)
 
 # name -> (restype, argtypes); every symbol include/dei2i_hip.h declares
 SIGNATURES = {
@@ -88,6 +94,15 @@ SIGNATURES = {
     "dei2i_adam_step": (c_int, [_P, c_int, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_float, _P]),
     "dei2i_prof_enable": (c_int, [c_int, c_int]),
     "dei2i_prof_collect": (c_int, [c_int, POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),
+    "dei2i_conv2d_fused_supported": (c_int, [_CD, c_int]),
+    "dei2i_conv2d_stats_chunks": (c_int, [_CD]),
+    "dei2i_conv2d_fwd_fused": (c_int, [_CD, _P, _P, _P, c_int, _P, _PD, _P, _P]),
+    "dei2i_conv2d_wgrad_pro_supported": (c_int, [_CD]),
+    "dei2i_conv2d_wgrad_oihw_pro": (c_int, [_CD, _P, _P, _P, c_size_t, _P, c_int, _PD, _P]),
+    "dei2i_ring_pixels": (c_size_t, [c_int, c_int]),
+    "dei2i_spade_prep": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "dei2i_bn_finalize_train_chunks": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P]),
+    "dei2i_affine_act_stats_fwd": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P, _P]),
     "dei2i_launch_counts": (c_int, [POINTER(c_int64), c_int]),
     "dei2i_launch_counts_reset": (None, []),
     "dei2i_kernel_name": (c_char_p, [c_int]),

@@ -418,6 +418,75 @@ int dei2i_conv2d_wgrad_oihw(const dei2i_conv* c, const void* x, const void* dy, 
   return (int)wgrad_reduce_unpack(scratch, nsplit, (long long)packed, dw_oihw, c->Cout, c->Cin, c->CinS, c->kh * c->kw, accumulate, st);
 }
 
+/* ---- fused conv + norm + act (halo-resident kernels only; ask *_supported first -- there is no fallback inside) ---- */
+static bool to_pro(const dei2i_conv* c, const dei2i_pro* p, ConvPro& out) {
+  if (p == nullptr) return false;
+  out.A = p->A; out.B = p->B; out.n_stride = p->n_stride; out.slope = p->slope;
+  out.ring = (const uint16_t*)p->ring;
+  out.ring_pix = p->ring != nullptr ? ring_pixels(c->H << c->up, c->W << c->up) : 0;
+  return true;
+}
+
+static bool halo_fwd_shape_ok(const dei2i_conv* c, int want_pro) {
+  if (!valid_conv(c) || c->dtype != DT_BF16) return false;
+  if (c->kh != 3 || c->kw != 3 || c->stride != 1 || c->pad != 1) return false;
+  const int Ho = c->H << c->up, Wo = c->W << c->up;
+  if (c->CinS % 64 != 0 || Ho % 8 != 0 || Wo % 32 != 0 || c->CoutS < 64) return false;
+  if ((long long)c->N * c->H * c->W * c->CinS >= (1ll << 31)) return false;
+  if (want_pro && (c->CinS > 512 || Ho < 4 || Wo < 4)) return false;
+  const int tiles_m = c->N * (Ho / 8) * (Wo / 32);
+  const int tn = c->CoutS >= 128 ? (c->CoutS + 127) / 128 : 1;
+  return tiles_m * tn >= num_cu() / 2;
+}
+
+int dei2i_conv2d_fused_supported(const dei2i_conv* c, int want_pro) { return halo_fwd_shape_ok(c, want_pro) ? 1 : 0; }
+
+int dei2i_conv2d_stats_chunks(const dei2i_conv* c) {
+  int Ho, Wo;
+  dei2i_conv2d_out_shape(c, &Ho, &Wo);
+  return (Ho / 8) * (Wo / 32);
+}
+
+int dei2i_conv2d_fwd_fused(const dei2i_conv* c, const void* x, const void* w_packed, const float* bias, int act, void* y,
+                           const dei2i_pro* pro, float* stats, dei2i_stream s) {
+  if (!x || !w_packed || !y || !halo_fwd_shape_ok(c, pro != nullptr)) return DEI2I_ERR_BAD_ARG;
+  if (pro != nullptr && (!pro->A || !pro->B)) return DEI2I_ERR_BAD_ARG;
+  GatherDesc g = make_fwd_desc(to_shape(c), c->CinS);
+  ConvPro cp;
+  const bool has = to_pro(c, pro, cp);
+  if (!has) {
+    hipError_t e = halo16_conv(g, x, w_packed, c->Cout, bias, y, c->CoutS, act, num_cu(), (hipStream_t)s, stats);
+    if (e != hipErrorNotSupported) return (int)e;
+  }
+  return (int)halo_conv(g, x, w_packed, c->Cout, bias, y, c->CoutS, act, num_cu(), (hipStream_t)s, nullptr, has ? &cp : nullptr, stats);
+}
+
+int dei2i_conv2d_wgrad_pro_supported(const dei2i_conv* c) {
+  if (!valid_conv(c) || c->dtype != DT_BF16) return 0;
+  if (c->kh != 3 || c->kw != 3 || c->stride != 1 || c->pad != 1) return 0;
+  const int Ho = c->H << c->up, Wo = c->W << c->up;
+  if (Ho % 4 != 0 || Wo % 32 != 0 || Ho < 4 || Wo < 4) return 0;
+  if ((long long)c->N * c->H * c->W * c->CinS >= (1ll << 31)) return 0;
+  const int co = c->Cout;
+  if (co <= 64) return ((c->CinS % 128 == 0 && co >= 48) || (c->CinS % 64 == 0 && co <= 32)) ? 1 : 0;
+  return (c->CinS % 64 == 0 && co >= 96) ? 1 : 0;
+}
+
+int dei2i_conv2d_wgrad_oihw_pro(const dei2i_conv* c, const void* x, const void* dy, float* scratch, size_t scratch_elems,
+                                float* dw_oihw, int accumulate, const dei2i_pro* pro, dei2i_stream s) {
+  if (!x || !dy || !scratch || !dw_oihw || !pro || !pro->A || !pro->B || !dei2i_conv2d_wgrad_pro_supported(c)) return DEI2I_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)s;
+  GatherDesc g = make_fwd_desc(to_shape(c), c->CinS);
+  const size_t packed = (size_t)wgrad_slab_elems(c->Cout, g.K);
+  if (scratch_elems < packed) return DEI2I_ERR_WORKSPACE;
+  ConvPro cp;
+  to_pro(c, pro, cp);
+  int nsplit = 0;
+  hipError_t e = wgrad_halo(g, x, dy, c->Cout, c->CoutS, scratch, scratch_elems, num_cu(), &nsplit, true, st, &cp);
+  if (e != hipSuccess) return (int)e;
+  return (int)wgrad_reduce_unpack(scratch, nsplit, (long long)packed, dw_oihw, c->Cout, c->Cin, c->CinS, c->kh * c->kw, accumulate, st);
+}
+
 int dei2i_fold_pad(int dtype, int N, int H, int W, int C, int pad, int pad_mode, int up, const void* dx_ext,
                    const void* addend, void* dx, dei2i_stream s) {
   const int vec = dtype == DT_BF16 ? 8 : 4;

@@ -680,8 +680,10 @@ hipError_t gather_gemm_multi(int dtype, const GatherDesc* descs, const long long
       e = thin_cout_conv(pack.d[0], src, (const bf16_t*)wgt + pack.woff[0], wrows, bias, out, ldc, act, g_num_cu, st);
       if (e != hipErrorNotSupported) return e;
     }
-    if (g_use_halo && pack.n == 1) {      // stride-1 3x3 layers: halo-resident kernel (conv_halo.hip)
-      hipError_t e = halo_conv(pack.d[0], src, (const bf16_t*)wgt + pack.woff[0],
+    if (g_use_halo && pack.n == 1) {      // stride-1 3x3 layers: halo-resident kernels (conv_halo16.hip, conv_halo.hip)
+      hipError_t e = halo16_conv(pack.d[0], src, (const bf16_t*)wgt + pack.woff[0], wrows, bias, out, ldc, act, g_num_cu, st);
+      if (e != hipErrorNotSupported) return e;
+      e = halo_conv(pack.d[0], src, (const bf16_t*)wgt + pack.woff[0],
                                wrows, bias, out, ldc, act, g_num_cu, st);
       if (e != hipErrorNotSupported) return e;
     }

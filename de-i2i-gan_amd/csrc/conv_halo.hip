@@ -55,14 +55,23 @@ template <int N> DEI2I_D void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"
 // channels), so every address, LDS image and DMA pattern is unchanged; a 16-byte fragment then holds 16 k-values and
 // feeds two v_mfma_f32_16x16x32_fp8_fp8 (low / high 8 bytes -- the same k permutation for both operands), and the
 // epilogue multiplies by *dequant = 1 / (activation scale * weight scale).  Half the LDS and DMA bytes per FLOP.
-template <int BN, int STAGES, bool DIAG, bool M16, bool FP8 = false>
+// PRO: the conv's input is normalised + activated on the operand path (ConvPro, geom.h): once a halo slice has landed in
+// LDS every thread rewrites its share of it in place, z = act(A*x + B) with this image's per-channel coefficients (LDS
+// table), spread over the M phases of taps 4..6 of the previous slice (slice 0: in the prologue); halo pixels on the
+// image's 2-pixel frame come from the pre-normalised ring tensor and are left alone, zero padding stays zero.
+// stats != nullptr: the epilogue also writes this tile's per-channel sum / sum of squares of the STORED (rounded) outputs,
+// record (n * tiles_per_image + tile) of a (N, tiles, 2, ldc) fp32 tensor -- the layout of moments_partial (reduce.hip),
+// so the BatchNorm / InstanceNorm finalize kernels read it unchanged and the separate statistics pass is gone.
+template <int BN, int STAGES, bool DIAG, bool M16, bool FP8 = false, bool PRO = false>
 __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, const bf16_t* __restrict__ src,
                                                         const bf16_t* __restrict__ wgt, const int wrows,
                                                         const float* __restrict__ bias, bf16_t* __restrict__ out,
                                                         const int ldc, const int act, const int tiles_n, const int ablate,
                                                         unsigned long long* __restrict__ dbg,
-                                                        const float* __restrict__ dequant) {
+                                                        const float* __restrict__ dequant, const ConvPro pro,
+                                                        float* __restrict__ stats) {
   static_assert(!FP8 || M16, "the fp8 variant uses the 16x16x32 shape");
+  static_assert(!PRO || (!FP8 && !DIAG), "operand-path normalisation: bf16 production variant only");
   constexpr int BM = HALO_TH * HALO_TW;             // 256 output pixels
   constexpr int WN = 2, WTN = BN / WN, TM = 2, TN = WTN / 32;
   constexpr int LB = BN / 64;                       // weight LDS-DMA instructions per wave per stage
@@ -97,16 +106,29 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, cons
   const int hy0 = y0 + g.by0 + (g.ys < 0 ? -(g.th - 1) : 0);
   const int hx0 = x0 + g.bx0 + (g.xs < 0 ? -(g.tw - 1) : 0);
 
-  // ---- halo source-offset table (element offset of each halo pixel's channel 0, -1 = contributes zero) ----
+  // ---- halo source-offset table (element offset of each halo pixel's channel 0, -1 = contributes zero;
+  //      PRO: <= -2 = element offset -2 - off into the pre-normalised ring tensor) ----
   for (int p = tid; p < HALO_GROUPS * 8; p += 512) {
     int off = -1;
     if (p < npix) {
       const int hy = p / hwd, hx = p - hy * hwd;
       const int y = bound_coord(hy0 + hy, g.Hl, g.pad_mode);
       const int x = bound_coord(hx0 + hx, g.Wl, g.pad_mode);
-      if ((y | x) >= 0) off = ((img * g.Hs + (y >> g.up)) * g.Ws + (x >> g.up)) * g.Cs;
+      if ((y | x) >= 0) {
+        if (PRO && pro.ring != nullptr && !(ring_interior(y, g.Hl) && ring_interior(x, g.Wl)))
+          off = -2 - (img * pro.ring_pix + ring_index(y, x, g.Hl, g.Wl)) * g.Cs;
+        else
+          off = ((img * g.Hs + (y >> g.up)) * g.Ws + (x >> g.up)) * g.Cs;
+      }
     }
     htab[p] = off;
+  }
+  float* const pcoef = reinterpret_cast<float*>(htab + HALO_GROUPS * 8);     // PRO: A[Cs] | B[Cs] of this image
+  if constexpr (PRO) {
+    for (int i = tid; i < 2 * g.Cs; i += 512) {
+      const int which = i >= g.Cs ? 1 : 0;
+      pcoef[i] = (which ? pro.B : pro.A)[(size_t)img * pro.n_stride + (i - which * g.Cs)];
+    }
   }
   __syncthreads();
 
@@ -120,8 +142,9 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, cons
     if (grp >= HALO_GROUPS) grp -= HALO_GROUPS;      // (identical bytes land twice; keeps vmcnt uniform across waves)
     const int pix = grp * 8 + lrow;
     const int o = htab[pix];
+    const int so = (lslot ^ ((pix >> 1) & 7)) << 3;
     h_group[j] = grp;
-    h_off[j] = o >= 0 ? o + ((lslot ^ ((pix >> 1) & 7)) << 3) : -1;
+    h_off[j] = o >= 0 ? o + so : (o == -1 ? -1 : o - so);
   }
   const bf16_t* b_ptr[LB];
 #pragma unroll
@@ -141,7 +164,35 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, cons
 #pragma unroll
     for (int j = 0; j < HALO_HL; ++j) {
       const bf16_t* p = h_off[j] >= 0 ? src + ((size_t)(unsigned)h_off[j] + (unsigned)ci0) : zero;
+      if constexpr (PRO) {
+        if (h_off[j] < -1) p = pro.ring + ((size_t)(unsigned)(-2 - h_off[j]) + (unsigned)ci0);
+      }
       glds16h(p, hb + h_group[j] * 1024);
+    }
+  };
+  // PRO: in-place normalisation of a landed halo slice.  Vector v = tid + 512 j is LDS slot (tid & 7) of halo pixel
+  // (tid >> 3) + 64 j, i.e. logical 16-byte chunk (tid & 7) ^ ((tid >> 4) & 7) for EVERY j: a thread's 8 channels -- and
+  // its 16 coefficients -- are fixed within a slice.
+  const int t_slot = tid & 7, t_chunk = t_slot ^ ((tid >> 4) & 7), t_pix0 = tid >> 3;
+  auto transform = [&](int tslice, int jbeg, int jend) {
+    unsigned char* hb = halo + (tslice & 1) * HALO_BYTES;
+    const float* ca = pcoef + (tslice << 6) + t_chunk * 8;
+    float A8[8], B8[8];
+    ldcoef<8>(ca, A8);
+    ldcoef<8>(ca + g.Cs, B8);
+    for (int j = jbeg; j < jend; ++j) {
+      const int pix = t_pix0 + 64 * j;
+      if (pix < npix && htab[pix] >= 0) {
+        u32x4* p = reinterpret_cast<u32x4*>(hb + pix * 128 + t_slot * 16);
+        float f[8];
+        Elem<bf16_t>::unpack(*p, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = fmaf(A8[e], f[e], B8[e]);
+          f[e] = fmaf(pro.slope, fminf(v, 0.f), fmaxf(v, 0.f));
+        }
+        *p = Elem<bf16_t>::pack(f);
+      }
     }
   };
   int is_tap = 0, is_slice = 0;                      // (tap, slice) of the next weight k-step to issue
@@ -281,6 +332,12 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, cons
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) read_frags(f, ks);
     advance_load();
+    if constexpr (PRO) {
+      // the next slice's halo (issued in C(tap 1)) has landed for EVERY wave once the barrier of the trailing group's
+      // M(tap 3) has passed; its first reader is the leading group's M(tap 0) of the next slice, after this group's
+      // M(tap 6) barrier in both groups' phase order
+      if (slice + 1 < nslices && tap >= 4 && tap <= 6) transform(slice + 1, (tap - 4) * 2, (tap - 4) * 2 + 2);
+    }
     __builtin_amdgcn_sched_barrier(0);
     const unsigned long long q2 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
     // my share of weights(j+1) [issued in C(j-2)] must have landed; younger: weights(j+2) [C(j-1)] and the halo slice
@@ -328,6 +385,11 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, cons
     if (nb >= 2) wait_vm<2 * LB>(); else if (nb == 1) wait_vm<LB>(); else wait_vm<0>();
   }
   __builtin_amdgcn_s_barrier();                          // halo 0 and weights(0) complete for every wave
+  if constexpr (PRO) {
+    transform(0, 0, 6);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                        // slice 0 normalised for every wave
+  }
   if (grp == 1) __builtin_amdgcn_s_barrier();            // group 1 starts one phase late
   // two k-steps per trip (two fragment register sets); an odd last k-step leaves through the break, so the phase code
   // exists twice, not three times (a dispatch walks its code cold: code size is start-up latency)
@@ -400,12 +462,41 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, cons
   constexpr int RPP = 512 / CPR;          // rows per pass
   const int chunk = tid % CPR, rsub = tid / CPR;
   const int ncol = n0 + chunk * 8;
+  float st8[16];                                        // stats: sum (0..7) / sum of squares (8..15) of this thread's 8 channels
+#pragma unroll
+  for (int k = 0; k < 16; ++k) st8[k] = 0.f;
   if (ncol < ldc) {
 #pragma unroll
     for (int p = 0; p < BM / RPP; ++p) {
       const int row = p * RPP + rsub;
       const size_t opix = (size_t)out_pixel(g, img, y0 + (row >> 5), x0 + (row & 31));
-      *reinterpret_cast<u32x4*>(out + opix * ldc + ncol) = *reinterpret_cast<const u32x4*>(ctile + row * CROW + chunk * 16);
+      const u32x4 v = *reinterpret_cast<const u32x4*>(ctile + row * CROW + chunk * 16);
+      *reinterpret_cast<u32x4*>(out + opix * ldc + ncol) = v;
+      if (stats != nullptr) {
+        float f[8];
+        Elem<bf16_t>::unpack(v, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { st8[e] += f[e]; st8[8 + e] = fmaf(f[e], f[e], st8[8 + e]); }
+      }
+    }
+  }
+  if (stats != nullptr) {                                // kernel-uniform
+    // per-thread partials -> the (free) weight-ring area [rsub][chunk][16] -> ordered sums over the RPP row groups
+    float* red = reinterpret_cast<float*>(smem + 2 * HALO_BYTES);
+    float* mine = red + ((size_t)rsub * CPR + chunk) * 16;
+#pragma unroll
+    for (int k = 0; k < 16; k += 4) {
+      f32x4 t;
+      t.x = st8[k]; t.y = st8[k + 1]; t.z = st8[k + 2]; t.w = st8[k + 3];
+      *reinterpret_cast<f32x4*>(mine + k) = t;
+    }
+    __syncthreads();
+    for (int o = tid; o < CPR * 16; o += 512) {
+      const int ch = o >> 4, k = o & 15;
+      float sum = 0.f;
+      for (int r = 0; r < RPP; ++r) sum += red[((size_t)r * CPR + ch) * 16 + k];
+      const int c = n0 + ch * 8 + (k & 7);
+      if (c < ldc) stats[((size_t)tile_m * 2 + (k >> 3)) * ldc + c] = sum;
     }
   }
   if (ablate == 5 && dbg != nullptr && lane == 0) {      // diagnostic: cycles from kernel entry to the last store issued
@@ -416,16 +507,26 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const GatherDesc g, cons
 
 template <int BN, int STAGES, bool FULL = true>      // FULL = false: a sweep instance (tile-size report), default variant only
 static hipError_t launch_halo(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out,
-                              int ldc, int act, const float* dequant, hipStream_t st) {
+                              int ldc, int act, const float* dequant, hipStream_t st, const ConvPro* pro = nullptr,
+                              float* stats = nullptr) {
   const int tiles_m = g.N * (g.Ho / HALO_TH) * (g.Wo / HALO_TW);
   const int tiles_n = (ldc + BN - 1) / BN;
-  const size_t lds = 2 * (size_t)HALO_BYTES + (size_t)STAGES * BN * 128 + HALO_GROUPS * 8 * sizeof(int);
+  const size_t lds = 2 * (size_t)HALO_BYTES + (size_t)STAGES * BN * 128 + HALO_GROUPS * 8 * sizeof(int) +
+                     (pro != nullptr ? 2 * (size_t)g.Cs * sizeof(float) : 0);
+  if (lds > 160 * 1024) return hipErrorNotSupported;
   auto kern = halo_conv_kernel<BN, STAGES, false, true>;
   if constexpr (FULL) {
     if (g_halo_mfma32) kern = halo_conv_kernel<BN, STAGES, false, false>;     // A/B option: 32x32x16 MFMAs
     if (g_v2_ablate == 6) kern = halo_conv_kernel<BN, STAGES, true, true>;   // diagnostic build: per-phase cycle stamps
     if (dequant != nullptr) kern = halo_conv_kernel<BN, STAGES, false, true, true>;   // e4m3 operands
+    if (pro != nullptr) {
+      if (dequant != nullptr) return hipErrorNotSupported;
+      kern = halo_conv_kernel<BN, STAGES, false, true, false, true>;           // operand-path normalisation
+    }
+  } else if (pro != nullptr) {
+    return hipErrorNotSupported;
   }
+  const ConvPro pv = pro != nullptr ? *pro : ConvPro{nullptr, nullptr, 0, 0.f, nullptr, 0};
   {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -434,22 +535,24 @@ static hipError_t launch_halo(const GatherDesc& g, const void* src, const void* 
   count_launch(dequant != nullptr ? K_HALO_CONV_FP8 : K_HALO_CONV);
   prof_begin(PROF_HALO_CONV, (dequant != nullptr ? 4.0 : 2.0) * (double)g.M * (double)(g.th * g.tw) * (double)g.Clog * (double)wrows, st);
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, st, g, (const bf16_t*)src, (const bf16_t*)wgt, wrows, bias,
-                     (bf16_t*)out, ldc, act, tiles_n, g_v2_ablate == 6 ? 5 : g_v2_ablate, g_v2_dbg, dequant);
+                     (bf16_t*)out, ldc, act, tiles_n, g_v2_ablate == 6 ? 5 : g_v2_ablate, g_v2_dbg, dequant, pv, stats);
   prof_end(PROF_HALO_CONV, st);
   return hipGetLastError();
 }
 
 // returns hipErrorNotSupported when the shape does not qualify (the caller falls through to the gather GEMMs)
 // dequant != nullptr selects the fp8 variant (g describes the e4m3 operands as byte pairs: see the kernel)
+// pro / stats: see the kernel (operand-path normalisation of the input, statistics of the output from the epilogue)
 hipError_t halo_conv(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out, int ldc,
-                     int act, int num_cu, hipStream_t st, const float* dequant) {
+                     int act, int num_cu, hipStream_t st, const float* dequant, const ConvPro* pro, float* stats) {
   if (g.sh != 1 || g.sw != 1 || (g.ys != 1 && g.ys != -1) || (g.xs != 1 && g.xs != -1)) return hipErrorNotSupported;
   if (g.th != 3 || g.tw != 3 || g.wK != g.K || g.wtw != g.tw) return hipErrorNotSupported;       // tap count >= ring depth + 1 (halo issue at tap 1)
   if (g.Cs % 64 != 0 || g.Ho % HALO_TH != 0 || g.Wo % HALO_TW != 0 || g.M != g.N * g.Ho * g.Wo) return hipErrorNotSupported;
   if ((long long)g.N * g.Hs * g.Ws * g.Cs >= (1ll << 31)) return hipErrorNotSupported;   // 32-bit offset table
   if (ldc < 64 || ldc % 8 != 0) return hipErrorNotSupported;
   const int tiles_m = g.N * (g.Ho / HALO_TH) * (g.Wo / HALO_TW);
-  if (dequant == nullptr && (g_halo_bn != 0 || g_halo_stages != 0)) {
+  if (pro != nullptr && (g.Cs > 512 || (pro->ring != nullptr && (g.Hl < 4 || g.Wl < 4)))) return hipErrorNotSupported;
+  if (dequant == nullptr && pro == nullptr && stats == nullptr && (g_halo_bn != 0 || g_halo_stages != 0)) {
     // tile-size sweep (options halo_bn / halo_stages; profiles/sweep_tiles.py): output-channel tile width x weight-ring
     // depth.  LDS = 88,064 B of halo + STAGES x BN x 128 B of ring (+ the offset table): 128x4 = 153.6 KB is the
     // largest 128-wide one that fits the 160 KB, 64-wide tiles leave room for rings up to 8 deep.
@@ -465,10 +568,10 @@ hipError_t halo_conv(const GatherDesc& g, const void* src, const void* wgt, int 
   }
   if (ldc >= 128) {
     if (tiles_m * ((ldc + 127) / 128) < num_cu / 2) return hipErrorNotSupported;   // small grids: split-K v1 fills the chip better
-    return launch_halo<128, 4>(g, src, wgt, wrows, bias, out, ldc, act, dequant, st);
+    return launch_halo<128, 4>(g, src, wgt, wrows, bias, out, ldc, act, dequant, st, pro, stats);
   }
   if (tiles_m < num_cu / 2) return hipErrorNotSupported;
-  return launch_halo<64, 4>(g, src, wgt, wrows, bias, out, ldc, act, dequant, st);
+  return launch_halo<64, 4>(g, src, wgt, wrows, bias, out, ldc, act, dequant, st, pro, stats);
 }
 
 }  // namespace dei2i

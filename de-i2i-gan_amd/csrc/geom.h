@@ -188,6 +188,44 @@ inline GatherDesc sub_taps_desc(const GatherDesc& g, int ty0, int nty, int tx0, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// The 2-pixel frame ("ring") of an H x W image: the pixels whose SPADE gamma/beta class is not the interior one when
+// the label map is constant (normalization.py:24-37: two zero-padded 3x3 convs reach 2 pixels in).  The fused
+// SPADE -> conv path keeps their normalised values in a compact side tensor [N][ring_pixels][C]:
+//   rows 0, 1 (W pixels each) | rows H-2, H-1 | for rows 2 .. H-3: columns 0, 1, W-2, W-1
+// ---------------------------------------------------------------------------------------------
+DEI2I_HD int ring_pixels(int H, int W) { return 4 * W + 4 * (H - 4); }
+DEI2I_HD bool ring_interior(int i, int extent) { return i >= 2 && i < extent - 2; }
+DEI2I_HD int ring_index(int y, int x, int H, int W) {
+  if (y < 2) return y * W + x;
+  if (y >= H - 2) return (2 + y - (H - 2)) * W + x;
+  return 4 * W + (y - 2) * 4 + (x < 2 ? x : 2 + x - (W - 2));
+}
+// inverse: ring pixel r -> (y, x)
+DEI2I_HD void ring_coord(int r, int H, int W, int& y, int& x) {
+  if (r < 2 * W) { y = r / W; x = r - y * W; return; }
+  if (r < 4 * W) { const int q = r - 2 * W; y = H - 2 + q / W; x = q - (q / W) * W; return; }
+  const int q = r - 4 * W;
+  y = 2 + (q >> 2);
+  const int k = q & 3;
+  x = k < 2 ? k : W - 2 + (k - 2);
+}
+
+// Operand-path normalisation of a conv's INPUT (fused conv + norm + act, SURVEY.md Appendix B groups G3..G16):
+//   z[n, y, x, c] = act(A[n*n_stride + c] * x[n, y>>up, x>>up, c] + B[...]),  act(v) = max(v,0) + slope*min(v,0)
+// applied by the halo-resident kernels to the input halo in LDS (BatchNorm apply + LeakyReLU: one coefficient set for
+// the batch, n_stride = 0; SPADE's InstanceNorm * (1+gamma) + beta + ReLU on its interior class: per image).  `ring`
+// (optional) holds z of the logical image's 2-pixel frame, already normalised with its own class coefficients: halo
+// pixels of the frame are fetched from it instead of from x and are not transformed.
+struct ConvPro {
+  const float* A;
+  const float* B;
+  int n_stride;
+  float slope;
+  const uint16_t* ring;
+  int ring_pix;
+};
+
+// ---------------------------------------------------------------------------------------------
 // Index maps shared by the device kernels and the CPU geometry check
 // ---------------------------------------------------------------------------------------------
 // packed forward weight element i of [Cout][kh*kw][CinS] -> OIHW source index, or -1 for channel padding

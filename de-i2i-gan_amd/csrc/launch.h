@@ -13,7 +13,7 @@ enum ProfFamily : int { PROF_GATHER_GEMM = 0, PROF_WGRAD = 1, PROF_HALO_CONV = 2
 // host-side launch counters, one per MFMA kernel family (dei2i_launch_counts: the tests assert WHICH kernel served a shape,
 // so that a silent fall-through to the generic GEMM cannot pass a parity test meant for a tuned kernel)
 enum KernelId : int { K_GATHER_V1 = 0, K_GATHER_V2, K_HALO_CONV, K_HALO_CONV_FP8, K_THIN_CIN, K_THIN_COUT, K_WGRAD_V1, K_WGRAD_V2,
-                      K_WGRAD_HALO, K_WGRAD_THIN, K_COUNT };
+                      K_WGRAD_HALO, K_WGRAD_THIN, K_HALO16_CONV, K_COUNT };
 void count_launch(int kid);
 void prof_begin(int family, double flops, hipStream_t st);
 void prof_end(int family, hipStream_t st);
@@ -42,7 +42,12 @@ hipError_t thin_cout_conv(const GatherDesc& g, const void* src, const void* wgt,
 hipError_t thin_cin_conv(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out, int ldc,
                          int act, int num_cu, hipStream_t st);
 hipError_t halo_conv(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out, int ldc,
-                     int act, int num_cu, hipStream_t st, const float* dequant = nullptr);
+                     int act, int num_cu, hipStream_t st, const float* dequant = nullptr, const ConvPro* pro = nullptr,
+                     float* stats = nullptr);
+
+// 16 x 32 pixel tiles, 32-channel slices (conv_halo16.hip): the large-grid 3x3 stride-1 layers
+hipError_t halo16_conv(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out, int ldc,
+                       int act, int num_cu, hipStream_t st, float* stats = nullptr);
 
 hipError_t gather_gemm(int dtype, const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias,
                        void* out, float* ws, size_t ws_bytes, int ldc, int act, hipStream_t st);
@@ -60,7 +65,8 @@ hipError_t wgrad_gemm(int dtype, const GatherDesc& g, const void* src, const voi
 hipError_t wgrad_v2(const GatherDesc& g, const void* src, const void* dy, int co_rows, int ldy, float* slabs,
                     size_t slab_capacity_elems, int num_cu, int* nsplit_out, hipStream_t st);
 hipError_t wgrad_halo(const GatherDesc& g, const void* src, const void* dy, int co_rows, int ldy, float* slabs,
-                      size_t slab_capacity_elems, int num_cu, int* nsplit_out, bool force, hipStream_t st);
+                      size_t slab_capacity_elems, int num_cu, int* nsplit_out, bool force, hipStream_t st,
+                      const ConvPro* pro = nullptr);
 hipError_t wgrad_thin(const GatherDesc& g, const void* src, const void* dy, int co_rows, int ldy, float* slabs,
                       size_t slab_capacity_elems, int num_cu, int* nsplit_out, hipStream_t st);
 hipError_t wgrad_reduce_unpack(float* slabs, int nsplit, long long slab_elems, float* dw, int Cout, int Cin, int CinS,

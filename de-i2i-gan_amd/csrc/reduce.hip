@@ -642,6 +642,129 @@ __global__ void l1_bwd_kernel(const float* __restrict__ a, const float* __restri
   }
 }
 
+// ---- fused conv + norm + act support (BASELINE.json configs[1]) ------------------------------
+// out = act(a[c]*x + b[c]) (+ res) like affine_act_kernel (elementwise.hip), AND the per-channel sum / sum of squares of
+// the stored (rounded) output in the moments_partial record layout: the InstanceNorm / BatchNorm that follows needs no
+// statistics pass of its own.  grid (chunks, N), the row split of moments_partial_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void affine_act_stats_kernel(const T* __restrict__ x, const float* __restrict__ a,
+                                                               const float* __restrict__ b, const T* __restrict__ res,
+                                                               T* __restrict__ out, float* __restrict__ partial, int HW, int C,
+                                                               int chunks, int act) {
+  constexpr int VEC = Elem<T>::VEC;
+  extern __shared__ float smem[];
+  const int cv = C / VEC, rpp = 256 / cv;
+  const int tid = threadIdx.x, vcol = tid % cv, prow = tid / cv;
+  const int chunk = blockIdx.x, n = blockIdx.y;
+  const int rows_per_chunk = (HW + chunks - 1) / chunks;
+  const int rbeg = chunk * rows_per_chunk, rend = min(HW, rbeg + rows_per_chunk);
+  float v[2][VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) v[0][e] = v[1][e] = 0.f;
+  if (prow < rpp) {
+    float av[VEC], bv[VEC];
+    ldcoef<VEC>(a + vcol * VEC, av);
+    ldcoef<VEC>(b + vcol * VEC, bv);
+    const size_t base = (size_t)n * HW * C + (size_t)vcol * VEC;
+    auto one = [&](int r, const u32x4& xq, const u32x4& rq) {
+      float f[VEC], rr[VEC], o[VEC];
+      Elem<T>::unpack(xq, f);
+      if (res != nullptr) Elem<T>::unpack(rq, rr);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float t = apply_act(fmaf(av[e], f[e], bv[e]), act);
+        if (res != nullptr) t += rr[e];
+        o[e] = t;
+      }
+      const u32x4 pk = Elem<T>::pack(o);
+      *reinterpret_cast<u32x4*>(out + base + (size_t)r * C) = pk;
+      Elem<T>::unpack(pk, o);                    // statistics of what the consumer will read
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { v[0][e] += o[e]; v[1][e] = fmaf(o[e], o[e], v[1][e]); }
+    };
+    int r = rbeg + prow;
+    for (; r + rpp < rend; r += 2 * rpp) {        // four 16-byte loads in flight per thread
+      const u32x4 x0 = *reinterpret_cast<const u32x4*>(x + base + (size_t)r * C);
+      const u32x4 x1 = *reinterpret_cast<const u32x4*>(x + base + (size_t)(r + rpp) * C);
+      u32x4 r0 = x0, r1 = x1;
+      if (res != nullptr) {
+        r0 = *reinterpret_cast<const u32x4*>(res + base + (size_t)r * C);
+        r1 = *reinterpret_cast<const u32x4*>(res + base + (size_t)(r + rpp) * C);
+      }
+      one(r, x0, r0);
+      one(r + rpp, x1, r1);
+    }
+    if (r < rend) {
+      const u32x4 x0 = *reinterpret_cast<const u32x4*>(x + base + (size_t)r * C);
+      const u32x4 r0 = res != nullptr ? *reinterpret_cast<const u32x4*>(res + base + (size_t)r * C) : x0;
+      one(r, x0, r0);
+    }
+  }
+  block_combine_store<2, VEC>(v, cv, rpp, smem, partial + ((size_t)n * chunks + chunk) * 2 * C, C);
+}
+
+// SPADE -> conv fusion, the one small kernel in front of the conv (replaces in_finalize + the full-size modulate pass):
+//   * InstanceNorm statistics of image n from the partial records (fp64 combine in record order: deterministic) ->
+//     mean / rstd (kept for the backward pass) and the INTERIOR-class coefficients of the conv's operand-path transform,
+//     A = rstd * (1 + gamma), B = beta - mean * A   (z = relu(A*x + B) == relu(IN(x) * (1 + gamma) + beta));
+//   * z of the logical image's 2-pixel frame, whose gamma / beta classes differ pixel by pixel, into the compact ring
+//     tensor [N][ring_pixels][C] (geom.h) the conv kernels read instead of x there.
+// gb: the (N, 5, 5, 2C) border-class table (normalization.py:24-37 on a constant label map).  grid (blocks, N): every
+// block of an image recomputes the image's statistics (a few KB of L2-resident records), block 0 stores them.
+DEI2I_D int prep_border_class(int i, int extent) { return i < 2 ? i : (i >= extent - 2 ? 4 - (extent - 1 - i) : 2); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void spade_prep_kernel(const T* __restrict__ x, const float* __restrict__ partial,
+                                                         const T* __restrict__ gb, float* __restrict__ mean,
+                                                         float* __restrict__ rstd, float* __restrict__ A, float* __restrict__ B,
+                                                         T* __restrict__ ring, int Hs, int Ws, int C, int up, int chunks,
+                                                         double count, float eps) {
+  constexpr int VEC = Elem<T>::VEC;
+  extern __shared__ float smem[];                 // mean[C] | rstd[C]
+  const int n = blockIdx.y, tid = threadIdx.x;
+  for (int c = tid; c < C; c += 256) {
+    double s0 = 0.0, s1 = 0.0;
+    const float* p = partial + (size_t)n * chunks * 2 * C + c;
+    for (int r = 0; r < chunks; ++r) { s0 += (double)p[(size_t)r * 2 * C]; s1 += (double)p[(size_t)r * 2 * C + C]; }
+    const double mu = s0 / count;
+    double var = s1 / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float m = (float)mu, rs = (float)(1.0 / sqrt(var + (double)eps));
+    smem[c] = m;
+    smem[C + c] = rs;
+    if (blockIdx.x == 0) {
+      mean[(size_t)n * C + c] = m;
+      rstd[(size_t)n * C + c] = rs;
+      const T* gi = gb + ((size_t)n * 25 + 12) * 2 * C;       // interior class (2, 2)
+      const float av = rs * (1.f + Elem<T>::load(gi + c));
+      A[(size_t)n * C + c] = av;
+      B[(size_t)n * C + c] = Elem<T>::load(gi + C + c) - m * av;
+    }
+  }
+  __syncthreads();
+  if (ring == nullptr) return;
+  const int H = Hs << up, W = Ws << up, cv = C / VEC;
+  const int rp = ring_pixels(H, W);
+  const int total = rp * cv;
+  for (int i = blockIdx.x * 256 + tid; i < total; i += gridDim.x * 256) {
+    const int r = i / cv, c = (i - r * cv) * VEC;
+    int y, xx;
+    ring_coord(r, H, W, y, xx);
+    float xv[VEC], gm[VEC], bt[VEC], o[VEC];
+    Elem<T>::unpack(*reinterpret_cast<const u32x4*>(x + (((size_t)n * Hs + (y >> up)) * Ws + (xx >> up)) * C + c), xv);
+    const size_t gpix = ((size_t)n * 5 + prep_border_class(y, H)) * 5 + prep_border_class(xx, W);
+    Elem<T>::unpack(*reinterpret_cast<const u32x4*>(gb + gpix * 2 * C + c), gm);
+    Elem<T>::unpack(*reinterpret_cast<const u32x4*>(gb + gpix * 2 * C + C + c), bt);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float xh = (xv[e] - smem[c + e]) * smem[C + c + e];
+      const float v = fmaf(xh, 1.f + gm[e], bt[e]);
+      o[e] = v > 0.f ? v : 0.f;
+    }
+    *reinterpret_cast<u32x4*>(ring + ((size_t)n * rp + r) * C + c) = Elem<T>::pack(o);
+  }
+}
+
 }  // namespace dei2i
 
 using namespace dei2i;
@@ -680,6 +803,52 @@ int dei2i_bn_finalize_train(int N, int HW, int C, const float* partial, const fl
   hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(C), dim3(combine_threads(N * dei2i_moments_chunks(HW))), 0, (hipStream_t)s, partial, N,
                      dei2i_moments_chunks(HW), C, (double)N * (double)HW, weight, bias, running_mean, running_var, momentum,
                      eps, mean, rstd, a, b, num_batches_tracked);
+  return (int)hipGetLastError();
+}
+
+int dei2i_bn_finalize_train_chunks(int N, int HW, int C, int chunks, const float* partial, const float* weight, const float* bias,
+                                   float* running_mean, float* running_var, float momentum, float eps, float* mean, float* rstd,
+                                   float* a, float* b, long long* num_batches_tracked, dei2i_stream s) {
+  if (N <= 0 || HW <= 0 || C <= 0 || chunks <= 0 || !partial || !weight || !bias || !mean || !rstd || !a || !b) return DEI2I_ERR_BAD_ARG;
+  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(C), dim3(combine_threads(N * chunks)), 0, (hipStream_t)s, partial, N, chunks, C,
+                     (double)N * (double)HW, weight, bias, running_mean, running_var, momentum, eps, mean, rstd, a, b,
+                     num_batches_tracked);
+  return (int)hipGetLastError();
+}
+
+int dei2i_affine_act_stats_fwd(int dtype, int N, int HW, int C, const void* x, const float* a, const float* b, const void* res,
+                               int act, void* out, float* partial, dei2i_stream s) {
+  if (N <= 0 || HW <= 0 || !cv_ok(dtype, C) || !x || !a || !b || !out || !partial) return DEI2I_ERR_BAD_ARG;
+  const int chunks = dei2i_moments_chunks(HW);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(affine_act_stats_kernel<bf16_t>, dim3(chunks, N), dim3(256), combine_lds(dtype, 2), (hipStream_t)s,
+                       (const bf16_t*)x, a, b, (const bf16_t*)res, (bf16_t*)out, partial, HW, C, chunks, act);
+  else
+    hipLaunchKernelGGL(affine_act_stats_kernel<float>, dim3(chunks, N), dim3(256), combine_lds(dtype, 2), (hipStream_t)s,
+                       (const float*)x, a, b, (const float*)res, (float*)out, partial, HW, C, chunks, act);
+  return (int)hipGetLastError();
+}
+
+size_t dei2i_ring_pixels(int H, int W) { return H >= 4 && W >= 4 ? (size_t)ring_pixels(H, W) : 0; }
+
+int dei2i_spade_prep(int dtype, int N, int Hs, int Ws, int C, int up, const void* x, const float* partial, int chunks, float eps,
+                     const void* gb_table, float* mean, float* rstd, float* A, float* B, void* ring, dei2i_stream s) {
+  if (N <= 0 || Hs <= 0 || Ws <= 0 || !cv_ok(dtype, C) || up < 0 || up > 1 || chunks <= 0 || !x || !partial || !gb_table || !mean ||
+      !rstd || !A || !B)
+    return DEI2I_ERR_BAD_ARG;
+  if (ring != nullptr && ((Hs << up) < 4 || (Ws << up) < 4)) return DEI2I_ERR_BAD_ARG;
+  const int vec = dtype == DT_BF16 ? 8 : 4;
+  const int work = ring != nullptr ? ring_pixels(Hs << up, Ws << up) * (C / vec) : 0;
+  int blocks = (work + 256 * 8 - 1) / (256 * 8);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 64) blocks = 64;
+  const size_t lds = 2 * (size_t)C * sizeof(float);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(spade_prep_kernel<bf16_t>, dim3(blocks, N), dim3(256), lds, (hipStream_t)s, (const bf16_t*)x, partial,
+                       (const bf16_t*)gb_table, mean, rstd, A, B, (bf16_t*)ring, Hs, Ws, C, up, chunks, (double)Hs * (double)Ws, eps);
+  else
+    hipLaunchKernelGGL(spade_prep_kernel<float>, dim3(blocks, N), dim3(256), lds, (hipStream_t)s, (const float*)x, partial,
+                       (const float*)gb_table, mean, rstd, A, B, (float*)ring, Hs, Ws, C, up, chunks, (double)Hs * (double)Ws, eps);
   return (int)hipGetLastError();
 }
 

@@ -49,11 +49,16 @@ template <int ROWB> DEI2I_D int hw_swz(int row) {
 
 // BCO x BCI = 128 x 64 (Cout >= 96) or 64 x 128 (Cout <= 64): 8 waves = (BCO/32) x (BCI/32) blocks, 9 taps each;
 // 64 x 64 with the taps split over NTG = 2 wave groups for 64-channel inputs (the 64 -> 4 heads: one live co block)
-template <int BCO, int BCI, int NTG>
+// PRO: the conv's input was normalised + activated on the operand path in the forward pass (ConvPro, geom.h; the
+// normalised tensor z was never written), so the same transform is applied here to every landed input halo, in place in
+// LDS, before its nine taps are read: one extra pass over 26 KB and one extra barrier per half-tile.
+template <int N> DEI2I_D void hw_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BCO, int BCI, int NTG, bool PRO = false>
 __global__ __launch_bounds__(512) void wgrad_halo_kernel(const GatherDesc g, const bf16_t* __restrict__ src,
                                                          const bf16_t* __restrict__ dy, const int co_rows, const int ldy,
                                                          float* __restrict__ slabs, const int nslices, const int tiles_per_split,
-                                                         const long long slab_elems) {
+                                                         const long long slab_elems, const ConvPro pro) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -112,9 +117,43 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const GatherDesc g, con
       if (hp < HW_HPIX) {
         const int y = bound_coord(y0 + g.by0 + hy, g.Hl, g.pad_mode);
         const int x = bound_coord(x0 + g.bx0 + hx, g.Wl, g.pad_mode);
-        if ((y | x) >= 0) p = src + ((size_t)((img * g.Hs + (y >> g.up)) * g.Ws + (x >> g.up))) * g.Cs + ci0 + (off >> 1);
+        if ((y | x) >= 0) {
+          if (PRO && pro.ring != nullptr && !(ring_interior(y, g.Hl) && ring_interior(x, g.Wl)))
+            p = pro.ring + ((size_t)(img * pro.ring_pix + ring_index(y, x, g.Hl, g.Wl))) * g.Cs + ci0 + (off >> 1);
+          else
+            p = src + ((size_t)((img * g.Hs + (y >> g.up)) * g.Ws + (x >> g.up))) * g.Cs + ci0 + (off >> 1);
+        }
       }
       glds16hw(p, sb + grp * 1024);
+    }
+  };
+  // PRO: z = act(A*x + B) on the landed halo of tile t (ring pixels arrive normalised, padding stays zero)
+  float* const pcoef = reinterpret_cast<float*>(smem + 2 * HW_STAGE);      // A[BCI] | B[BCI] of the current image's slice
+  auto transform = [&](int stage, int t) {
+    unsigned char* sb = smem + stage * HW_STAGE + HW_A_BYTES;
+    const int img = t / tiles_img;
+    const int rem = t - img * tiles_img;
+    const int ty = rem / tiles_x;
+    const int y0 = ty * HW_TH, x0 = (rem - ty * tiles_x) * HW_TW;
+    for (int v = tid; v < HW_HPIX * SPR_B; v += 512) {
+      const int hp = v / SPR_B, sl = v - hp * SPR_B;
+      const int hy = hp / HW_HWD, hx = hp - hy * HW_HWD;
+      const int y = bound_coord(y0 + g.by0 + hy, g.Hl, g.pad_mode);
+      const int x = bound_coord(x0 + g.bx0 + hx, g.Wl, g.pad_mode);
+      if ((y | x) < 0) continue;
+      if (pro.ring != nullptr && !(ring_interior(y, g.Hl) && ring_interior(x, g.Wl))) continue;
+      const int cofs = ((sl * 16) ^ hw_swz<ROWB_B>(hp)) >> 1;
+      float A8[8], B8[8], f[8];
+      ldcoef<8>(pcoef + cofs, A8);
+      ldcoef<8>(pcoef + BCI + cofs, B8);
+      u32x4* p = reinterpret_cast<u32x4*>(sb + hp * ROWB_B + sl * 16);
+      Elem<bf16_t>::unpack(*p, f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float w = fmaf(A8[e], f[e], B8[e]);
+        f[e] = fmaf(pro.slope, fminf(w, 0.f), fmaxf(w, 0.f));
+      }
+      *p = Elem<bf16_t>::pack(f);
     }
   };
 
@@ -162,13 +201,37 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const GatherDesc g, con
   // ---- two-stage ring over the half-tiles of this split: one barrier per half-tile (~4 600 cycles of MFMA) ----
   // (rotated: the trip it = -1 only issues stage 0, so `issue` and `compute` each exist once in the instruction stream)
   const int nt = tend - tbeg;
+  int cur_img = -1;
 #pragma unroll 1
   for (int it = -1; it < nt; ++it) {
     if (it >= 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // my share of stage `it` has landed
       __builtin_amdgcn_s_barrier();                                       // ... everyone's; compute(it-1) is done everywhere
     }
+    bool reload = false;
+    float cval = 0.f;
+    if constexpr (PRO) {
+      if (it >= 0) {
+        const int img = (tbeg + it) / tiles_img;
+        reload = img != cur_img;                                          // workgroup-uniform: a new image's coefficients
+        if (reload && tid < 2 * BCI)
+          cval = (tid < BCI ? pro.A : pro.B)[(size_t)img * pro.n_stride + ci0 + (tid < BCI ? tid : tid - BCI)];
+        cur_img = img;
+      }
+    }
     if (it + 1 < nt) issue((it + 1) & 1, tbeg + it + 1);
+    if constexpr (PRO) {
+      if (it >= 0) {
+        if (reload) {
+          if (it + 1 < nt) hw_wait_vm<NA + NB>(); else hw_wait_vm<0>();   // the coefficient load is older than the DMA just issued
+          if (tid < 2 * BCI) pcoef[tid] = cval;
+          __syncthreads();
+        }
+        transform(it & 1, tbeg + it);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                     // the halo is normalised for every wave
+      }
+    }
     if (it >= 0) compute(it & 1);
   }
 
@@ -195,7 +258,8 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const GatherDesc g, con
 
 template <int BCO, int BCI, int NTG>
 static hipError_t launch_wgrad_halo(const GatherDesc& g, const void* src, const void* dy, int co_rows, int ldy, float* slabs,
-                                    size_t slab_capacity_elems, int num_cu, int* nsplit_out, bool force, hipStream_t st) {
+                                    size_t slab_capacity_elems, int num_cu, int* nsplit_out, bool force, hipStream_t st,
+                                    const ConvPro* pro) {
   const int nslices = g.Cs / BCI, tiles_c = (co_rows + BCO - 1) / BCO;
   const int combos = nslices * tiles_c;
   const int ntiles = g.N * (g.Ho / HW_TH) * (g.Wo / HW_TW);
@@ -208,18 +272,19 @@ static hipError_t launch_wgrad_halo(const GatherDesc& g, const void* src, const 
   if (!force && combos * splits < (num_cu * 3) / 4) return hipErrorNotSupported;   // too little parallelism: wgrad_v2 / v1 fill the chip better
   const int tps = (ntiles + splits - 1) / splits;
   const int zs = (ntiles + tps - 1) / tps;
-  const size_t lds = 2 * (size_t)(128 * BCO * 2 + HW_HPAD * BCI * 2);
-  auto kern = wgrad_halo_kernel<BCO, BCI, NTG>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  const size_t lds = 2 * (size_t)(128 * BCO * 2 + HW_HPAD * BCI * 2) + (pro != nullptr ? 2 * BCI * sizeof(float) : 0);
+  auto kern = pro != nullptr ? wgrad_halo_kernel<BCO, BCI, NTG, true> : wgrad_halo_kernel<BCO, BCI, NTG, false>;
+  static bool attr_done[2] = {false, false};
+  if (!attr_done[pro != nullptr]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_done[pro != nullptr] = true;
   }
+  const ConvPro pv = pro != nullptr ? *pro : ConvPro{nullptr, nullptr, 0, 0.f, nullptr, 0};
   count_launch(K_WGRAD_HALO);
   prof_begin(PROF_WGRAD, 2.0 * (double)g.M * 9.0 * (double)g.Clog * (double)co_rows, st);
   hipLaunchKernelGGL(kern, dim3(zs, combos), dim3(512), lds, st, g, (const bf16_t*)src, (const bf16_t*)dy, co_rows, ldy, slabs,
-                     nslices, tps, slab_elems);
+                     nslices, tps, slab_elems, pv);
   prof_end(PROF_WGRAD, st);
   *nsplit_out = zs;
   return hipGetLastError();
@@ -227,19 +292,20 @@ static hipError_t launch_wgrad_halo(const GatherDesc& g, const void* src, const 
 
 // returns hipErrorNotSupported when the shape does not qualify (the caller falls through to wgrad_v2 / v1)
 hipError_t wgrad_halo(const GatherDesc& g, const void* src, const void* dy, int co_rows, int ldy, float* slabs,
-                      size_t slab_capacity_elems, int num_cu, int* nsplit_out, bool force, hipStream_t st) {
+                      size_t slab_capacity_elems, int num_cu, int* nsplit_out, bool force, hipStream_t st, const ConvPro* pro) {
+  if (pro != nullptr && pro->ring != nullptr && (g.Hl < 4 || g.Wl < 4)) return hipErrorNotSupported;
   if (g.sh != 1 || g.sw != 1 || g.ys != 1 || g.xs != 1 || g.th != 3 || g.tw != 3) return hipErrorNotSupported;
   if (g.Ho % HW_TH != 0 || g.Wo % HW_TW != 0) return hipErrorNotSupported;
   if ((long long)g.N * g.Hs * g.Ws * g.Cs >= (1ll << 31)) return hipErrorNotSupported;
   if (co_rows <= 64) {
     if (g.Cs % 128 == 0 && co_rows >= 48)
-      return launch_wgrad_halo<64, 128, 1>(g, src, dy, co_rows, ldy, slabs, slab_capacity_elems, num_cu, nsplit_out, force, st);
+      return launch_wgrad_halo<64, 128, 1>(g, src, dy, co_rows, ldy, slabs, slab_capacity_elems, num_cu, nsplit_out, force, st, pro);
     if (g.Cs % 64 == 0 && co_rows <= 32)        // thin heads: the work is the input stream; taps split over two wave groups
-      return launch_wgrad_halo<64, 64, 2>(g, src, dy, co_rows, ldy, slabs, slab_capacity_elems, num_cu, nsplit_out, force, st);
+      return launch_wgrad_halo<64, 64, 2>(g, src, dy, co_rows, ldy, slabs, slab_capacity_elems, num_cu, nsplit_out, force, st, pro);
     return hipErrorNotSupported;
   }
   if (g.Cs % 64 != 0 || co_rows < 96) return hipErrorNotSupported;
-  return launch_wgrad_halo<128, 64, 1>(g, src, dy, co_rows, ldy, slabs, slab_capacity_elems, num_cu, nsplit_out, force, st);
+  return launch_wgrad_halo<128, 64, 1>(g, src, dy, co_rows, ldy, slabs, slab_capacity_elems, num_cu, nsplit_out, force, st, pro);
 }
 
 }  // namespace dei2i

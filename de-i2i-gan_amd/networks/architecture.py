@@ -61,9 +61,10 @@ class Conv2d(nn.Module):
         return ops.ConvGeom(self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding,
                             self.padding_mode == "reflect" and self.padding > 0, up)
 
-    def forward(self, x, act="none", up=False):
+    def forward(self, x, act="none", up=False, stats=False):
+        """``stats``: a BatchNorm / InstanceNorm reads the output next (its statistics come from the conv epilogue)."""
         w, sources = self.effective_weight()
-        return ops.conv2d(x, w, self.bias, self._packed, self.geom(up), act, sources=sources)
+        return ops.conv2d(x, w, self.bias, self._packed, self.geom(up), act, sources=sources, stats=stats)
 
     def extra_repr(self):
         return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, "
@@ -86,9 +87,20 @@ class BatchNorm2d(nn.Module):
         nn.init.ones_(self.weight)
         nn.init.zeros_(self.bias)
 
-    def forward(self, y, act="none", res=None):
+    def forward(self, y, act="none", res=None, stats=False):
         return ops.batchnorm_act(y, self.weight, self.bias, self.running_mean, self.running_var, self.training, act, res,
-                                 self.momentum, self.eps, self.num_batches_tracked)
+                                 self.momentum, self.eps, self.num_batches_tracked, stats=stats)
+
+    def fused_conv(self, y, act, conv, stats=False):
+        """conv(act(self(y))) with this BatchNorm's apply + activation on ``conv``'s operand path when the kernels take the
+        shape (ops.bn_act_conv: the normalised tensor is never written); the two-kernel formulation otherwise."""
+        if type(conv) is Conv2d and conv.bias is None:     # (a spectral conv derives its weight per call: effective_weight() iterates u, v)
+            w, geom = conv.weight, conv.geom(False)
+            need_grad = torch.is_grad_enabled() and (y.requires_grad or w.requires_grad or self.weight.requires_grad)
+            if ops.bn_act_conv_supported(y, self.weight, w, geom, need_grad):
+                return ops.bn_act_conv(y, self.weight, self.bias, self.running_mean, self.running_var, self.training, act, w,
+                                       conv._packed, geom, self.momentum, self.eps, self.num_batches_tracked, stats=stats)
+        return conv(self(y, act), stats=stats)
 
     def extra_repr(self):
         return f"{self.num_features}, eps={self.eps}, momentum={self.momentum}"
@@ -219,10 +231,10 @@ class ConvBlock(nn.Module):
         blocks.append(get_act_layer(act_layer))
         self.conv_block = nn.Sequential(*blocks)
 
-    def forward(self, x, seg=None, res=None):
+    def forward(self, x, seg=None, res=None, out_stats=False):
         if self._has_norm:
-            y = self.conv_block[0](x)
-            return self.conv_block[1](y, self._act, res)
+            y = self.conv_block[0](x, stats=True)
+            return self.conv_block[1](y, self._act, res, stats=out_stats)
         assert res is None
         return self.conv_block[0](x, self._act)
 
@@ -259,9 +271,16 @@ class ResBlock(nn.Module):
             ConvBlock(f_in, f_in, kernel_size, stride, padding, padding_mode, bias, norm_layer, act_layer, use_spectral),
             ConvBlock(f_in, f_out, kernel_size, stride, padding, padding_mode, bias, norm_layer, None, use_spectral))
 
-    def forward(self, x, seg=None):
-        h = self.res_block[0](x)
-        return self.res_block[1](h, res=x)           # identity add fused into the BatchNorm-apply kernel
+    def forward(self, x, seg=None, out_stats=False):
+        """``out_stats``: a norm layer (the decoder's first SPADE) reads the block's output next."""
+        first, second = self.res_block[0], self.res_block[1]
+        if first._has_norm and second._has_norm:
+            # conv -> [BN + LeakyReLU on the second conv's operand path] -> conv -> BN + identity add (one kernel)
+            y1 = first.conv_block[0](x, stats=True)
+            y2 = first.conv_block[1].fused_conv(y1, first._act, second.conv_block[0], stats=True)
+            return second.conv_block[1](y2, second._act, x, stats=out_stats)
+        h = first(x)
+        return second(h, res=x, out_stats=out_stats)           # identity add fused into the BatchNorm-apply kernel
 
 
 class SPADE(nn.Module):
@@ -292,14 +311,28 @@ class SPADE(nn.Module):
         geom = ops.ConvGeom(self.hidden_nc, 2 * self.norm_nc, self.mlp_gamma.kernel_size, 1, self.mlp_gamma.padding, False, False)
         return ops.conv2d(actv, w_gb, b_gb, self._packed_gb, geom, "none", sources=(self.mlp_gamma.weight, self.mlp_beta.weight))
 
-    def forward(self, x, segmap, up=False, skip=False):
+    def fused_conv(self, x, segmap, conv, up=False, skip=False, stats=False):
+        """conv(self(x, segmap, up)) -- with skip: (that, x) -- the InstanceNorm apply + modulate + ReLU (+ upsample) on
+        ``conv``'s operand path when the label map is constant and the kernels take the shape (ops.spade_conv); the
+        two-kernel formulation otherwise."""
         prec = ops.precision_of(x)
         n, hs, ws, c = x.shape
         h, w = (2 * hs, 2 * ws) if up else (hs, ws)
         class_mode = segmap.shape[2] == 1 and segmap.shape[3] == 1 and h >= 4 and w >= 4
-        self._ran_class_mode = class_mode                 # prime() only serves modules that run (norm_s never does)
-        if not class_mode:
-            return ops.spade_relu(x, self._gamma_beta(segmap, prec, False, h, w), up, 0, skip=skip)
+        if class_mode and type(conv) is Conv2d and conv.bias is None:     # (spectral convs derive their weight per call: unfused)
+            wt, geom = conv.weight, conv.geom(up)
+            params_grad = wt.requires_grad or self.mlp_gamma.weight.requires_grad
+            need_grad = torch.is_grad_enabled() and (x.requires_grad or params_grad)
+            if ops.spade_conv_supported(x, wt, geom, need_grad):
+                self._ran_class_mode = True
+                gb = self._class_table(segmap, prec, h, w)
+                return ops.spade_conv(x, gb, wt, conv._packed, geom, skip=skip, stats=stats)
+        if skip:
+            z, xs = self(x, segmap, up=up, skip=True)
+            return conv(z, stats=stats), xs
+        return conv(self(x, segmap, up=up), stats=stats)
+
+    def _class_table(self, segmap, prec, h, w):
         # The class table depends only on (label map, this module's weights), not on x: the loss graphs call G several
         # times with the SAME label tensors (defectgan_model.py:185-190), so the table -- with its autograd history,
         # autograd sums the gradients of all its uses -- is computed once per (label tensor, weight state, grad mode).
@@ -310,9 +343,18 @@ class SPADE(nn.Module):
             if len(self._gb_cache) >= 2:
                 self._gb_cache.clear()
             self._gb_cache[key] = (segmap, gb)          # keep the label tensor alive so its id stays unique
-        else:
-            gb = hit[1]
-        return ops.spade_relu(x, gb, up, 1, skip=skip)
+            return gb
+        return hit[1]
+
+    def forward(self, x, segmap, up=False, skip=False):
+        prec = ops.precision_of(x)
+        n, hs, ws, c = x.shape
+        h, w = (2 * hs, 2 * ws) if up else (hs, ws)
+        class_mode = segmap.shape[2] == 1 and segmap.shape[3] == 1 and h >= 4 and w >= 4
+        self._ran_class_mode = class_mode                 # prime() only serves modules that run (norm_s never does)
+        if not class_mode:
+            return ops.spade_relu(x, self._gamma_beta(segmap, prec, False, h, w), up, 0, skip=skip)
+        return ops.spade_relu(x, self._class_table(segmap, prec, h, w), up, 1, skip=skip)
 
     def _table_key(self, segmap, prec):
         params = (self.mlp_shared[0].weight, self.mlp_shared[0].bias, self.mlp_gamma.weight, self.mlp_gamma.bias,
@@ -361,8 +403,9 @@ class NormConvBlock(nn.Module):
         self.conv = make_conv(use_spectral, f_in, f_out, kernel_size, stride, padding, padding_mode, bias)
         self.act = get_act_layer(act_layer)
 
-    def forward(self, x, labels, style_feat=None):
-        return self.noise(self.conv(self.norm(x, labels, up=self.up_scale)))
+    def forward(self, x, labels, style_feat=None, out_stats=False):
+        """``out_stats``: another norm layer reads the output next (the following NormConvBlock's SPADE)."""
+        return self.noise(self.norm.fused_conv(x, labels, self.conv, up=self.up_scale, stats=out_stats))
 
 
 class NormResBlock(nn.Module):
@@ -390,12 +433,15 @@ class NormResBlock(nn.Module):
         self.conv_1 = make_conv(use_spectral, f_mid, f_out, kernel_size, stride, padding, padding_mode, bias)
         self.conv_s = make_conv(use_spectral, f_in, f_out, kernel_size, stride, padding, padding_mode, bias)
 
-    def forward(self, x, labels, style_feat=None):
+    def forward(self, x, labels, style_feat=None, out_stats=False):
         # norm_0 hands x through (xs) so that the identity branch's gradient is added inside its backward kernel
-        z, xs = self.norm_0(x, labels, skip=True) if x.is_contiguous() else (self.norm_0(x, labels), x)
-        h = self.noise_0(self.conv_0(z))
-        h = self.noise_1(self.conv_1(self.norm_1(h, labels)))
-        return ops.add(h, xs)
+        if x.is_contiguous():
+            h, xs = self.norm_0.fused_conv(x, labels, self.conv_0, skip=True, stats=True)
+        else:
+            h, xs = self.norm_0.fused_conv(x, labels, self.conv_0, stats=True), x
+        h = self.noise_0(h)
+        h = self.noise_1(self.norm_1.fused_conv(h, labels, self.conv_1))
+        return ops.add(h, xs, stats=out_stats)
 
 
 class MaskToken(nn.Module):

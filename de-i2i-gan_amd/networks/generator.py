@@ -72,12 +72,14 @@ class DefectGanGenerator(BaseNetwork):
         feat = self.stem(ops.to_nhwc(x, self.prec))
         for enc_blk in self.enc_blk:
             feat = enc_blk(feat, labels)
-        for enc_res_blk in self.enc_res_blk:
-            feat = enc_res_blk(feat, labels)
-        for dec_res_blk in self.dec_res_blk:
-            feat = dec_res_blk(feat, labels, style_feat)
-        for dec_blk in self.dec_blk:
-            feat = dec_blk(feat, labels, style_feat)
+        # out_stats: the next layer is a norm -- the producer leaves the statistics records of its output (ops._stats_of)
+        n_enc, n_dec, n_up = len(self.enc_res_blk), len(self.dec_res_blk), len(self.dec_blk)
+        for i, enc_res_blk in enumerate(self.enc_res_blk):
+            feat = enc_res_blk(feat, labels, out_stats=(i == n_enc - 1))
+        for i, dec_res_blk in enumerate(self.dec_res_blk):
+            feat = dec_res_blk(feat, labels, style_feat, out_stats=True)
+        for i, dec_blk in enumerate(self.dec_blk):
+            feat = dec_blk(feat, labels, style_feat, out_stats=(i < n_up - 1))
         # generator.py:266-267 -- nan_to_num only when a NaN is present; device-side flag, no host sync
         with torch.no_grad():
             ops.nan_guard_(feat)

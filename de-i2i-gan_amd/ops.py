@@ -59,6 +59,16 @@ class fp8_forward:
         return False
 
 
+# fused conv + norm + act (halo-resident kernels).  Run-time switches for same-box A/B timing and for the parity tests of
+# fused against unfused:
+#   fuse_norm : statistics of a conv's / affine kernel's output from its own epilogue (no separate moments pass)  -- ON
+#   fuse_pro  : BatchNorm / SPADE apply on the CONSUMER conv's operand path (the normalised tensor is never written) -- OFF:
+#               measured at 256x256 batch 16 (profiles/r02_b_*): the in-LDS transform costs +33 us on a 99 us conv and
+#               +34 us on a 91 us wgrad (it is repeated per output-channel tile and again in the wgrad, in kernels whose
+#               VALU slots compete with the MFMA issue) against ~39 us of statistics + modulate kernels saved: +1.4 ms/step.
+fuse_norm = True
+fuse_pro = False
+
 _fp8_stash = []          # e4m3 copy produced by the last normalisation kernel, handed to its output tensor by the wrapper
 
 
@@ -366,9 +376,68 @@ class PackedWeights:
         return self.fp8
 
 
+_stats_stash = []        # (partial records, records per image) of the last producer, handed to its output tensor by the wrapper
+
+
+def _attach_stats(out):
+    if _stats_stash:
+        out._dei2i_stats = _stats_stash.pop()
+    return out
+
+
+def _stats_of(t, n, hw, c):
+    """The statistics records a producer kernel left for tensor ``t`` ((N, chunks, 2, C) fp32, chunks), or None."""
+    st = getattr(t, "_dei2i_stats", None)
+    if st is None:
+        return None
+    partial, chunks = st
+    if partial.shape != (n, chunks, 2, c) or partial.device != t.device:
+        return None
+    return partial, chunks
+
+
+def _conv_dgrad(lib, prec, geom, x_shape, couts, g, weight, cache, sources, per_call, dtype, device):
+    """Gradient w.r.t. the conv's physical input (N, H, W, CinS) from g = dL/dy (activation already folded in)."""
+    n, h, w, cins = x_shape
+    d = _desc(prec, geom, n, h, w, cins, couts)
+    _, wd = cache.get(weight, sources, prec, geom, cins, couts, need_dgrad=True, need_fwd=False, per_call=per_call)
+    ws = _workspace(device, lib.dei2i_conv2d_workspace_bytes(byref(d)))
+    dx = torch.empty(x_shape, dtype=dtype, device=device)
+    ext = None
+    if (geom.reflect and geom.pad > 0) or geom.up:           # the dgrad frame differs from the input: scratch
+        oh, ow = c_int(), c_int()
+        lib.dei2i_conv2d_dgrad_shape(byref(d), byref(oh), byref(ow))
+        ext = _workspace(device, n * oh.value * ow.value * cins * dx.element_size(), slot="dgrad_frame")
+    L.check(lib.dei2i_conv2d_dgrad_input(byref(d), _p(g), _p(wd), _p(ext), _p(dx), _p(ws), ws.numel() * 4, _stream()),
+            "conv2d_dgrad_input")
+    return dx
+
+
+def _wgrad_scratch(lib, d, device):
+    packed = lib.dei2i_wgrad_slab_elems(byref(d))
+    # partial slabs: up to 64, or as many as fit 96 MB (a (co, ci, 9-tap) register block per CU is 256 x 295 KB)
+    return _workspace(device, max(packed * 4, min(max(packed * 4 * 64, 96 << 20), 512 << 20)), slot="wgrad")
+
+
+def _conv_wgrad(lib, prec, geom, x, g, weight, pro=None):
+    """OIHW fp32 weight gradient (in-place accumulated across the nodes of one pass: _grad_target); ``pro``: the conv's
+    input was normalised on the operand path, x is the un-normalised tensor."""
+    n, h, w, cins = x.shape
+    d = _desc(prec, geom, n, h, w, cins, g.shape[-1])
+    scratch = _wgrad_scratch(lib, d, x.device)
+    dw, dw_ptr, accumulate = _grad_target(weight, weight.shape, x.device)
+    if pro is None:
+        L.check(lib.dei2i_conv2d_wgrad_oihw(byref(d), _p(x), _p(g), _p(scratch), scratch.numel(), c_void_p(dw_ptr), accumulate,
+                                            _stream()), "conv2d_wgrad")
+    else:
+        L.check(lib.dei2i_conv2d_wgrad_oihw_pro(byref(d), _p(x), _p(g), _p(scratch), scratch.numel(), c_void_p(dw_ptr), accumulate,
+                                                byref(pro), _stream()), "conv2d_wgrad_pro")
+    return dw
+
+
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, cache: PackedWeights, sources, geom: ConvGeom, act: int):
+    def forward(ctx, x, weight, bias, cache: PackedWeights, sources, geom: ConvGeom, act: int, want_stats: bool = False):
         _require_gpu(x, "conv2d")
         prec = precision_of(x)
         x = x.contiguous()
@@ -390,11 +459,11 @@ class _Conv2d(torch.autograd.Function):
         ho, wo = c_int(), c_int()
         lib.dei2i_conv2d_out_shape(byref(d), byref(ho), byref(wo))
         y = torch.empty((n, ho.value, wo.value, couts), dtype=prec.dtype, device=x.device)
-        ws_bytes = lib.dei2i_conv2d_workspace_bytes(byref(d))
-        ws = _workspace(x.device, ws_bytes)
         b32 = None
         if bias is not None:
             b32 = bias.detach().float().contiguous()
+        # the epilogue of the halo-resident kernel can leave the per-channel statistics of y for the norm that follows
+        stats_fused = bool(want_stats and fuse_norm and not use_fp8 and prec is BF16 and lib.dei2i_conv2d_fused_supported(byref(d), 0))
         if use_fp8:
             wq, dequant = cache.get_fp8(weight, sources, prec, geom, cins, couts)
             xq = getattr(x, "_dei2i_fp8", None)      # written by the producing normalisation kernel in the same pass
@@ -405,7 +474,14 @@ class _Conv2d(torch.autograd.Function):
                 L.check(lib.dei2i_quantize_fp8(x.numel(), _p(x), FP8_ACT_SCALE, _p(xq), _stream()), "quantize_fp8")
             L.check(lib.dei2i_conv2d_fwd_fp8(byref(d), _p(xq), _p(wq), _p(b32), _p(dequant), act, _p(y), _stream()),
                     "conv2d_fwd_fp8")
+        elif stats_fused:
+            chunks = lib.dei2i_conv2d_stats_chunks(byref(d))
+            partial = torch.empty((n, chunks, 2, couts), dtype=torch.float32, device=x.device)
+            L.check(lib.dei2i_conv2d_fwd_fused(byref(d), _p(x), _p(wf), _p(b32), act, _p(y), None, _p(partial), _stream()),
+                    "conv2d_fwd_fused")
+            _stats_stash.append((partial, chunks))
         else:
+            ws = _workspace(x.device, lib.dei2i_conv2d_workspace_bytes(byref(d)))
             L.check(lib.dei2i_conv2d_fwd(byref(d), _p(x), _p(wf), _p(b32), act, _p(y), _p(ws), ws.numel() * 4, _stream()),
                     "conv2d_fwd")
         ctx.geom, ctx.act, ctx.cache, ctx.sources, ctx.prec, ctx.per_call = geom, act, cache, sources, prec, per_call
@@ -419,9 +495,7 @@ class _Conv2d(torch.autograd.Function):
         geom, prec, act = ctx.geom, ctx.prec, ctx.act
         lib = _lib_for(x)
         dy = dy.contiguous()
-        n, h, w, cins = x.shape
         couts = dy.shape[-1]
-        d = _desc(prec, geom, n, h, w, cins, couts)
         st = _stream()
         if act != L.ACT_NONE:
             g = torch.empty_like(dy)
@@ -430,36 +504,24 @@ class _Conv2d(torch.autograd.Function):
             g = dy
         dx = dw = db = None
         if _wants_grad(ctx, 0):
-            _, wd = ctx.cache.get(weight, ctx.sources, prec, geom, cins, couts, need_dgrad=True, need_fwd=False,
-                                  per_call=ctx.per_call)
-            ws = _workspace(x.device, lib.dei2i_conv2d_workspace_bytes(byref(d)))
-            dx = torch.empty_like(x)
-            ext = None
-            if (geom.reflect and geom.pad > 0) or geom.up:           # the dgrad frame differs from the input: scratch
-                oh, ow = c_int(), c_int()
-                lib.dei2i_conv2d_dgrad_shape(byref(d), byref(oh), byref(ow))
-                ext = _workspace(x.device, n * oh.value * ow.value * cins * x.element_size(), slot="dgrad_frame")
-            L.check(lib.dei2i_conv2d_dgrad_input(byref(d), _p(g), _p(wd), _p(ext), _p(dx), _p(ws), ws.numel() * 4, st),
-                    "conv2d_dgrad_input")
+            dx = _conv_dgrad(lib, prec, geom, tuple(x.shape), couts, g, weight, ctx.cache, ctx.sources, ctx.per_call, x.dtype, x.device)
         if _wants_grad(ctx, 1):
-            packed = lib.dei2i_wgrad_slab_elems(byref(d))
-            # partial slabs: up to 64, or as many as fit 96 MB (a (co, ci, 9-tap) register block per CU is 256 x 295 KB)
-            scratch = _workspace(x.device, max(packed * 4, min(max(packed * 4 * 64, 96 << 20), 512 << 20)), slot="wgrad")
-            dw, dw_ptr, accumulate = _grad_target(weight, weight.shape, x.device)
-            L.check(lib.dei2i_conv2d_wgrad_oihw(byref(d), _p(x), _p(g), _p(scratch), scratch.numel(), c_void_p(dw_ptr), accumulate,
-                                                st), "conv2d_wgrad")
+            dw = _conv_wgrad(lib, prec, geom, x, g, weight)
         if ctx.has_bias and _wants_grad(ctx, 2):
             dbf = torch.empty(couts, dtype=torch.float32, device=x.device)
             rows = g.numel() // couts
             part = torch.empty(lib.dei2i_colsum_blocks(rows) * couts, dtype=torch.float32, device=x.device)
             L.check(lib.dei2i_colsum(prec.code, rows, couts, _p(g), _p(part), _p(dbf), st), "colsum")
             db = dbf if couts == geom.cout else dbf[:geom.cout].clone()
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
-def conv2d(x, weight, bias, cache: PackedWeights, geom: ConvGeom, act="none", sources=None):
-    """y = act(conv(x) + bias) on an NHWC activation; ``weight`` is the reference's OIHW fp32 parameter."""
-    return _Conv2d.apply(x, weight, bias, cache, tuple(sources) if sources is not None else (weight,), geom, ACT[act])
+def conv2d(x, weight, bias, cache: PackedWeights, geom: ConvGeom, act="none", sources=None, stats=False):
+    """y = act(conv(x) + bias) on an NHWC activation; ``weight`` is the reference's OIHW fp32 parameter.  ``stats``: a
+    BatchNorm / InstanceNorm follows -- leave the statistics records of y with it when the kernel can (see _stats_of)."""
+    del _stats_stash[:]
+    return _attach_stats(_Conv2d.apply(x, weight, bias, cache, tuple(sources) if sources is not None else (weight,), geom,
+                                       ACT[act], bool(stats)))
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -526,10 +588,94 @@ def to_nchw(x_nhwc, c: int):
 # --------------------------------------------------------------------------------------------------------------
 # BatchNorm2d (+ LeakyReLU) (+ residual)
 # --------------------------------------------------------------------------------------------------------------
+def _bn_coefs(lib, y, prec, weight, bias, running_mean, running_var, training, momentum, eps, num_batches_tracked):
+    """BatchNorm2d statistics + affine coefficients of an NHWC tensor: a[c] = weight * rstd, b[c] = bias - mean * a (batch
+    statistics in training mode, running statistics otherwise; running buffers and the counter are updated in place).
+    The statistics come from the records its producer left (conv epilogue / affine_act_stats) when there are any."""
+    n, h, w, c = y.shape
+    dev, st = y.device, _stream()
+    a = torch.empty(c, dtype=torch.float32, device=dev)
+    b = torch.empty(c, dtype=torch.float32, device=dev)
+    w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+    nf = w32.numel()
+    if nf > c or running_mean.numel() != nf or running_var.numel() != nf:
+        raise ValueError(f"batchnorm_act: {nf} features for a {c}-channel activation")
+    rm, rv = running_mean, running_var
+    if nf < c:
+        # the channel stride is padded to a 16-byte vector (c > num_features: widths that are no multiple of 8 / 4): the
+        # kernels index every per-channel vector up to c, so hand them padded copies -- weight = bias = 0 makes the
+        # padded channels' a = b = 0 (their activations stay zero) -- and copy the live running statistics back
+        def _padded(v, fill):
+            o = torch.full((c,), fill, dtype=torch.float32, device=dev)
+            o[:nf] = v.detach()
+            return o
+        w32, b32, rm, rv = _padded(w32, 0.0), _padded(b32, 0.0), _padded(running_mean, 0.0), _padded(running_var, 1.0)
+    if training:
+        mean = torch.empty(c, dtype=torch.float32, device=dev)
+        rstd = torch.empty(c, dtype=torch.float32, device=dev)
+        have = _stats_of(y, n, h * w, c) if fuse_norm else None
+        if have is not None:
+            partial, chunks = have
+        else:
+            chunks = lib.dei2i_moments_chunks(h * w)
+            partial = torch.empty((n, chunks, 2, c), dtype=torch.float32, device=dev)
+            L.check(lib.dei2i_moments_partial(prec.code, n, h * w, c, _p(y), _p(partial), st), "moments_partial")
+        L.check(lib.dei2i_bn_finalize_train_chunks(n, h * w, c, chunks, _p(partial), _p(w32), _p(b32), _p(rm), _p(rv),
+                                                   momentum, eps, _p(mean), _p(rstd), _p(a), _p(b), _p(num_batches_tracked), st),
+                "bn_finalize_train")
+        if nf < c:
+            running_mean.copy_(rm[:nf])
+            running_var.copy_(rv[:nf])
+    else:
+        L.check(lib.dei2i_bn_finalize_eval(c, _p(w32), _p(b32), _p(rm), _p(rv), eps, _p(a), _p(b), st),
+                "bn_finalize_eval")
+        mean = rm.detach().clone()
+        rstd = torch.rsqrt(rv.detach() + eps)
+    return a, b, mean, rstd, nf
+
+
+def _bn_backward(lib, prec, dout, y, a, b, mean, rstd, act, training, weight, bias, nf):
+    """-> (dy, dweight, dbias) of z = act(a*y + b) given dL/dz (csrc/reduce.hip: bn_bwd_partial / bn_bwd_apply)."""
+    st = _stream()
+    dout = dout.contiguous()
+    n, h, w, c = y.shape
+    pixels = n * h * w
+    chunks = lib.dei2i_bn_bwd_chunks(pixels)
+    partial = torch.empty((chunks, 2, c), dtype=torch.float32, device=y.device)
+    L.check(lib.dei2i_bn_bwd_partial(prec.code, pixels, c, _p(dout), _p(y), _p(a), _p(b), _p(mean), _p(rstd), act,
+                                     _p(partial), st), "bn_bwd_partial")
+    padded = nf < c               # padded channel stride: c-sized scratch vectors, sliced to num_features below
+    if padded:
+        tmp_wb = torch.empty((2, c), dtype=torch.float32, device=y.device)
+        dweight = dbias = None
+        dw_ptr, db_ptr, acc_w, acc_b = tmp_wb.data_ptr(), tmp_wb.data_ptr() + 4 * c, 0, 0
+    else:
+        dweight, dw_ptr, acc_w = _grad_target(weight, (c,), y.device)
+        dbias, db_ptr, acc_b = _grad_target(bias, (c,), y.device)
+    acc_ptrs = (None, None)
+    if acc_w or acc_b:            # the kernel needs this call's own sums as well: they go to scratch vectors
+        if not (acc_w and acc_b):
+            # one of the pair lost its first gradient tensor (see _grad_target): give both a fresh tensor
+            dweight = torch.empty((c,), dtype=torch.float32, device=y.device)
+            dbias = torch.empty((c,), dtype=torch.float32, device=y.device)
+            dw_ptr, db_ptr, acc_w, acc_b = dweight.data_ptr(), dbias.data_ptr(), 0, 0
+        else:
+            acc_ptrs = (c_void_p(dw_ptr), c_void_p(db_ptr))
+            tmp = torch.empty((2, c), dtype=torch.float32, device=y.device)
+            dw_ptr, db_ptr = tmp.data_ptr(), tmp.data_ptr() + 4 * c
+    dy = torch.empty_like(y)
+    L.check(lib.dei2i_bn_bwd_apply(prec.code, pixels, c, _p(dout), _p(y), _p(a), _p(b), _p(mean), _p(rstd), act,
+                                   1 if training else 0, _p(partial), chunks, c_void_p(dw_ptr), c_void_p(db_ptr),
+                                   acc_ptrs[0], acc_ptrs[1], _p(dy), st), "bn_bwd_apply")
+    if padded:
+        dweight, dbias = tmp_wb[0, :nf].clone(), tmp_wb[1, :nf].clone()
+    return dy, dweight, dbias
+
+
 class _BatchNormAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, weight, bias, res, running_mean, running_var, training: bool, momentum: float, eps: float, act: int,
-                num_batches_tracked=None):
+                num_batches_tracked=None, want_stats: bool = False):
         _require_gpu(y, "batchnorm_act")
         prec = precision_of(y)
         y = y.contiguous()
@@ -537,45 +683,22 @@ class _BatchNormAct(torch.autograd.Function):
         lib = _lib_for(y)
         st = _stream()
         dev = y.device
-        a = torch.empty(c, dtype=torch.float32, device=dev)
-        b = torch.empty(c, dtype=torch.float32, device=dev)
-        w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
-        nf = w32.numel()
-        if nf > c or running_mean.numel() != nf or running_var.numel() != nf:
-            raise ValueError(f"batchnorm_act: {nf} features for a {c}-channel activation")
-        rm, rv = running_mean, running_var
-        if nf < c:
-            # the channel stride is padded to a 16-byte vector (c > num_features: widths that are no multiple of 8 / 4): the
-            # kernels index every per-channel vector up to c, so hand them padded copies -- weight = bias = 0 makes the
-            # padded channels' a = b = 0 (their activations stay zero) -- and copy the live running statistics back
-            def _padded(v, fill):
-                o = torch.full((c,), fill, dtype=torch.float32, device=dev)
-                o[:nf] = v.detach()
-                return o
-            w32, b32, rm, rv = _padded(w32, 0.0), _padded(b32, 0.0), _padded(running_mean, 0.0), _padded(running_var, 1.0)
-        if training:
-            chunks = lib.dei2i_moments_chunks(h * w)
-            partial = torch.empty((n, chunks, 2, c), dtype=torch.float32, device=dev)
-            mean = torch.empty(c, dtype=torch.float32, device=dev)
-            rstd = torch.empty(c, dtype=torch.float32, device=dev)
-            L.check(lib.dei2i_moments_partial(prec.code, n, h * w, c, _p(y), _p(partial), st), "moments_partial")
-            L.check(lib.dei2i_bn_finalize_train(n, h * w, c, _p(partial), _p(w32), _p(b32), _p(rm), _p(rv),
-                                                momentum, eps, _p(mean), _p(rstd), _p(a), _p(b), _p(num_batches_tracked), st),
-                    "bn_finalize_train")
-            if nf < c:
-                running_mean.copy_(rm[:nf])
-                running_var.copy_(rv[:nf])
-        else:
-            L.check(lib.dei2i_bn_finalize_eval(c, _p(w32), _p(b32), _p(rm), _p(rv), eps, _p(a), _p(b), st),
-                    "bn_finalize_eval")
-            mean = rm.detach().clone()
-            rstd = torch.rsqrt(rv.detach() + eps)
+        a, b, mean, rstd, nf = _bn_coefs(lib, y, prec, weight, bias, running_mean, running_var, training, momentum, eps,
+                                         num_batches_tracked)
         out = torch.empty_like(y)
         if res is not None:
             res = res.contiguous()
         xq = torch.empty(out.numel(), dtype=torch.uint8, device=dev) if _fp8_copy_wanted(prec, c) else None
-        L.check(lib.dei2i_affine_act_fwd(prec.code, n * h * w, c, _p(y), _p(a), _p(b), _p(res), act, _p(out), _p(xq), FP8_ACT_SCALE,
-                                         st), "affine_act")
+        if want_stats and fuse_norm and xq is None:
+            # the statistics records of the output in the same pass (an InstanceNorm / BatchNorm reads this tensor next)
+            chunks = lib.dei2i_moments_chunks(h * w)
+            partial = torch.empty((n, chunks, 2, c), dtype=torch.float32, device=dev)
+            L.check(lib.dei2i_affine_act_stats_fwd(prec.code, n, h * w, c, _p(y), _p(a), _p(b), _p(res), act, _p(out), _p(partial), st),
+                    "affine_act_stats")
+            _stats_stash.append((partial, chunks))
+        else:
+            L.check(lib.dei2i_affine_act_fwd(prec.code, n * h * w, c, _p(y), _p(a), _p(b), _p(res), act, _p(out), _p(xq), FP8_ACT_SCALE,
+                                             st), "affine_act")
         if xq is not None:
             _fp8_stash.append(xq)
         ctx.prec, ctx.act, ctx.training, ctx.has_res = prec, act, training, res is not None
@@ -586,79 +709,153 @@ class _BatchNormAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         y, a, b, mean, rstd = ctx.saved_tensors
-        prec = ctx.prec
-        lib = _lib_for(y)
-        st = _stream()
-        dout = dout.contiguous()
-        n, h, w, c = y.shape
-        pixels = n * h * w
-        chunks = lib.dei2i_bn_bwd_chunks(pixels)
-        partial = torch.empty((chunks, 2, c), dtype=torch.float32, device=y.device)
-        L.check(lib.dei2i_bn_bwd_partial(prec.code, pixels, c, _p(dout), _p(y), _p(a), _p(b), _p(mean), _p(rstd), ctx.act,
-                                         _p(partial), st), "bn_bwd_partial")
         weight, bias = ctx.params
-        padded = ctx.nf < c               # padded channel stride: c-sized scratch vectors, sliced to num_features below
-        if padded:
-            tmp_wb = torch.empty((2, c), dtype=torch.float32, device=y.device)
-            dweight = dbias = None
-            dw_ptr, db_ptr, acc_w, acc_b = tmp_wb.data_ptr(), tmp_wb.data_ptr() + 4 * c, 0, 0
-        else:
-            dweight, dw_ptr, acc_w = _grad_target(weight, (c,), y.device)
-            dbias, db_ptr, acc_b = _grad_target(bias, (c,), y.device)
-        acc_ptrs = (None, None)
-        if acc_w or acc_b:            # the kernel needs this call's own sums as well: they go to scratch vectors
-            if not (acc_w and acc_b):
-                # one of the pair lost its first gradient tensor (see _grad_target): give both a fresh tensor
-                dweight = torch.empty((c,), dtype=torch.float32, device=y.device)
-                dbias = torch.empty((c,), dtype=torch.float32, device=y.device)
-                dw_ptr, db_ptr, acc_w, acc_b = dweight.data_ptr(), dbias.data_ptr(), 0, 0
-            else:
-                acc_ptrs = (c_void_p(dw_ptr), c_void_p(db_ptr))
-                tmp = torch.empty((2, c), dtype=torch.float32, device=y.device)
-                dw_ptr, db_ptr = tmp.data_ptr(), tmp.data_ptr() + 4 * c
-        dy = torch.empty_like(y)
-        L.check(lib.dei2i_bn_bwd_apply(prec.code, pixels, c, _p(dout), _p(y), _p(a), _p(b), _p(mean), _p(rstd), ctx.act,
-                                       1 if ctx.training else 0, _p(partial), chunks, c_void_p(dw_ptr), c_void_p(db_ptr),
-                                       acc_ptrs[0], acc_ptrs[1], _p(dy), st), "bn_bwd_apply")
-        if padded:
-            dweight, dbias = tmp_wb[0, :ctx.nf].clone(), tmp_wb[1, :ctx.nf].clone()
-        return dy, dweight, dbias, (dout if ctx.has_res else None), None, None, None, None, None, None, None
+        dy, dweight, dbias = _bn_backward(_lib_for(y), ctx.prec, dout, y, a, b, mean, rstd, ctx.act, ctx.training, weight, bias, ctx.nf)
+        return dy, dweight, dbias, (dout if ctx.has_res else None), None, None, None, None, None, None, None, None
 
 
 def batchnorm_act(y, weight, bias, running_mean, running_var, training, act="none", res=None, momentum=0.1, eps=1e-5,
-                  num_batches_tracked=None):
-    """num_batches_tracked: the module's int64 counter, incremented inside the statistics kernel in training mode."""
+                  num_batches_tracked=None, stats=False):
+    """num_batches_tracked: the module's int64 counter, incremented inside the statistics kernel in training mode.
+    ``stats``: a norm layer reads the output next -- leave its statistics records with it (see _stats_of)."""
     del _fp8_stash[:]
-    return _attach_fp8(_BatchNormAct.apply(y, weight, bias, res, running_mean, running_var, bool(training), float(momentum),
-                                           float(eps), ACT[act], num_batches_tracked))
+    del _stats_stash[:]
+    return _attach_stats(_attach_fp8(_BatchNormAct.apply(y, weight, bias, res, running_mean, running_var, bool(training),
+                                                         float(momentum), float(eps), ACT[act], num_batches_tracked, bool(stats))))
 
 
-def add(x, res):
-    """x + res on NHWC activations (NormResBlock identity branch, architecture.py:350)."""
+class _BnActConv(torch.autograd.Function):
+    """conv(act(BatchNorm(y1))) with the BatchNorm apply + activation on the conv's operand path (architecture.py:116-118
+    followed by the next block's conv, e.g. the two halves of a ResBlock, architecture.py:139-156): the normalised tensor is
+    never written -- forward, and the weight gradient in backward, re-normalise y1's halo tiles in LDS (ConvPro, csrc/geom.h)."""
+
+    @staticmethod
+    def forward(ctx, y1, bn_w, bn_b, weight, running_mean, running_var, training, momentum, eps, act, num_batches_tracked,
+                cache: PackedWeights, sources, geom: ConvGeom, want_stats):
+        prec = precision_of(y1)
+        y1 = y1.contiguous()
+        n, h, w, c = y1.shape
+        lib = _lib_for(y1)
+        a, b, mean, rstd, nf = _bn_coefs(lib, y1, prec, bn_w, bn_b, running_mean, running_var, training, momentum, eps,
+                                         num_batches_tracked)
+        couts = prec.pad(geom.cout)
+        d = _desc(prec, geom, n, h, w, c, couts)
+        wf = cache.get(weight, sources, prec, geom, c, couts, need_dgrad=any(s_.requires_grad for s_ in sources))[0]
+        ho, wo = c_int(), c_int()
+        lib.dei2i_conv2d_out_shape(byref(d), byref(ho), byref(wo))
+        y = torch.empty((n, ho.value, wo.value, couts), dtype=prec.dtype, device=y1.device)
+        pro = L.ProDesc(a.data_ptr(), b.data_ptr(), 0, 0.2 if act == L.ACT_LRELU else (0.0 if act == L.ACT_RELU else 1.0), None)
+        partial = None
+        if want_stats:
+            chunks = lib.dei2i_conv2d_stats_chunks(byref(d))
+            partial = torch.empty((n, chunks, 2, couts), dtype=torch.float32, device=y1.device)
+            _stats_stash.append((partial, chunks))
+        L.check(lib.dei2i_conv2d_fwd_fused(byref(d), _p(y1), _p(wf), None, L.ACT_NONE, _p(y), byref(pro), _p(partial), _stream()),
+                "conv2d_fwd_fused(bn)")
+        ctx.prec, ctx.act, ctx.training, ctx.nf, ctx.geom = prec, act, training, nf, geom
+        ctx.cache, ctx.sources, ctx.params, ctx.slope = cache, sources, (bn_w, bn_b), pro.slope
+        ctx.save_for_backward(y1, a, b, mean, rstd, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y1, a, b, mean, rstd, weight = ctx.saved_tensors
+        prec, geom = ctx.prec, ctx.geom
+        lib = _lib_for(y1)
+        dy = dy.contiguous()
+        dw = None
+        if _wants_grad(ctx, 3):
+            pro = L.ProDesc(a.data_ptr(), b.data_ptr(), 0, ctx.slope, None)
+            dw = _conv_wgrad(lib, prec, geom, y1, dy, weight, pro)
+        dy1 = dbw = dbb = None
+        if _wants_grad(ctx, 0) or _wants_grad(ctx, 1) or _wants_grad(ctx, 2):
+            dh = _conv_dgrad(lib, prec, geom, tuple(y1.shape), dy.shape[-1], dy, weight, ctx.cache, ctx.sources, False, y1.dtype, y1.device)
+            bn_w, bn_b = ctx.params
+            dy1, dbw, dbb = _bn_backward(lib, prec, dh, y1, a, b, mean, rstd, ctx.act, ctx.training, bn_w, bn_b, ctx.nf)
+        return (dy1, dbw, dbb, dw) + (None,) * 11
+
+
+def bn_act_conv_supported(y1, bn_weight, weight, geom: ConvGeom, need_grad: bool) -> bool:
+    """Can conv(act(BatchNorm(y1))) run with the norm on the conv's operand path?  (bf16, halo-resident forward kernel takes
+    the shape, and -- when gradients are needed -- so does the halo-resident wgrad kernel; plain weights only)"""
+    if not (fuse_norm and fuse_pro and y1.is_cuda and y1.dtype == torch.bfloat16 and not _fp8_forward):
+        return False
+    if getattr(weight, "_dei2i_per_call", False) or bn_weight.numel() != y1.shape[-1]:
+        return False
+    lib = _lib_for(y1)
+    n, h, w, c = y1.shape
+    d = _desc(BF16, geom, n, h, w, c, BF16.pad(geom.cout))
+    if not lib.dei2i_conv2d_fused_supported(byref(d), 1):
+        return False
+    return bool(lib.dei2i_conv2d_wgrad_pro_supported(byref(d))) if need_grad else True
+
+
+def bn_act_conv(y1, bn_weight, bn_bias, running_mean, running_var, training, act, weight, cache, geom, momentum=0.1, eps=1e-5,
+                num_batches_tracked=None, sources=None, stats=False):
+    """conv(act(BatchNorm2d(y1))), the norm + activation fused into the conv (ask bn_act_conv_supported first)."""
+    del _stats_stash[:]
+    return _attach_stats(_BnActConv.apply(y1, bn_weight, bn_bias, weight, running_mean, running_var, bool(training), float(momentum),
+                                          float(eps), ACT[act], num_batches_tracked, cache,
+                                          tuple(sources) if sources is not None else (weight,), geom, bool(stats)))
+
+
+def add(x, res, stats=False):
+    """x + res on NHWC activations (NormResBlock identity branch, architecture.py:350).  ``stats``: a norm layer reads the
+    sum next -- leave its statistics records with it."""
     c = x.shape[-1]
-    return _AffineAdd.apply(x, res, _const_vec(x.device, c, 1.0), _const_vec(x.device, c, 0.0))
+    del _stats_stash[:]
+    return _attach_stats(_AffineAdd.apply(x, res, _const_vec(x.device, c, 1.0), _const_vec(x.device, c, 0.0), bool(stats)))
 
 
 class _AffineAdd(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, res, ones, zeros):
+    def forward(ctx, x, res, ones, zeros, want_stats=False):
         _require_gpu(x, "add")
         prec = precision_of(x)
         x, res = x.contiguous(), res.contiguous()
         out = torch.empty_like(x)
         lib = _lib_for(x)
-        L.check(lib.dei2i_affine_act_fwd(prec.code, x.numel() // x.shape[-1], x.shape[-1], _p(x), _p(ones), _p(zeros), _p(res),
-                                         L.ACT_NONE, _p(out), None, 1.0, _stream()), "add")
+        c = x.shape[-1]
+        if want_stats and fuse_norm and x.dim() == 4:
+            n, hw = x.shape[0], x.shape[1] * x.shape[2]
+            chunks = lib.dei2i_moments_chunks(hw)
+            partial = torch.empty((n, chunks, 2, c), dtype=torch.float32, device=x.device)
+            L.check(lib.dei2i_affine_act_stats_fwd(prec.code, n, hw, c, _p(x), _p(ones), _p(zeros), _p(res), L.ACT_NONE, _p(out),
+                                                   _p(partial), _stream()), "add_stats")
+            _stats_stash.append((partial, chunks))
+        else:
+            L.check(lib.dei2i_affine_act_fwd(prec.code, x.numel() // c, c, _p(x), _p(ones), _p(zeros), _p(res),
+                                             L.ACT_NONE, _p(out), None, 1.0, _stream()), "add")
         return out
 
     @staticmethod
     def backward(ctx, g):
-        return g, g, None, None
+        return g, g, None, None, None
 
 
 # --------------------------------------------------------------------------------------------------------------
 # SPADE (InstanceNorm * (1+gamma) + beta) + ReLU, optional fused nearest x2 upsample of x
 # --------------------------------------------------------------------------------------------------------------
+def _spade_backward(lib, prec, dout, dskip, x, gb, mean, rstd, up, gb_mode, out_shape):
+    """-> (dx, dgb) of z = relu(IN(x)*(1+gamma)+beta) given dL/dz at the (upsampled) output resolution; dskip (optional) is
+    added to dx inside the apply kernel (the res block's identity branch)."""
+    st = _stream()
+    dev = x.device
+    dout = dout.contiguous()
+    n, h, w, c = out_shape
+    chunks = lib.dei2i_moments_chunks(h * w)
+    partial = torch.empty((n, chunks, 4, c), dtype=torch.float32, device=dev)
+    dgb = torch.empty_like(gb)         # dense (N,H,W,2C), or the (N,5,5,2C) class table -- both written in full
+    L.check(lib.dei2i_spade_bwd_partial(prec.code, n, h, w, c, 1 if up else 0, _p(dout), _p(x), _p(mean), _p(rstd),
+                                        _p(gb), gb_mode, _p(dgb), _p(partial), st), "spade_bwd_partial")
+    coef = torch.empty((n, 2, c), dtype=torch.float32, device=dev)
+    dx = torch.empty_like(x)
+    L.check(lib.dei2i_spade_bwd_apply(prec.code, n, h, w, c, 1 if up else 0, _p(dout), _p(x), _p(mean), _p(rstd), _p(gb), gb_mode,
+                                      _p(partial), chunks, _p(dgb) if gb_mode == 1 else None, _p(coef), _p(dskip), _p(dx), st),
+            "spade_bwd_apply")
+    return dx, dgb
+
+
 class _SpadeRelu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gb, up: bool, gb_mode: int, eps: float, skip: bool = False):
@@ -675,11 +872,11 @@ class _SpadeRelu(torch.autograd.Function):
         lib = _lib_for(x)
         st = _stream()
         dev = x.device
-        chunks = lib.dei2i_moments_chunks(hs * ws)
-        partial = torch.empty((n, chunks, 2, c), dtype=torch.float32, device=dev)
         mean = torch.empty((n, c), dtype=torch.float32, device=dev)
         rstd = torch.empty((n, c), dtype=torch.float32, device=dev)
         # statistics of the upsampled tensor == statistics of the source tensor (every pixel replicated 4x)
+        chunks = lib.dei2i_moments_chunks(hs * ws)
+        partial = torch.empty((n, chunks, 2, c), dtype=torch.float32, device=dev)
         L.check(lib.dei2i_moments_partial(prec.code, n, hs * ws, c, _p(x), _p(partial), st), "moments_partial")
         L.check(lib.dei2i_in_finalize(n, hs * ws, c, _p(partial), eps, _p(mean), _p(rstd), st), "in_finalize")
         out = torch.empty((n, h, w, c), dtype=prec.dtype, device=dev)
@@ -702,22 +899,7 @@ class _SpadeRelu(torch.autograd.Function):
             dskip = dskip.contiguous()
             if dskip.dtype != x.dtype or dskip.shape != x.shape:
                 raise RuntimeError("spade_relu: identity-branch gradient does not match the activation")
-        prec, up, gb_mode = ctx.prec, ctx.up, ctx.gb_mode
-        lib = _lib_for(x)
-        st = _stream()
-        dev = x.device
-        dout = dout.contiguous()
-        n, h, w, c = ctx.out_shape
-        chunks = lib.dei2i_moments_chunks(h * w)
-        partial = torch.empty((n, chunks, 4, c), dtype=torch.float32, device=dev)
-        dgb = torch.empty_like(gb)         # dense (N,H,W,2C), or the (N,5,5,2C) class table -- both written in full
-        L.check(lib.dei2i_spade_bwd_partial(prec.code, n, h, w, c, 1 if up else 0, _p(dout), _p(x), _p(mean), _p(rstd),
-                                            _p(gb), gb_mode, _p(dgb), _p(partial), st), "spade_bwd_partial")
-        coef = torch.empty((n, 2, c), dtype=torch.float32, device=dev)
-        dx = torch.empty_like(x)
-        L.check(lib.dei2i_spade_bwd_apply(prec.code, n, h, w, c, 1 if up else 0, _p(dout), _p(x), _p(mean), _p(rstd), _p(gb), gb_mode,
-                                          _p(partial), chunks, _p(dgb) if gb_mode == 1 else None, _p(coef), _p(dskip), _p(dx), st),
-                "spade_bwd_apply")
+        dx, dgb = _spade_backward(_lib_for(x), ctx.prec, dout, dskip, x, gb, mean, rstd, ctx.up, ctx.gb_mode, ctx.out_shape)
         return dx, dgb, None, None, None, None
 
 
@@ -728,6 +910,108 @@ def spade_relu(x, gb, up: bool, gb_mode: int, eps: float = 1e-5, skip: bool = Fa
         out, xs = _SpadeRelu.apply(x, gb, bool(up), int(gb_mode), float(eps), True)
         return _attach_fp8(out), xs
     return _attach_fp8(_SpadeRelu.apply(x, gb, bool(up), int(gb_mode), float(eps)))
+
+
+class _SpadeConv(torch.autograd.Function):
+    """conv(relu(SPADE(up(x)))) -- architecture.py:241-245 (NormConvBlock) and :343-350 (NormResBlock) with
+    normalization.py:24-37 -- for the constant-label-map case (class table, gb_mode 1), the InstanceNorm apply + modulate +
+    ReLU (+ nearest x2 upsample) on the conv's operand path: one small preparation kernel (statistics finalize, interior
+    coefficients, the 2-pixel frame's values) and the conv; the normalised tensor is never written.  Backward: the input
+    gradient of the conv at the logical resolution, the weight gradient with the same operand-path transform, then the
+    SPADE backward kernels of the unfused op."""
+
+    @staticmethod
+    def forward(ctx, x, gb, weight, up, eps, skip, cache: PackedWeights, sources, geom: ConvGeom, want_stats):
+        prec = precision_of(x)
+        x_in = x
+        x, gb = x.contiguous(), gb.contiguous()
+        if skip and (up or x is not x_in):
+            raise ValueError("spade_conv(skip=True) wants a contiguous activation and no upsample")
+        n, hs, ws, c = x.shape
+        h, w = (hs * 2, ws * 2) if up else (hs, ws)
+        lib = _lib_for(x)
+        st = _stream()
+        dev = x.device
+        have = _stats_of(x, n, hs * ws, c)
+        if have is not None:
+            partial, chunks = have
+        else:
+            chunks = lib.dei2i_moments_chunks(hs * ws)
+            partial = torch.empty((n, chunks, 2, c), dtype=torch.float32, device=dev)
+            L.check(lib.dei2i_moments_partial(prec.code, n, hs * ws, c, _p(x), _p(partial), st), "moments_partial")
+        coefs = torch.empty((4, n, c), dtype=torch.float32, device=dev)          # mean | rstd | A | B
+        ring = torch.empty((n, lib.dei2i_ring_pixels(h, w), c), dtype=prec.dtype, device=dev)
+        L.check(lib.dei2i_spade_prep(prec.code, n, hs, ws, c, 1 if up else 0, _p(x), _p(partial), chunks, eps, _p(gb),
+                                     _p(coefs[0]), _p(coefs[1]), _p(coefs[2]), _p(coefs[3]), _p(ring), st), "spade_prep")
+        couts = prec.pad(geom.cout)
+        d = _desc(prec, geom, n, hs, ws, c, couts)
+        wf = cache.get(weight, sources, prec, geom, c, couts, need_dgrad=any(s_.requires_grad for s_ in sources))[0]
+        y = torch.empty((n, h, w, couts), dtype=prec.dtype, device=dev)
+        pro = L.ProDesc(coefs[2].data_ptr(), coefs[3].data_ptr(), c, 0.0, ring.data_ptr())
+        out_partial = None
+        if want_stats:
+            ochunks = lib.dei2i_conv2d_stats_chunks(byref(d))
+            out_partial = torch.empty((n, ochunks, 2, couts), dtype=torch.float32, device=dev)
+            _stats_stash.append((out_partial, ochunks))
+        L.check(lib.dei2i_conv2d_fwd_fused(byref(d), _p(x), _p(wf), None, L.ACT_NONE, _p(y), byref(pro), _p(out_partial), st),
+                "conv2d_fwd_fused(spade)")
+        ctx.prec, ctx.up, ctx.geom, ctx.cache, ctx.sources = prec, up, geom, cache, sources
+        ctx.out_shape = (n, h, w, c)
+        ctx.save_for_backward(x, gb, coefs, ring, weight)
+        return (y, x_in) if skip else y
+
+    @staticmethod
+    def backward(ctx, dy, dskip=None):
+        x, gb, coefs, ring, weight = ctx.saved_tensors
+        prec, geom, up = ctx.prec, ctx.geom, ctx.up
+        if dy is None:                                   # only the identity branch was used
+            return (dskip,) + (None,) * 9
+        lib = _lib_for(x)
+        dy = dy.contiguous()
+        n, h, w, c = ctx.out_shape
+        if dskip is not None:
+            dskip = dskip.contiguous()
+            if dskip.dtype != x.dtype or dskip.shape != x.shape:
+                raise RuntimeError("spade_conv: identity-branch gradient does not match the activation")
+        dw = None
+        if _wants_grad(ctx, 2):
+            pro = L.ProDesc(coefs[2].data_ptr(), coefs[3].data_ptr(), c, 0.0, ring.data_ptr())
+            dw = _conv_wgrad(lib, prec, geom, x, dy, weight, pro)
+        dx = dgb = None
+        if _wants_grad(ctx, 0) or _wants_grad(ctx, 1):
+            # dL/dz at the LOGICAL (upsampled) resolution: the conv seen as a plain conv on z (the SPADE backward sums the
+            # 2x2 cells itself, and needs the per-logical-pixel mask and class)
+            g_log = ConvGeom(geom.cin, geom.cout, geom.k, geom.stride, geom.pad, geom.reflect, False)
+            dz = _conv_dgrad(lib, prec, g_log, (n, h, w, c), dy.shape[-1], dy, weight, ctx.cache, ctx.sources, False, x.dtype, x.device)
+            dx, dgb = _spade_backward(lib, prec, dz, dskip, x, gb, coefs[0], coefs[1], up, 1, ctx.out_shape)
+        elif dskip is not None:
+            dx = dskip
+        return (dx, dgb, dw) + (None,) * 7
+
+
+def spade_conv_supported(x, weight, geom: ConvGeom, need_grad: bool) -> bool:
+    """Can conv(relu(SPADE(up(x)))) run with the norm on the conv's operand path?  ``geom`` carries the upsample flag."""
+    if not (fuse_norm and fuse_pro and x.is_cuda and x.dtype == torch.bfloat16 and not _fp8_forward):
+        return False
+    if getattr(weight, "_dei2i_per_call", False):
+        return False
+    lib = _lib_for(x)
+    n, hs, ws, c = x.shape
+    d = _desc(BF16, geom, n, hs, ws, c, BF16.pad(geom.cout))
+    if not lib.dei2i_conv2d_fused_supported(byref(d), 1):
+        return False
+    return bool(lib.dei2i_conv2d_wgrad_pro_supported(byref(d))) if need_grad else True
+
+
+def spade_conv(x, gb, weight, cache, geom: ConvGeom, eps: float = 1e-5, skip: bool = False, sources=None, stats=False):
+    """conv(relu(IN(up(x)) * (1 + gamma) + beta)) with the class table ``gb`` (N,5,5,2C); ``geom.up`` = nearest x2 upsample in
+    front of the norm.  With ``skip`` -> (y, x).  Ask spade_conv_supported first."""
+    del _stats_stash[:]
+    src = tuple(sources) if sources is not None else (weight,)
+    if skip:
+        y, xs = _SpadeConv.apply(x, gb, weight, bool(geom.up), float(eps), True, cache, src, geom, bool(stats))
+        return _attach_stats(y), xs
+    return _attach_stats(_SpadeConv.apply(x, gb, weight, bool(geom.up), float(eps), False, cache, src, geom, bool(stats)))
 
 
 # --------------------------------------------------------------------------------------------------------------

@@ -239,10 +239,52 @@ int dei2i_prof_enable(int family, int on);
 /* synchronises the recorded events; returns launches, total ms and total algorithmic FLOPs since enable */
 int dei2i_prof_collect(int family, int64_t* launches, double* total_ms, double* total_flops);
 
+/* ---- fused conv + norm + act (BASELINE.json configs[1]; SURVEY.md Appendix B groups G3..G16) -------------------------
+ * The normalisation + activation that the reference applies BETWEEN two convs (architecture.py:116-118: conv -> BatchNorm
+ * -> LeakyReLU; architecture.py:241-245,343-350 with normalization.py:24-37: SPADE's InstanceNorm * (1+gamma) + beta ->
+ * ReLU -> conv) runs inside the halo-resident conv kernels:
+ *   - `stats` (epilogue): per-channel sum / sum of squares of the conv's stored output, one record per 8x32-pixel tile,
+ *     (N, dei2i_conv2d_stats_chunks, 2, CoutS) fp32 -- the dei2i_moments_partial layout, consumed by the finalize kernels;
+ *   - `pro` (operand path): the conv's INPUT is z = act(A[n*n_stride + c] * x + B[...]), act(v) = max(v,0) + slope*min(v,0),
+ *     applied to the input halo in LDS; z is never written to memory.  BatchNorm: A = a, B = b of dei2i_bn_finalize_*,
+ *     n_stride = 0, slope = 0.2.  SPADE on a constant label map: A, B, ring from dei2i_spade_prep, n_stride = CinS,
+ *     slope = 0; `ring` holds z of the logical input's 2-pixel frame (whose gamma / beta differ per pixel),
+ *     [N][dei2i_ring_pixels(H<<up, W<<up)][CinS] in the compute dtype.
+ * bf16, 3x3, stride 1, pad 1 only; no fallback inside: ask dei2i_conv2d_fused_supported / _wgrad_pro_supported first. */
+typedef struct dei2i_pro {
+  const float* A;
+  const float* B;
+  int n_stride;
+  float slope;
+  const void* ring;
+} dei2i_pro;
+int dei2i_conv2d_fused_supported(const dei2i_conv* c, int want_pro);          /* 1 / 0 */
+int dei2i_conv2d_stats_chunks(const dei2i_conv* c);                           /* records per image written to `stats` */
+int dei2i_conv2d_fwd_fused(const dei2i_conv* c, const void* x, const void* w_packed, const float* bias, int act, void* y,
+                           const dei2i_pro* pro, float* stats, dei2i_stream s);   /* pro, stats: either may be NULL */
+int dei2i_conv2d_wgrad_pro_supported(const dei2i_conv* c);
+/* dei2i_conv2d_wgrad_oihw for a conv whose input was normalised on the operand path: x is the UN-normalised tensor */
+int dei2i_conv2d_wgrad_oihw_pro(const dei2i_conv* c, const void* x, const void* dy, float* scratch, size_t scratch_elems,
+                                float* dw_oihw, int accumulate, const dei2i_pro* pro, dei2i_stream s);
+size_t dei2i_ring_pixels(int H, int W);                                        /* 4*W + 4*(H-4) */
+/* InstanceNorm finalize + SPADE coefficient preparation in one launch: mean / rstd (N,C) from the partial records (`chunks`
+ * per image, HW = Hs*Ws pixels each image), A = rstd*(1+gamma_int), B = beta_int - mean*A for the interior class of the
+ * (N,5,5,2C) table, and (ring != NULL) relu(IN(x)*(1+gamma)+beta) of the 2-pixel frame of the (Hs<<up, Ws<<up) image */
+int dei2i_spade_prep(int dtype, int N, int Hs, int Ws, int C, int up, const void* x, const float* partial, int chunks, float eps,
+                     const void* gb_table, float* mean, float* rstd, float* A, float* B, void* ring, dei2i_stream s);
+/* dei2i_bn_finalize_train with an explicit record count per image (records written by a conv epilogue) */
+int dei2i_bn_finalize_train_chunks(int N, int HW, int C, int chunks, const float* partial, const float* weight, const float* bias,
+                                   float* running_mean, float* running_var, float momentum, float eps, float* mean, float* rstd,
+                                   float* a, float* b, long long* num_batches_tracked, dei2i_stream s);
+/* dei2i_affine_act_fwd that also writes the statistics records of its output: partial (N, dei2i_moments_chunks(HW), 2, C) */
+int dei2i_affine_act_stats_fwd(int dtype, int N, int HW, int C, const void* x, const float* a, const float* b, const void* res,
+                               int act, void* out, float* partial, dei2i_stream s);
+
 /* ---- which kernel served a call: host-side launch counters per MFMA kernel family (tests assert the family, so a
  * fall-through from a tuned kernel to the generic GEMM cannot pass unnoticed).  dei2i_launch_counts copies up to n
  * counters and returns how many families exist; dei2i_kernel_name(i) names family i ("halo_conv", "gather_v2",
- * "gather_v1", "thin_cin", "thin_cout", "wgrad_halo", "wgrad_v2", "wgrad_v1", "wgrad_thin", "halo_conv_fp8"). */
+ * "gather_v1", "thin_cin", "thin_cout", "wgrad_halo", "wgrad_v2", "wgrad_v1", "wgrad_thin", "halo_conv_fp8",
+ * "halo16_conv"). */
 int dei2i_launch_counts(int64_t* out, int n);
 void dei2i_launch_counts_reset(void);
 const char* dei2i_kernel_name(int kid);

@@ -1,0 +1,255 @@
+"""Fused conv + norm + act (BASELINE.json configs[1]: "fused conv+InstanceNorm+act HIP kernels"):
+
+  * statistics of a conv's output from the halo conv's epilogue (no separate moments pass);
+  * BatchNorm apply + LeakyReLU (architecture.py:116-118) and SPADE's InstanceNorm * (1+gamma) + beta + ReLU (+ nearest x2
+    upsample; normalization.py:24-37, architecture.py:241-245,343-350) on the NEXT conv's operand path, forward and in the
+    weight gradient -- the normalised tensor is never written.
+
+Checked (a) against the oracle's functions in float64 on bf16-rounded operands, and (b) against this build's own unfused
+formulation (ops.fuse_norm = False) on the same inputs, where everything except the position of one bf16 rounding is
+the same arithmetic."""
+import math
+
+import pytest
+import torch
+
+from helpers import make_opt
+from oracle import defectgan_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture()
+def ops():
+    from de_i2i_gan_amd import ops as _ops
+    keep = (_ops.fuse_norm, _ops.fuse_pro)
+    _ops.fuse_norm, _ops.fuse_pro = True, True          # the operand-path fusion is off by default (ops.py: measured slower)
+    yield _ops
+    _ops.fuse_norm, _ops.fuse_pro = keep
+
+
+def _counts(reset=True):
+    from de_i2i_gan_amd import _lib
+    return {k: v for k, v in _lib.launch_counts(reset=reset).items() if v}
+
+
+def maxrel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def nhwc(t, cs=None):
+    n, c, h, w = t.shape
+    out = torch.zeros(n, h, w, cs or c, dtype=t.dtype)
+    out[..., :c] = t.permute(0, 2, 3, 1)
+    return out
+
+
+@pytest.mark.parametrize("cin,cout,H,W,N,up,act", [(128, 128, 64, 64, 8, False, "none"), (64, 64, 64, 128, 8, False, "leaky_relu"),
+                                                    (64, 136, 32, 64, 16, False, "none"), (128, 64, 32, 32, 16, True, "none"),
+                                                    # 16 x 32 tile kernel (conv_halo16.hip): two 8 x 32 records per tile
+                                                    (64, 128, 64, 64, 32, False, "none"), (128, 64, 64, 64, 16, True, "leaky_relu")])
+def test_conv_epilogue_statistics_equal_the_stored_outputs_moments(ops, cin, cout, H, W, N, up, act):
+    torch.manual_seed(3)
+    x = torch.randn(N, H, W, cin, device=DEV).bfloat16()
+    w = torch.randn(cout, cin, 3, 3, device=DEV) * math.sqrt(2.0 / (cin * 9))
+    geom = ops.ConvGeom(cin, cout, 3, 1, 1, True, up)
+    _counts()
+    y = ops.conv2d(x, w, None, ops.PackedWeights(), geom, act, stats=True)
+    fam = _counts()
+    big = N * ((H << up) // 16) * ((W << up) // 32) * max(1, (cout + 127) // 128 if cout >= 128 else 1) >= 224
+    assert fam == ({"halo16_conv": 1} if big else {"halo_conv": 1}), fam
+    partial, chunks = y._dei2i_stats
+    assert partial.shape == (N, chunks, 2, y.shape[-1])
+    yf = y.float()
+    s0, s1 = yf.sum(dim=(1, 2)), (yf * yf).sum(dim=(1, 2))
+    got = partial.double().sum(dim=1)
+    assert maxrel(got[:, 0], s0) < 1e-4 and maxrel(got[:, 1], s1) < 1e-5
+    ops.fuse_norm = False                      # and the output itself is the plain kernel's
+    y0 = ops.conv2d(x, w, None, ops.PackedWeights(), geom, act, stats=True)
+    assert not hasattr(y0, "_dei2i_stats") and torch.equal(y0, y)
+
+
+@pytest.mark.parametrize("C,cout,H,W,N,training", [(128, 128, 64, 64, 8, True), (128, 64, 64, 64, 16, True), (256, 128, 32, 64, 16, False)])
+def test_bn_act_conv_fused(ops, C, cout, H, W, N, training):
+    """conv(LeakyReLU(BatchNorm(y1))): fused against the oracle (float64, rounded operands) and against the unfused kernels."""
+    prec = ops.BF16
+    torch.manual_seed(5)
+    y1 = (torch.randn(N, C, H, W) * 1.5 + 0.3).bfloat16().float()
+    w = (torch.randn(cout, C, 3, 3) * math.sqrt(2.0 / (C * 9))).bfloat16().float()
+    bn_w, bn_b = 1 + 0.2 * torch.randn(C), 0.1 * torch.randn(C)
+    rm0, rv0 = 0.1 * torch.randn(C), 1 + 0.1 * torch.rand(C)
+    gy = torch.randn(N, cout, H, W).bfloat16().float()
+    S = {"bn.weight": bn_w.double().requires_grad_(True), "bn.bias": bn_b.double().requires_grad_(True),
+         "bn.running_mean": rm0.double().clone(), "bn.running_var": rv0.double().clone(),
+         "bn.num_batches_tracked": torch.zeros((), dtype=torch.long)}
+    yr, wr = y1.double().requires_grad_(True), w.double().requires_grad_(True)
+    h_ref = O.leaky_relu(O.batchnorm(S, "bn", yr, training))
+    out_ref = O.conv2d(h_ref, wr, stride=1, pad=1, mode="reflect")
+    g_ref = torch.autograd.grad(out_ref, [yr, wr, S["bn.weight"], S["bn.bias"]], gy.double())
+
+    geom = ops.ConvGeom(C, cout, 3, 1, 1, True, False)
+    res = {}
+    for fused in (True, False):
+        ops.fuse_norm = fused
+        yg = nhwc(y1).to(DEV).bfloat16().requires_grad_(True)
+        wg = w.to(DEV).requires_grad_(True)
+        bw, bb = bn_w.to(DEV).requires_grad_(True), bn_b.to(DEV).requires_grad_(True)
+        rm, rv = rm0.to(DEV), rv0.to(DEV)
+        cache = ops.PackedWeights()
+        _counts()
+        if fused:
+            assert ops.bn_act_conv_supported(yg, bw, wg, geom, True)
+            out = ops.bn_act_conv(yg, bw, bb, rm, rv, training, "leaky_relu", wg, cache, geom, stats=True)
+            assert hasattr(out, "_dei2i_stats")
+        else:
+            out = ops.conv2d(ops.batchnorm_act(yg, bw, bb, rm, rv, training, "leaky_relu"), wg, None, cache, geom)
+        c_fwd = _counts()
+        out.backward(nhwc(gy).to(DEV).bfloat16())
+        c_bwd = _counts()
+        res[fused] = (out.detach(), yg.grad, wg.grad, bw.grad, bb.grad, rm, rv, c_fwd, c_bwd)
+    f, u = res[True], res[False]
+    assert f[7] == {"halo_conv": 1} and u[7] == {"halo_conv": 1}
+    assert f[8].get("wgrad_halo") == 1 and f[8].get("halo_conv") == 1
+    # against the oracle: bf16 tolerances of the op tests (the intermediate h is rounded to bf16 once, like in the unfused path)
+    assert maxrel(ops.to_nchw(f[0], cout), out_ref) < 1.5e-2 and rel_l2(ops.to_nchw(f[0], cout), out_ref) < 4e-3
+    assert rel_l2(ops.to_nchw(f[1], C), g_ref[0]) < 1e-2                   # LeakyReLU kinks: relative L2
+    assert rel_l2(f[2], g_ref[1]) < 5e-3 and rel_l2(f[3], g_ref[2]) < 1e-2 and rel_l2(f[4], g_ref[3]) < 1e-2
+    if training:
+        assert maxrel(f[5], S["bn.running_mean"]) < 5e-3 and maxrel(f[6], S["bn.running_var"]) < 5e-3
+    # against the unfused kernels: the same arithmetic on the same rounded intermediate -> (near) bit-identical
+    for a, b, nm in zip(f[:7], u[:7], ("y", "dy1", "dw", "dbn_w", "dbn_b", "running_mean", "running_var")):
+        assert maxrel(a, b) < 1e-5, nm
+
+
+@pytest.mark.parametrize("C,cout,hs,ws,N,up,skip", [(128, 128, 64, 64, 8, False, True), (256, 128, 32, 32, 16, True, False),
+                                                     (128, 64, 64, 64, 8, True, False), (64, 128, 64, 64, 16, False, False),
+                                                     (128, 128, 16, 32, 64, False, False)])
+def test_spade_conv_fused(ops, C, cout, hs, ws, N, up, skip):
+    """conv(ReLU(SPADE(up(x)))) on a constant label map through the product modules: fused against the oracle (float64,
+    rounded operands) and against the unfused kernels (same inputs)."""
+    from de_i2i_gan_amd.networks.architecture import SPADE, Conv2d
+    prec = ops.BF16
+    torch.manual_seed(7)
+    label_nc, hidden = 6, 32
+    x = (torch.randn(N, C, hs, ws) * 1.3 + 0.2).bfloat16().float()
+    seg = torch.zeros(N, label_nc, 1, 1)
+    for i in range(N):
+        seg[i, 1 + i % 5] = 1
+    mod = SPADE(label_nc, C, hidden_nc=hidden, kernel_size=(3, 3), padding="same")
+    conv = Conv2d(C, cout, 3, padding="same", padding_mode="reflect", bias=False)
+    S = {}
+    with torch.no_grad():
+        for k_, p in mod.named_parameters():
+            p.copy_(O.formula_tensor("spade." + k_, tuple(p.shape)) * (3.0 if p.dim() == 4 else 1.0))
+            S["sp." + k_] = (p.detach().clone().bfloat16().float() if p.dim() == 4 else p.detach().clone()).double().requires_grad_(True)
+        conv.weight.copy_((torch.randn(cout, C, 3, 3) * math.sqrt(2.0 / (C * 9))).bfloat16().float())
+    mod, conv = mod.to(DEV), conv.to(DEV)
+    h, w = (2 * hs, 2 * ws) if up else (hs, ws)
+    gy = torch.randn(N, cout, h, w).bfloat16().float()
+    gs = torch.randn(N, C, hs, ws).bfloat16().float()
+    # ---- oracle ----
+    xr = x.double().requires_grad_(True)
+    wr = conv.weight.detach().cpu().double().requires_grad_(True)
+    z_ref = torch.relu(O.spade(S, "sp", O.upsample2x(xr) if up else xr, seg.double()))
+    out_ref = O.conv2d(z_ref, wr, stride=1, pad=1, mode="reflect")
+    loss = (out_ref * gy.double()).sum() + ((xr * gs.double()).sum() if skip else 0.0)
+    keys = list(S)
+    g_ref = torch.autograd.grad(loss, [xr, wr] + [S[k_] for k_ in keys])
+    # ---- product: fused and unfused ----
+    res = {}
+    for fused in (True, False):
+        ops.fuse_norm = fused
+        for p in list(mod.parameters()) + list(conv.parameters()):
+            p.grad = None
+        mod._gb_cache.clear()
+        xg = nhwc(x).to(DEV).bfloat16().requires_grad_(True)
+        _counts()
+        if skip:
+            out, xs = mod.fused_conv(xg, seg.to(DEV), conv, up=up, skip=True)
+            assert xs.data_ptr() == xg.data_ptr()
+        else:
+            out, xs = mod.fused_conv(xg, seg.to(DEV), conv, up=up), None
+        c_fwd = _counts()
+        if skip:
+            torch.autograd.backward([out, xs], [nhwc(gy).to(DEV).bfloat16(), nhwc(gs).to(DEV).bfloat16()])
+        else:
+            out.backward(nhwc(gy).to(DEV).bfloat16())
+        res[fused] = (out.detach(), xg.grad, conv.weight.grad.clone(), {k_: p.grad.clone() for k_, p in mod.named_parameters()}, c_fwd)
+    f, u = res[True], res[False]
+    assert f[4].get("halo_conv") == 1, f[4]
+    m = {"y_vs_oracle": (maxrel(ops.to_nchw(f[0], cout), out_ref), rel_l2(ops.to_nchw(f[0], cout), out_ref)),
+         "dx_vs_oracle": rel_l2(ops.to_nchw(f[1], C), g_ref[0]), "dx_unfused_vs_oracle": rel_l2(ops.to_nchw(u[1], C), g_ref[0]),
+         "dw_vs_oracle": rel_l2(f[2], g_ref[1]), "dw_unfused_vs_oracle": rel_l2(u[2], g_ref[1]),
+         "params_vs_oracle": {k_: rel_l2(f[3][k_[3:]], gref) for k_, gref in zip(keys, g_ref[2:])},
+         "y_vs_unfused": rel_l2(f[0], u[0]), "dx_vs_unfused": rel_l2(f[1], u[1]), "dw_vs_unfused": rel_l2(f[2], u[2]),
+         "params_vs_unfused": {k_: rel_l2(f[3][k_], u[3][k_]) for k_ in f[3]}}
+    import json, os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/spade_conv_fused_{C}_{cout}_{hs}_{int(up)}.json", "w") as fh:
+        json.dump(m, fh, indent=1)
+    tol = 1.5e-2 * 3                               # the op tests' SPADE bound: gamma / beta / actv are bf16 intermediates too
+    assert m["y_vs_oracle"][0] < tol and m["y_vs_oracle"][1] < 1.5e-2, m
+    # InstanceNorm's backward subtracts means: the bf16 rounding of dz is amplified by the cancellation (the unfused kernels
+    # sit at the same distance from the float64 reference -- recorded above -- and 1e-2 from the fused ones)
+    assert m["dx_vs_oracle"] < 5e-2 and m["dx_vs_oracle"] < 1.3 * m["dx_unfused_vs_oracle"] + 2e-3, m
+    assert m["dw_vs_oracle"] < 1.5e-2, m
+    for k_, v in m["params_vs_oracle"].items():
+        # the label path's intermediates (actv, the gamma | beta table and its gradient) are bf16 tensors: a few ReLU masks of
+        # actv flip against the float64 reference (measured up to 9.4e-2 on mlp_shared.bias, the end of that chain, identically for the unfused kernels)
+        assert v < 0.12, (k_, m)
+    # against the unfused kernels: identical up to the position of one rounding (A*x + B vs ((x-m)*r)*(1+gamma) + beta)
+    assert m["y_vs_unfused"] < 2e-3 and m["dx_vs_unfused"] < 1e-2 and m["dw_vs_unfused"] < 2e-3, m
+    for k_, v in m["params_vs_unfused"].items():
+        assert v < 2e-2, (k_, m)
+
+
+def test_generator_and_both_loss_graphs_fused_equal_unfused_at_256_batch_4(ops):
+    """The whole model at 256x256 (default widths), batch 4 -- the smallest batch at which the 64x64 res-block convs reach
+    the halo-resident kernels: fused and unfused builds of the same step agree on the losses to 2e-4 and on every
+    gradient to cosine 0.999 (one bf16 rounding moves in each fused SPADE)."""
+    from de_i2i_gan_amd.trainers.defectgan_trainer import DefectGanTrainer
+    c = dict(image_size=256, batch=4, num_layers=5, ngf=64, ndf=64, hidden_nc=128)
+    bg, labels, df = O.synthetic_batch(4, 256)
+    res = {}
+    for fused in (True, False):
+        ops.fuse_norm = fused
+        torch.manual_seed(123)
+        tr = DefectGanTrainer(make_opt(c, DEV, "bf16"))
+        G, D = tr.model.netG, tr.model.netD
+        _counts()
+        g1, c1 = tr.model("discriminator", bg, labels, df)
+        (g1 + 2 * c1).backward()
+        dgr = torch.cat([p.grad.double().flatten() for p in D.parameters()])
+        for p in D.parameters():
+            p.grad = None
+        ls = tr.model("generator", bg, labels, df)
+        (ls[0] + 5 * ls[1] + 5 * ls[2] + 5 * ls[3] + ls[4]).backward()
+        ggr = {k: p.grad.double().flatten().cpu() for k, p in G.named_parameters() if p.grad is not None}
+        bufs = {k: v.double().cpu() for k, v in G.state_dict().items() if "running" in k}
+        res[fused] = ([float(g1.detach()), float(c1.detach())] + [float(v.detach()) for v in ls], dgr.cpu(), ggr, bufs)
+        del tr
+    f, u = res[True], res[False]
+    full_f = torch.cat([f[2][k] for k in u[2]])
+    full_u = torch.cat([u[2][k] for k in u[2]])
+    cosv = lambda a, b: float(torch.dot(a, b) / (a.norm() * b.norm()))     # noqa: E731
+    per = {k: cosv(f[2][k], u[2][k]) for k in u[2] if float(u[2][k].norm()) > 1e-3 * float(full_u.norm())}
+    m = {"losses_fused": f[0], "losses_unfused": u[0], "D_cos": cosv(f[1], u[1]), "G_cos": cosv(full_f, full_u),
+         "G_worst_param_cos": min(per.values()), "running_stats_maxrel": max(maxrel(f[3][k], u[3][k]) for k in u[3])}
+    import json, os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/fused_vs_unfused_256x4.json", "w") as fh:
+        json.dump(m, fh, indent=1)
+    # one bf16 rounding moves in each fused SPADE (A*x + B instead of ((x - m) * r) * (1 + gamma) + beta), i.e. a 2^-9 perturbation
+    # of a few activations per layer; the gradients then differ like bf16 differs from f32 (tests/test_hot_shapes_gpu.py:
+    # ReLU masks within rounding of 0 flip), the losses and forward statistics by 1e-4
+    for a, b in zip(f[0], u[0]):
+        assert abs(a - b) <= 5e-4 * max(abs(b), 1e-3), m
+    assert m["D_cos"] > 0.9995 and m["G_cos"] > 0.999 and m["G_worst_param_cos"] > 0.95, m
+    assert m["running_stats_maxrel"] < 2e-3, m

@@ -57,11 +57,12 @@ def maxrel(a, b):
 # DESIGN.md as open): D's first-conv dgrad (64 -> 3 channels, stride 2), the wgrads of the 64-channel-input stride-2 convs
 # and of D's first and last conv, D's last conv forward (M = 1024 rows: split-K generic GEMM).
 R, V2, V1 = {"halo_conv": 1, "gather_v1": 1}, {"gather_v2": 1}, {"gather_v1": 1}
+R16 = {"halo16_conv": 1, "gather_v1": 1}            # interior on the 16 x 32 tile kernel (grids of >= 7/8 of the CUs)
 HOT = [
-    ("res 256->256 3x3 @64^2 N=16", 256, 256, 3, 1, 1, False, 64, 64, 16, "none", "halo_conv", R, "wgrad_halo"),
+    ("res 256->256 3x3 @64^2 N=16", 256, 256, 3, 1, 1, False, 64, 64, 16, "none", "halo16_conv", R16, "wgrad_halo"),
     ("res 256->256 3x3 @64^2 N=8", 256, 256, 3, 1, 1, False, 64, 64, 8, "none", "halo_conv", R, "wgrad_halo"),
-    ("dec0 256->128 up @128^2 N=16", 256, 128, 3, 1, 1, True, 64, 64, 16, "none", "halo_conv", V2, "wgrad_halo"),
-    ("dec1 128->64 up @256^2 N=16", 128, 64, 3, 1, 1, True, 128, 128, 16, "none", "halo_conv", V2, "wgrad_halo"),
+    ("dec0 256->128 up @128^2 N=16", 256, 128, 3, 1, 1, True, 64, 64, 16, "none", "halo16_conv", V2, "wgrad_halo"),
+    ("dec1 128->64 up @256^2 N=16", 128, 64, 3, 1, 1, True, 128, 128, 16, "none", "halo16_conv", V2, "wgrad_halo"),
     ("enc0 64->128 4x4 s2 @256^2 N=16", 64, 128, 4, 2, 1, False, 256, 256, 16, "none", "gather_v2", V2, "wgrad_v1"),
     ("enc1 128->256 4x4 s2 @128^2 N=16", 128, 256, 4, 2, 1, False, 128, 128, 16, "none", "gather_v2", V2, "wgrad_v2"),
     ("stem 3->64 7x7 @256^2 N=16", 3, 64, 7, 1, 3, False, 256, 256, 16, "none", "thin_cin", {"thin_cout": 1, "gather_v1": 1}, "wgrad_thin"),
@@ -194,7 +195,7 @@ def test_bf16_step_tracks_f32_mode_at_256_batch_16():
     b_loss, b_fwd, b_d, b_g, b_fam = _losses_and_grads("bf16")
     # f32 mode runs the generic exact-f32 GEMMs only; bf16 mode must have run the tuned families
     assert set(f_fam) <= {"gather_v1", "wgrad_v1"}, f_fam
-    for fam in ("halo_conv", "gather_v2", "thin_cin", "thin_cout", "wgrad_halo", "wgrad_v2", "wgrad_thin"):
+    for fam in ("halo16_conv", "gather_v2", "thin_cin", "thin_cout", "wgrad_halo", "wgrad_v2", "wgrad_thin"):
         assert b_fam.get(fam, 0) > 0, (fam, b_fam)
     for a, b in zip(b_loss, f_loss):
         assert abs(a - b) <= 1e-3 * max(abs(b), 1e-3), (b_loss, f_loss)

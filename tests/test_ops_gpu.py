@@ -81,6 +81,14 @@ CONV_CASES += [
     (64, 4, 3, 1, 1, True, False, 128, 128, 4, False, "none"),          # heads: the interior dgrad (dY has 8 channels)
     (64, 4, 3, 1, 1, True, False, 16, 32, 4, False, "none"),            # heads wgrad: 64 x 64 block, taps split over two wave groups (forced)
 ]
+CONV_CASES += [
+    # 16x32-tile halo kernel (conv_halo16.hip: bf16, stride-1 3x3, H % 16 == 0, W % 32 == 0, channel stride % 32 == 0, a grid of
+    # >= 7/8 of the CUs); the interior dgrad of each case takes it as well
+    (64, 128, 3, 1, 1, True, False, 64, 64, 32, False, "none"),        # two 32-channel slices, BN = 128
+    (32, 64, 3, 1, 1, True, False, 64, 64, 32, False, "leaky_relu"),   # ONE slice (no halo re-issue), BN = 64, fused LReLU
+    (96, 136, 3, 1, 1, False, False, 64, 64, 16, True, "relu"),        # three slices, zero padding, bias, ragged N tile
+    (64, 64, 3, 1, 1, True, True, 32, 32, 32, False, "none"),          # fused nearest upsample
+]
 FORCE_WGRAD_HALO = {(128, 64, 3, 1, 1, True, False, 16, 32, 8, False, "none"), (256, 48, 3, 1, 1, False, False, 8, 32, 4, False, "none"),
                     (64, 4, 3, 1, 1, True, False, 16, 32, 4, False, "none")}
 
@@ -373,6 +381,7 @@ def test_halo_conv_tile_variants_bit_identical(ops):
     3-deep ring failed exactly this -- a race between the two wave groups -- and was removed.)"""
     from de_i2i_gan_amd import _lib
     lib = _lib.load()
+    lib.dei2i_set_option(b"halo16", 0)          # the sweep options belong to the 8 x 32 tile kernel: keep the 16 x 32 one out
     try:
         for cin, cout, hw, n, up in ((128, 64, 128, 8, False), (256, 128, 64, 16, False), (128, 128, 32, 16, True)):
             torch.manual_seed(11)
@@ -400,6 +409,7 @@ def test_halo_conv_tile_variants_bit_identical(ops):
     finally:
         lib.dei2i_set_option(b"halo_bn", 0)
         lib.dei2i_set_option(b"halo_stages", 0)
+        lib.dei2i_set_option(b"halo16", 1)
 
 
 @pytest.mark.parametrize("pname", ["f32", "bf16"])
