@@ -100,7 +100,11 @@ SIGNATURES = {
     "dei2i_conv2d_wgrad_pro_supported": (c_int, [_CD]),
     "dei2i_conv2d_wgrad_oihw_pro": (c_int, [_CD, _P, _P, _P, c_size_t, _P, c_int, _PD, _P]),
     "dei2i_ring_pixels": (c_size_t, [c_int, c_int]),
+    "dei2i_conv2d_ring_supported": (c_int, [_CD]),
+    "dei2i_conv2d_fwd_ring": (c_int, [_CD, _P, _P, _P, _P, c_int, _P, _P, _P]),
+    "dei2i_affine_act_img_fwd": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, c_float, _P, _P]),
     "dei2i_spade_prep": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "dei2i_in_finalize_chunks": (c_int, [c_int, c_int, c_int, c_int, _P, c_float, _P, _P, _P]),
     "dei2i_bn_finalize_train_chunks": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P]),
     "dei2i_affine_act_stats_fwd": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P, _P]),
     "dei2i_launch_counts": (c_int, [POINTER(c_int64), c_int]),

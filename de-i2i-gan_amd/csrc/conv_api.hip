@@ -461,6 +461,24 @@ int dei2i_conv2d_fwd_fused(const dei2i_conv* c, const void* x, const void* w_pac
   return (int)halo_conv(g, x, w_packed, c->Cout, bias, y, c->CoutS, act, num_cu(), (hipStream_t)s, nullptr, has ? &cp : nullptr, stats);
 }
 
+/* conv of the upsampled z of a SPADE block, z kept at the SOURCE resolution + the logical frame's ring tensor: the 16 x 32
+ * tile kernel only (no fallback: ask first) */
+int dei2i_conv2d_ring_supported(const dei2i_conv* c) {
+  if (!halo_fwd_shape_ok(c, 0) || !c->up) return 0;
+  const int Ho = c->H << c->up, Wo = c->W << c->up;
+  if (Ho % 16 != 0 || Wo % 32 != 0 || c->CinS % 32 != 0) return 0;
+  const int tiles_m = c->N * (Ho / 16) * (Wo / 32);
+  const int tn = c->CoutS >= 128 ? (c->CoutS + 127) / 128 : 1;
+  return tiles_m * tn >= (num_cu() * 7) / 8 ? 1 : 0;
+}
+
+int dei2i_conv2d_fwd_ring(const dei2i_conv* c, const void* z_src, const void* ring, const void* w_packed, const float* bias, int act,
+                          void* y, float* stats, dei2i_stream s) {
+  if (!z_src || !ring || !w_packed || !y || !dei2i_conv2d_ring_supported(c)) return DEI2I_ERR_BAD_ARG;
+  GatherDesc g = make_fwd_desc(to_shape(c), c->CinS);
+  return (int)halo16_conv(g, z_src, w_packed, c->Cout, bias, y, c->CoutS, act, num_cu(), (hipStream_t)s, stats, ring);
+}
+
 int dei2i_conv2d_wgrad_pro_supported(const dei2i_conv* c) {
   if (!valid_conv(c) || c->dtype != DT_BF16) return 0;
   if (c->kh != 3 || c->kw != 3 || c->stride != 1 || c->pad != 1) return 0;
@@ -474,7 +492,8 @@ int dei2i_conv2d_wgrad_pro_supported(const dei2i_conv* c) {
 
 int dei2i_conv2d_wgrad_oihw_pro(const dei2i_conv* c, const void* x, const void* dy, float* scratch, size_t scratch_elems,
                                 float* dw_oihw, int accumulate, const dei2i_pro* pro, dei2i_stream s) {
-  if (!x || !dy || !scratch || !dw_oihw || !pro || !pro->A || !pro->B || !dei2i_conv2d_wgrad_pro_supported(c)) return DEI2I_ERR_BAD_ARG;
+  if (!x || !dy || !scratch || !dw_oihw || !pro || !dei2i_conv2d_wgrad_pro_supported(c)) return DEI2I_ERR_BAD_ARG;
+  if ((pro->A == nullptr) != (pro->B == nullptr) || (pro->A == nullptr && pro->ring == nullptr)) return DEI2I_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)s;
   GatherDesc g = make_fwd_desc(to_shape(c), c->CinS);
   const size_t packed = (size_t)wgrad_slab_elems(c->Cout, g.K);

@@ -62,7 +62,11 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
                                                           const bf16_t* __restrict__ wgt, const int wrows,
                                                           const float* __restrict__ bias, bf16_t* __restrict__ out,
                                                           const int ldc, const int act, const int tiles_n,
-                                                          float* __restrict__ stats, unsigned long long* __restrict__ dbg) {
+                                                          float* __restrict__ stats, unsigned long long* __restrict__ dbg,
+                                                          const bf16_t* __restrict__ zring, const int ring_pix) {
+  // zring (optional): the input tensor is the SOURCE-resolution z of a SPADE -> upsample -> conv block whose 2-pixel frame
+  // (at the logical, upsampled resolution) has per-pixel gamma / beta classes: those halo pixels come from the compact
+  // ring tensor [N][ring_pix][Cs] (geom.h) instead of from src[y >> up][x >> up]
   const unsigned long long kt0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
   unsigned long long dg[6] = {0, 0, 0, 0, 0, 0};
   auto now = [&]() -> unsigned long long {
@@ -107,7 +111,12 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
       const int hy = p / hwd, hx = p - hy * hwd;
       const int y = bound_coord(hy0 + hy, g.Hl, g.pad_mode);
       const int x = bound_coord(hx0 + hx, g.Wl, g.pad_mode);
-      if ((y | x) >= 0) off = ((img * g.Hs + (y >> g.up)) * g.Ws + (x >> g.up)) * g.Cs;
+      if ((y | x) >= 0) {
+        if (zring != nullptr && !(ring_interior(y, g.Hl) && ring_interior(x, g.Wl)))
+          off = -2 - (img * ring_pix + ring_index(y, x, g.Hl, g.Wl)) * g.Cs;       // <= -2: element offset -2 - off into zring
+        else
+          off = ((img * g.Hs + (y >> g.up)) * g.Ws + (x >> g.up)) * g.Cs;
+      }
     }
     htab[p] = off;
   }
@@ -124,7 +133,8 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
     const int pix = grp * 16 + lrow;
     const int o = htab[pix];
     h_group[j] = grp;
-    h_off[j] = o >= 0 ? o + ((lslot ^ sw16(pix)) << 3) : -1;
+    const int so = (lslot ^ sw16(pix)) << 3;
+    h_off[j] = o >= 0 ? o + so : (o == -1 ? -1 : o - so);
   }
   const int rg = BN == 128 ? wave : (wave & 3);        // 16-row group of the weight stage this wave fetches
   const bf16_t* b_ptr;
@@ -144,6 +154,7 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
 #pragma unroll
     for (int j = 0; j < H16_HL; ++j) {
       const bf16_t* p = h_off[j] >= 0 ? src + ((size_t)(unsigned)h_off[j] + (unsigned)ci0) : zero;
+      if (h_off[j] < -1) p = zring + ((size_t)(unsigned)(-2 - h_off[j]) + (unsigned)ci0);
       glds16x(p, hb + h_group[j] * 1024);
     }
   };
@@ -721,7 +732,7 @@ int g_halo16_stages = 8;
 
 template <int BN, int STAGES>
 static hipError_t launch_halo16(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out,
-                                int ldc, int act, hipStream_t st, float* stats) {
+                                int ldc, int act, hipStream_t st, float* stats, const void* ring = nullptr) {
   const int tiles_m = g.N * (g.Ho / H16_TH) * (g.Wo / H16_TW);
   const int tiles_n = (ldc + BN - 1) / BN;
   constexpr size_t loop_lds = 2 * (size_t)H16_HBYTES + (size_t)STAGES * BN * 64 + H16_GROUPS * 16 * sizeof(int);
@@ -738,14 +749,16 @@ static hipError_t launch_halo16(const GatherDesc& g, const void* src, const void
   count_launch(K_HALO16_CONV);
   prof_begin(PROF_HALO_CONV, 2.0 * (double)g.M * (double)(g.th * g.tw) * (double)g.Clog * (double)wrows, st);
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, st, g, (const bf16_t*)src, (const bf16_t*)wgt, wrows, bias,
-                     (bf16_t*)out, ldc, act, tiles_n, stats, g_v2_dbg);
+                     (bf16_t*)out, ldc, act, tiles_n, stats, g_v2_dbg, (const bf16_t*)ring,
+                     ring != nullptr ? ring_pixels(g.Hl, g.Wl) : 0);
   prof_end(PROF_HALO_CONV, st);
   return hipGetLastError();
 }
 
 // returns hipErrorNotSupported when the shape does not qualify (the caller goes on to the 8 x 32 tile kernel)
+// ring: see the kernel (SPADE -> upsample -> conv with z kept at the source resolution); only the 8-wave kernel takes it
 hipError_t halo16_conv(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out, int ldc,
-                       int act, int num_cu, hipStream_t st, float* stats) {
+                       int act, int num_cu, hipStream_t st, float* stats, const void* ring) {
   if (!g_halo16 || g_halo_bn != 0 || g_halo_stages != 0) return hipErrorNotSupported;   // (the tile sweep is the 8 x 32 kernel's)
   if (g.sh != 1 || g.sw != 1 || (g.ys != 1 && g.ys != -1) || (g.xs != 1 && g.xs != -1)) return hipErrorNotSupported;
   if (g.th != 3 || g.tw != 3 || g.wK != g.K || g.wtw != g.tw) return hipErrorNotSupported;
@@ -756,17 +769,18 @@ hipError_t halo16_conv(const GatherDesc& g, const void* src, const void* wgt, in
   const int tn = ldc >= 128 ? (ldc + 127) / 128 : 1;
   // the double-size tile needs a grid that still covers the chip: at least ~7/8 of a round (fewer: the 8 x 32 tiles spread better)
   if (tiles_m * tn < (num_cu * 7) / 8) return hipErrorNotSupported;
-  if (g_halo16 == 2) {          // the four-wave software-pipelined variant
+  if (ring != nullptr && (g.Hl < 4 || g.Wl < 4)) return hipErrorNotSupported;
+  if (g_halo16 == 2 && ring == nullptr) {          // the four-wave software-pipelined variant
     if (ldc >= 128) return launch_halo16w4<128, 8>(g, src, wgt, wrows, bias, out, ldc, act, st, stats);
     return launch_halo16w4<64, 8>(g, src, wgt, wrows, bias, out, ldc, act, st, stats);
   }
   if (ldc >= 128) {
     if (g_halo16_stages == 4) return launch_halo16<128, 4>(g, src, wgt, wrows, bias, out, ldc, act, st, stats);
     if (g_halo16_stages == 6) return launch_halo16<128, 6>(g, src, wgt, wrows, bias, out, ldc, act, st, stats);
-    return launch_halo16<128, 8>(g, src, wgt, wrows, bias, out, ldc, act, st, stats);
+    return launch_halo16<128, 8>(g, src, wgt, wrows, bias, out, ldc, act, st, stats, ring);
   }
   if (g_halo16_stages == 4) return launch_halo16<64, 4>(g, src, wgt, wrows, bias, out, ldc, act, st, stats);
-  return launch_halo16<64, 8>(g, src, wgt, wrows, bias, out, ldc, act, st, stats);
+  return launch_halo16<64, 8>(g, src, wgt, wrows, bias, out, ldc, act, st, stats, ring);
 }
 
 }  // namespace dei2i

@@ -1,6 +1,7 @@
 // HBM-bound elementwise kernels (NHWC, 16-byte vectors): layout conversion at the module boundary, BatchNorm-apply
 // + activation, SPADE modulate + ReLU, activation backward, head compose, NaN guard, casts.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <math.h>
 
 #include "../../include/dei2i_hip.h"
@@ -82,6 +83,30 @@ __global__ void affine_act_kernel(const T* __restrict__ x, const float* __restri
     if constexpr (sizeof(T) == 2) {              // fp8 forward mode: the e4m3 copy the next convolution reads
       if (out8 != nullptr) store_e4m3_of_bf16x8(out8 + i * 8, pk, scale8);
     }
+  }
+}
+
+// ---- out = act(A[n,c]*x + B[n,c]) with per-image coefficients (grid.y = image) ----
+template <typename T>
+__global__ void affine_act_img_kernel(const T* __restrict__ x, const float* __restrict__ A, const float* __restrict__ B,
+                                      T* __restrict__ out, size_t nvec_img, int cv, float slope) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int n = blockIdx.y;
+  const size_t base = (size_t)n * nvec_img;
+  float av[VEC], bv[VEC];
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // launch: gridDim.x * blockDim.x is a multiple of cv
+  const int c = (int)(i % cv) * VEC;
+  ldcoef<VEC>(A + (size_t)n * cv * VEC + c, av);
+  ldcoef<VEC>(B + (size_t)n * cv * VEC + c, bv);
+  for (; i < nvec_img; i += (size_t)gridDim.x * blockDim.x) {
+    float f[VEC];
+    Elem<T>::unpack(*reinterpret_cast<const u32x4*>(x + (base + i) * VEC), f);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float v = fmaf(av[e], f[e], bv[e]);
+      f[e] = fmaf(slope, fminf(v, 0.f), fmaxf(v, 0.f));
+    }
+    *reinterpret_cast<u32x4*>(out + (base + i) * VEC) = Elem<T>::pack(f);
   }
 }
 
@@ -287,6 +312,25 @@ int dei2i_affine_act_fwd(int dtype, size_t pixels, int C, const void* x, const f
     if (inv) hipLaunchKernelGGL((affine_act_kernel<float, true>), dim3(grid), dim3(256), 0, st, (const float*)x, a, b, (const float*)res, (float*)out, nvec, cv, act, o8, e4m3_scale);
     else hipLaunchKernelGGL((affine_act_kernel<float, false>), dim3(grid), dim3(256), 0, st, (const float*)x, a, b, (const float*)res, (float*)out, nvec, cv, act, o8, e4m3_scale);
   }
+  return (int)hipGetLastError();
+}
+
+int dei2i_affine_act_img_fwd(int dtype, int N, int HW, int C, const void* x, const float* A, const float* B, float slope, void* out,
+                             dei2i_stream s) {
+  const int vec = vec_of(dtype);
+  if (N <= 0 || HW <= 0 || C <= 0 || C % vec || !x || !A || !B || !out) return DEI2I_ERR_BAD_ARG;
+  const int cv = C / vec;
+  if (256 % cv != 0 && cv % 256 != 0) return DEI2I_ERR_BAD_ARG;      // a thread keeps one channel vector
+  const size_t nvec_img = (size_t)HW * cv;
+  unsigned blocks = (unsigned)std::min<size_t>((nvec_img + 255) / 256, 512);
+  if (cv > 256) blocks = (blocks / (cv / 256)) * (cv / 256);
+  if (blocks < 1) blocks = cv > 256 ? cv / 256 : 1;
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(affine_act_img_kernel<bf16_t>, dim3(blocks, N), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, A, B, (bf16_t*)out,
+                       nvec_img, cv, slope);
+  else
+    hipLaunchKernelGGL(affine_act_img_kernel<float>, dim3(blocks, N), dim3(256), 0, (hipStream_t)s, (const float*)x, A, B, (float*)out,
+                       nvec_img, cv, slope);
   return (int)hipGetLastError();
 }
 

@@ -860,6 +860,14 @@ int dei2i_bn_finalize_eval(int C, const float* weight, const float* bias, const 
   return (int)hipGetLastError();
 }
 
+int dei2i_in_finalize_chunks(int N, int HW, int C, int chunks, const float* partial, float eps, float* mean, float* rstd,
+                             dei2i_stream s) {
+  if (N <= 0 || HW <= 0 || C <= 0 || chunks <= 0 || !partial || !mean || !rstd) return DEI2I_ERR_BAD_ARG;
+  hipLaunchKernelGGL(in_finalize_kernel, dim3(C, N), dim3(combine_threads(chunks)), 0, (hipStream_t)s, partial, N, chunks, C,
+                     (double)HW, eps, mean, rstd);
+  return (int)hipGetLastError();
+}
+
 int dei2i_in_finalize(int N, int HW, int C, const float* partial, float eps, float* mean, float* rstd, dei2i_stream s) {
   if (N <= 0 || HW <= 0 || C <= 0 || !partial || !mean || !rstd) return DEI2I_ERR_BAD_ARG;
   hipLaunchKernelGGL(in_finalize_kernel, dim3(C, N), dim3(combine_threads(dei2i_moments_chunks(HW))), 0, (hipStream_t)s, partial, N,

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const GatherDesc g, con
     bool reload = false;
     float cval = 0.f;
     if constexpr (PRO) {
-      if (it >= 0) {
+      if (it >= 0 && pro.A != nullptr) {            // (A == nullptr: ring redirect only -- the tensor is already normalised)
         const int img = (tbeg + it) / tiles_img;
         reload = img != cur_img;                                          // workgroup-uniform: a new image's coefficients
         if (reload && tid < 2 * BCI)
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const GatherDesc g, con
     }
     if (it + 1 < nt) issue((it + 1) & 1, tbeg + it + 1);
     if constexpr (PRO) {
-      if (it >= 0) {
+      if (it >= 0 && pro.A != nullptr) {
         if (reload) {
           if (it + 1 < nt) hw_wait_vm<NA + NB>(); else hw_wait_vm<0>();   // the coefficient load is older than the DMA just issued
           if (tid < 2 * BCI) pcoef[tid] = cval;

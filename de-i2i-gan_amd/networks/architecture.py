@@ -323,10 +323,11 @@ class SPADE(nn.Module):
             wt, geom = conv.weight, conv.geom(up)
             params_grad = wt.requires_grad or self.mlp_gamma.weight.requires_grad
             need_grad = torch.is_grad_enabled() and (x.requires_grad or params_grad)
-            if ops.spade_conv_supported(x, wt, geom, need_grad):
+            mode = ops.spade_conv_supported(x, wt, geom, need_grad)
+            if mode is not None:
                 self._ran_class_mode = True
                 gb = self._class_table(segmap, prec, h, w)
-                return ops.spade_conv(x, gb, wt, conv._packed, geom, skip=skip, stats=stats)
+                return ops.spade_conv(x, gb, wt, conv._packed, geom, skip=skip, stats=stats, mode=mode)
         if skip:
             z, xs = self(x, segmap, up=up, skip=True)
             return conv(z, stats=stats), xs

@@ -66,8 +66,11 @@ class fp8_forward:
 #               measured at 256x256 batch 16 (profiles/r02_b_*): the in-LDS transform costs +33 us on a 99 us conv and
 #               +34 us on a 91 us wgrad (it is repeated per output-channel tile and again in the wgrad, in kernels whose
 #               VALU slots compete with the MFMA issue) against ~39 us of statistics + modulate kernels saved: +1.4 ms/step.
+#   fuse_ring : SPADE -> nearest x2 upsample -> conv keeps the normalised tensor at the SOURCE resolution (+ the logical
+#               image's 2-pixel frame in a compact ring tensor): the 4x larger upsampled tensor is never written or read -- ON
 fuse_norm = True
 fuse_pro = False
+fuse_ring = True
 
 _fp8_stash = []          # e4m3 copy produced by the last normalisation kernel, handed to its output tensor by the wrapper
 
@@ -454,8 +457,9 @@ class _Conv2d(torch.autograd.Function):
         use_fp8 = bool(_fp8_forward and prec is BF16 and not per_call and lib.dei2i_conv2d_fp8_supported(byref(d)))
         # trainable weights: a backward pass of this optimizer step will want the dgrad layout too (also when THIS call
         # is the no-grad generator pass of the D step) -> both layouts in one pack launch
-        wf = None if use_fp8 else cache.get(weight, sources, prec, geom, cins, couts,
-                                            need_dgrad=any(s_.requires_grad for s_ in sources), per_call=per_call)[0]
+        # (a frozen weight behind an input that needs a gradient -- D inside the G step -- wants the dgrad layout just as well)
+        want_dgrad = any(s_.requires_grad for s_ in sources) or bool(ctx.needs_input_grad[0])
+        wf = None if use_fp8 else cache.get(weight, sources, prec, geom, cins, couts, need_dgrad=want_dgrad, per_call=per_call)[0]
         ho, wo = c_int(), c_int()
         lib.dei2i_conv2d_out_shape(byref(d), byref(ho), byref(wo))
         y = torch.empty((n, ho.value, wo.value, couts), dtype=prec.dtype, device=x.device)
@@ -874,11 +878,16 @@ class _SpadeRelu(torch.autograd.Function):
         dev = x.device
         mean = torch.empty((n, c), dtype=torch.float32, device=dev)
         rstd = torch.empty((n, c), dtype=torch.float32, device=dev)
-        # statistics of the upsampled tensor == statistics of the source tensor (every pixel replicated 4x)
-        chunks = lib.dei2i_moments_chunks(hs * ws)
-        partial = torch.empty((n, chunks, 2, c), dtype=torch.float32, device=dev)
-        L.check(lib.dei2i_moments_partial(prec.code, n, hs * ws, c, _p(x), _p(partial), st), "moments_partial")
-        L.check(lib.dei2i_in_finalize(n, hs * ws, c, _p(partial), eps, _p(mean), _p(rstd), st), "in_finalize")
+        # statistics of the upsampled tensor == statistics of the source tensor (every pixel replicated 4x); the records its
+        # producer left (conv epilogue / affine kernel) when there are any
+        have = _stats_of(x, n, hs * ws, c) if fuse_norm else None
+        if have is not None:
+            partial, chunks = have
+        else:
+            chunks = lib.dei2i_moments_chunks(hs * ws)
+            partial = torch.empty((n, chunks, 2, c), dtype=torch.float32, device=dev)
+            L.check(lib.dei2i_moments_partial(prec.code, n, hs * ws, c, _p(x), _p(partial), st), "moments_partial")
+        L.check(lib.dei2i_in_finalize_chunks(n, hs * ws, c, chunks, _p(partial), eps, _p(mean), _p(rstd), st), "in_finalize")
         out = torch.empty((n, h, w, c), dtype=prec.dtype, device=dev)
         xq = torch.empty(out.numel(), dtype=torch.uint8, device=dev) if _fp8_copy_wanted(prec, c) else None
         L.check(lib.dei2i_spade_act_fwd(prec.code, n, h, w, c, 1 if up else 0, _p(x), _p(mean), _p(rstd), _p(gb), gb_mode,
@@ -921,7 +930,10 @@ class _SpadeConv(torch.autograd.Function):
     SPADE backward kernels of the unfused op."""
 
     @staticmethod
-    def forward(ctx, x, gb, weight, up, eps, skip, cache: PackedWeights, sources, geom: ConvGeom, want_stats):
+    def forward(ctx, x, gb, weight, up, eps, skip, cache: PackedWeights, sources, geom: ConvGeom, want_stats, ring_mode=False):
+        # ring_mode (up only): instead of normalising on the conv's operand path, write z at the SOURCE resolution with the
+        # interior-class coefficients (one elementwise pass over the small tensor) and let the conv read it through its fused
+        # upsample, the logical frame's pixels from the ring tensor -- see fuse_ring
         prec = precision_of(x)
         x_in = x
         x, gb = x.contiguous(), gb.contiguous()
@@ -947,25 +959,33 @@ class _SpadeConv(torch.autograd.Function):
         d = _desc(prec, geom, n, hs, ws, c, couts)
         wf = cache.get(weight, sources, prec, geom, c, couts, need_dgrad=any(s_.requires_grad for s_ in sources))[0]
         y = torch.empty((n, h, w, couts), dtype=prec.dtype, device=dev)
-        pro = L.ProDesc(coefs[2].data_ptr(), coefs[3].data_ptr(), c, 0.0, ring.data_ptr())
         out_partial = None
         if want_stats:
             ochunks = lib.dei2i_conv2d_stats_chunks(byref(d))
             out_partial = torch.empty((n, ochunks, 2, couts), dtype=torch.float32, device=dev)
             _stats_stash.append((out_partial, ochunks))
-        L.check(lib.dei2i_conv2d_fwd_fused(byref(d), _p(x), _p(wf), None, L.ACT_NONE, _p(y), byref(pro), _p(out_partial), st),
-                "conv2d_fwd_fused(spade)")
-        ctx.prec, ctx.up, ctx.geom, ctx.cache, ctx.sources = prec, up, geom, cache, sources
+        z_src = None
+        if ring_mode:
+            z_src = torch.empty_like(x)
+            L.check(lib.dei2i_affine_act_img_fwd(prec.code, n, hs * ws, c, _p(x), _p(coefs[2]), _p(coefs[3]), 0.0, _p(z_src), st),
+                    "affine_act_img")
+            L.check(lib.dei2i_conv2d_fwd_ring(byref(d), _p(z_src), _p(ring), _p(wf), None, L.ACT_NONE, _p(y), _p(out_partial), st),
+                    "conv2d_fwd_ring")
+        else:
+            pro = L.ProDesc(coefs[2].data_ptr(), coefs[3].data_ptr(), c, 0.0, ring.data_ptr())
+            L.check(lib.dei2i_conv2d_fwd_fused(byref(d), _p(x), _p(wf), None, L.ACT_NONE, _p(y), byref(pro), _p(out_partial), st),
+                    "conv2d_fwd_fused(spade)")
+        ctx.prec, ctx.up, ctx.geom, ctx.cache, ctx.sources, ctx.ring_mode = prec, up, geom, cache, sources, ring_mode
         ctx.out_shape = (n, h, w, c)
-        ctx.save_for_backward(x, gb, coefs, ring, weight)
+        ctx.save_for_backward(x, gb, coefs, ring, weight, z_src)
         return (y, x_in) if skip else y
 
     @staticmethod
     def backward(ctx, dy, dskip=None):
-        x, gb, coefs, ring, weight = ctx.saved_tensors
+        x, gb, coefs, ring, weight, z_src = ctx.saved_tensors
         prec, geom, up = ctx.prec, ctx.geom, ctx.up
         if dy is None:                                   # only the identity branch was used
-            return (dskip,) + (None,) * 9
+            return (dskip,) + (None,) * 10
         lib = _lib_for(x)
         dy = dy.contiguous()
         n, h, w, c = ctx.out_shape
@@ -975,8 +995,11 @@ class _SpadeConv(torch.autograd.Function):
                 raise RuntimeError("spade_conv: identity-branch gradient does not match the activation")
         dw = None
         if _wants_grad(ctx, 2):
-            pro = L.ProDesc(coefs[2].data_ptr(), coefs[3].data_ptr(), c, 0.0, ring.data_ptr())
-            dw = _conv_wgrad(lib, prec, geom, x, dy, weight, pro)
+            if ctx.ring_mode:                            # the conv's input was z_src (+ ring): no transform in the wgrad
+                dw = _conv_wgrad(lib, prec, geom, z_src, dy, weight, L.ProDesc(None, None, 0, 0.0, ring.data_ptr()))
+            else:
+                pro = L.ProDesc(coefs[2].data_ptr(), coefs[3].data_ptr(), c, 0.0, ring.data_ptr())
+                dw = _conv_wgrad(lib, prec, geom, x, dy, weight, pro)
         dx = dgb = None
         if _wants_grad(ctx, 0) or _wants_grad(ctx, 1):
             # dL/dz at the LOGICAL (upsampled) resolution: the conv seen as a plain conv on z (the SPADE backward sums the
@@ -986,32 +1009,37 @@ class _SpadeConv(torch.autograd.Function):
             dx, dgb = _spade_backward(lib, prec, dz, dskip, x, gb, coefs[0], coefs[1], up, 1, ctx.out_shape)
         elif dskip is not None:
             dx = dskip
-        return (dx, dgb, dw) + (None,) * 7
+        return (dx, dgb, dw) + (None,) * 8
 
 
-def spade_conv_supported(x, weight, geom: ConvGeom, need_grad: bool) -> bool:
-    """Can conv(relu(SPADE(up(x)))) run with the norm on the conv's operand path?  ``geom`` carries the upsample flag."""
-    if not (fuse_norm and fuse_pro and x.is_cuda and x.dtype == torch.bfloat16 and not _fp8_forward):
-        return False
+def spade_conv_supported(x, weight, geom: ConvGeom, need_grad: bool):
+    """How can conv(relu(SPADE(up(x)))) run fused?  -> "pro" (the norm on the conv's operand path: fuse_pro), "ring" (upsampling
+    blocks: z at the source resolution + the frame's ring tensor: fuse_ring) or None.  ``geom`` carries the upsample flag."""
+    if not (fuse_norm and x.is_cuda and x.dtype == torch.bfloat16 and not _fp8_forward):
+        return None
     if getattr(weight, "_dei2i_per_call", False):
-        return False
+        return None
     lib = _lib_for(x)
     n, hs, ws, c = x.shape
     d = _desc(BF16, geom, n, hs, ws, c, BF16.pad(geom.cout))
-    if not lib.dei2i_conv2d_fused_supported(byref(d), 1):
-        return False
-    return bool(lib.dei2i_conv2d_wgrad_pro_supported(byref(d))) if need_grad else True
+    wg_ok = (not need_grad) or bool(lib.dei2i_conv2d_wgrad_pro_supported(byref(d)))
+    if fuse_pro and wg_ok and lib.dei2i_conv2d_fused_supported(byref(d), 1):
+        return "pro"
+    if fuse_ring and geom.up and wg_ok and lib.dei2i_conv2d_ring_supported(byref(d)):
+        return "ring"
+    return None
 
 
-def spade_conv(x, gb, weight, cache, geom: ConvGeom, eps: float = 1e-5, skip: bool = False, sources=None, stats=False):
+def spade_conv(x, gb, weight, cache, geom: ConvGeom, eps: float = 1e-5, skip: bool = False, sources=None, stats=False, mode="pro"):
     """conv(relu(IN(up(x)) * (1 + gamma) + beta)) with the class table ``gb`` (N,5,5,2C); ``geom.up`` = nearest x2 upsample in
-    front of the norm.  With ``skip`` -> (y, x).  Ask spade_conv_supported first."""
+    front of the norm.  With ``skip`` -> (y, x).  ``mode``: what spade_conv_supported answered."""
     del _stats_stash[:]
     src = tuple(sources) if sources is not None else (weight,)
+    ring_mode = mode == "ring"
     if skip:
-        y, xs = _SpadeConv.apply(x, gb, weight, bool(geom.up), float(eps), True, cache, src, geom, bool(stats))
+        y, xs = _SpadeConv.apply(x, gb, weight, bool(geom.up), float(eps), True, cache, src, geom, bool(stats), ring_mode)
         return _attach_stats(y), xs
-    return _attach_stats(_SpadeConv.apply(x, gb, weight, bool(geom.up), float(eps), False, cache, src, geom, bool(stats)))
+    return _attach_stats(_SpadeConv.apply(x, gb, weight, bool(geom.up), float(eps), False, cache, src, geom, bool(stats), ring_mode))
 
 
 # --------------------------------------------------------------------------------------------------------------

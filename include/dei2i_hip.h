@@ -266,13 +266,27 @@ int dei2i_conv2d_wgrad_pro_supported(const dei2i_conv* c);
 /* dei2i_conv2d_wgrad_oihw for a conv whose input was normalised on the operand path: x is the UN-normalised tensor */
 int dei2i_conv2d_wgrad_oihw_pro(const dei2i_conv* c, const void* x, const void* dy, float* scratch, size_t scratch_elems,
                                 float* dw_oihw, int accumulate, const dei2i_pro* pro, dei2i_stream s);
+/* SPADE -> nearest x2 upsample -> conv (architecture.py:241-245) with z kept at the SOURCE resolution: gamma / beta of a constant
+ * label map only differ on the 2-pixel frame of the upsampled image, so z[y][x] = z_src[y >> 1][x >> 1] everywhere else; the
+ * conv (c->up = 1) reads z_src through its fused upsample and the frame's pixels from `ring` (dei2i_spade_prep) -- the
+ * upsampled, normalised tensor (4x the bytes) is never written or read.  dei2i_conv2d_wgrad_oihw_pro with pro->A = pro->B =
+ * NULL and pro->ring set is the matching weight gradient (x = z_src). */
+int dei2i_conv2d_ring_supported(const dei2i_conv* c);
+int dei2i_conv2d_fwd_ring(const dei2i_conv* c, const void* z_src, const void* ring, const void* w_packed, const float* bias, int act,
+                          void* y, float* stats, dei2i_stream s);
+/* out[n, p, c] = max(A[n, c] * x[n, p, c] + B[n, c], 0) + slope * min(..., 0): an affine + activation with per-IMAGE
+ * coefficients (SPADE's interior class at the source resolution; HW pixels per image) */
+int dei2i_affine_act_img_fwd(int dtype, int N, int HW, int C, const void* x, const float* A, const float* B, float slope, void* out,
+                             dei2i_stream s);
 size_t dei2i_ring_pixels(int H, int W);                                        /* 4*W + 4*(H-4) */
 /* InstanceNorm finalize + SPADE coefficient preparation in one launch: mean / rstd (N,C) from the partial records (`chunks`
  * per image, HW = Hs*Ws pixels each image), A = rstd*(1+gamma_int), B = beta_int - mean*A for the interior class of the
  * (N,5,5,2C) table, and (ring != NULL) relu(IN(x)*(1+gamma)+beta) of the 2-pixel frame of the (Hs<<up, Ws<<up) image */
 int dei2i_spade_prep(int dtype, int N, int Hs, int Ws, int C, int up, const void* x, const float* partial, int chunks, float eps,
                      const void* gb_table, float* mean, float* rstd, float* A, float* B, void* ring, dei2i_stream s);
-/* dei2i_bn_finalize_train with an explicit record count per image (records written by a conv epilogue) */
+/* dei2i_in_finalize / dei2i_bn_finalize_train with an explicit record count per image (records written by a conv epilogue) */
+int dei2i_in_finalize_chunks(int N, int HW, int C, int chunks, const float* partial, float eps, float* mean, float* rstd,
+                             dei2i_stream s);
 int dei2i_bn_finalize_train_chunks(int N, int HW, int C, int chunks, const float* partial, const float* weight, const float* bias,
                                    float* running_mean, float* running_var, float momentum, float eps, float* mean, float* rstd,
                                    float* a, float* b, long long* num_batches_tracked, dei2i_stream s);

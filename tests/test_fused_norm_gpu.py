@@ -23,10 +23,10 @@ DEV = "cuda:0"
 @pytest.fixture()
 def ops():
     from de_i2i_gan_amd import ops as _ops
-    keep = (_ops.fuse_norm, _ops.fuse_pro)
-    _ops.fuse_norm, _ops.fuse_pro = True, True          # the operand-path fusion is off by default (ops.py: measured slower)
+    keep = (_ops.fuse_norm, _ops.fuse_pro, _ops.fuse_ring)
+    _ops.fuse_norm, _ops.fuse_pro, _ops.fuse_ring = True, True, True     # the operand-path fusion is off by default (ops.py: measured slower)
     yield _ops
-    _ops.fuse_norm, _ops.fuse_pro = keep
+    _ops.fuse_norm, _ops.fuse_pro, _ops.fuse_ring = keep
 
 
 def _counts(reset=True):
@@ -128,10 +128,14 @@ def test_bn_act_conv_fused(ops, C, cout, H, W, N, training):
         assert maxrel(a, b) < 1e-5, nm
 
 
-@pytest.mark.parametrize("C,cout,hs,ws,N,up,skip", [(128, 128, 64, 64, 8, False, True), (256, 128, 32, 32, 16, True, False),
-                                                     (128, 64, 64, 64, 8, True, False), (64, 128, 64, 64, 16, False, False),
-                                                     (128, 128, 16, 32, 64, False, False)])
-def test_spade_conv_fused(ops, C, cout, hs, ws, N, up, skip):
+@pytest.mark.parametrize("C,cout,hs,ws,N,up,skip,mode", [(128, 128, 64, 64, 8, False, True, "pro"), (256, 128, 32, 32, 16, True, False, "pro"),
+                                                          (128, 64, 64, 64, 8, True, False, "pro"), (64, 128, 64, 64, 16, False, False, "pro"),
+                                                          (128, 128, 16, 32, 64, False, False, "pro"),
+                                                          # "ring": z at the source resolution + the logical frame's ring tensor (the
+                                                          # default path of the upsampling decoder blocks, 16 x 32 tile conv kernel)
+                                                          (256, 128, 64, 64, 16, True, False, "ring"), (128, 64, 64, 64, 16, True, False, "ring"),
+                                                          (64, 128, 32, 64, 32, True, False, "ring")])
+def test_spade_conv_fused(ops, C, cout, hs, ws, N, up, skip, mode):
     """conv(ReLU(SPADE(up(x)))) on a constant label map through the product modules: fused against the oracle (float64,
     rounded operands) and against the unfused kernels (same inputs)."""
     from de_i2i_gan_amd.networks.architecture import SPADE, Conv2d
@@ -166,6 +170,7 @@ def test_spade_conv_fused(ops, C, cout, hs, ws, N, up, skip):
     res = {}
     for fused in (True, False):
         ops.fuse_norm = fused
+        ops.fuse_pro = mode == "pro"
         for p in list(mod.parameters()) + list(conv.parameters()):
             p.grad = None
         mod._gb_cache.clear()
@@ -183,7 +188,7 @@ def test_spade_conv_fused(ops, C, cout, hs, ws, N, up, skip):
             out.backward(nhwc(gy).to(DEV).bfloat16())
         res[fused] = (out.detach(), xg.grad, conv.weight.grad.clone(), {k_: p.grad.clone() for k_, p in mod.named_parameters()}, c_fwd)
     f, u = res[True], res[False]
-    assert f[4].get("halo_conv") == 1, f[4]
+    assert f[4].get("halo_conv" if mode == "pro" else "halo16_conv") == 1, f[4]
     m = {"y_vs_oracle": (maxrel(ops.to_nchw(f[0], cout), out_ref), rel_l2(ops.to_nchw(f[0], cout), out_ref)),
          "dx_vs_oracle": rel_l2(ops.to_nchw(f[1], C), g_ref[0]), "dx_unfused_vs_oracle": rel_l2(ops.to_nchw(u[1], C), g_ref[0]),
          "dw_vs_oracle": rel_l2(f[2], g_ref[1]), "dw_unfused_vs_oracle": rel_l2(u[2], g_ref[1]),
@@ -192,7 +197,7 @@ def test_spade_conv_fused(ops, C, cout, hs, ws, N, up, skip):
          "params_vs_unfused": {k_: rel_l2(f[3][k_], u[3][k_]) for k_ in f[3]}}
     import json, os
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(f"gpurun_out/spade_conv_fused_{C}_{cout}_{hs}_{int(up)}.json", "w") as fh:
+    with open(f"gpurun_out/spade_conv_{mode}_{C}_{cout}_{hs}_{int(up)}.json", "w") as fh:
         json.dump(m, fh, indent=1)
     tol = 1.5e-2 * 3                               # the op tests' SPADE bound: gamma / beta / actv are bf16 intermediates too
     assert m["y_vs_oracle"][0] < tol and m["y_vs_oracle"][1] < 1.5e-2, m
