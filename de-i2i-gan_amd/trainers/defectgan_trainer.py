@@ -1,10 +1,14 @@
 """DefectGanTrainer (trainers/defectgan_trainer.py:19-188): the two ``_train_*_once`` methods with the reference's
-signatures and side effects, plus ``step()`` = one D update then (every ``num_critics`` iterations) one G update.
+signatures and side effects, ``step()`` = one D update then (every ``num_critics`` iterations) one G update, and the
+epoch loop ``train()`` / ``_train_epoch()`` with the reference's checkpoint / resume behaviour (``latest`` weights and
+``iter.txt`` every ``save_latest_freq`` iterations, numbered weights every ``save_ckpt_freq`` epochs, one scheduler step per
+epoch).
 
-TensorBoard logging, image grids and FID/IS/LPIPS validation are host-side tooling outside the hot path
+TensorBoard logging, progress bars, image grids and FID/IS/LPIPS validation are host-side tooling outside the hot path
  and are not part of this package."""
 from collections import defaultdict
 
+import numpy as np
 import torch
 
 from .base_trainer import BaseTrainer
@@ -62,6 +66,33 @@ class DefectGanTrainer(BaseTrainer):
         self._train_discriminator_once(bg_data, df_labels, df_data)
         if self.iters % self.opt.num_critics == 0:
             self._train_generator_once(bg_data, df_labels, df_data)
+
+    # ---- the epoch loop with the reference's checkpoint / resume rules (defectgan_trainer.py:75-120) -------------------
+    def train(self, train_loaders, val_loaders=None):
+        """Epochs ``first_epoch .. num_epochs`` (1-based, like the reference): ``train_loaders['defects']`` is iterated once
+        per epoch, ``train_loaders['background']`` is an (infinite) iterator drawn with ``next`` -- both yield
+        ``(images, labels, _)``.  ``val_loaders`` is accepted for signature compatibility (metrics are out of scope)."""
+        for epoch in range(self.first_epoch, self.opt.num_epochs + 1):
+            self._init_losses()
+            self._train_epoch(train_loaders, epoch)
+            if epoch % getattr(self.opt, "save_ckpt_freq", 10 ** 9) == 0:
+                self.model.save(epoch)
+            self._update_per_epoch(epoch)
+
+    def _train_epoch(self, data_loaders, epoch):
+        for df_data, df_labels, _ in data_loaders["defects"]:
+            bg_data, bg_labels, _ = next(data_loaders["background"])
+            bg_data = bg_data[:df_data.size(0)]            # truncate to the defect batch (defectgan_trainer.py:102-105)
+            self.step(bg_data, df_labels, df_data)
+            if self.iters % self.opt.save_latest_freq == 0:
+                self.save_latest(epoch)
+
+    def save_latest(self, epoch):
+        """``latest_net_{G,D}.pth`` + ``iter.txt`` = (epoch, iters), what ``--continue_training`` restores
+        (defectgan_trainer.py:111-113, base_trainer.py:38-44).  Optimizer state is not saved -- the reference does not."""
+        self.model.save("latest")
+        self.iter_record_path.parent.mkdir(parents=True, exist_ok=True)
+        np.savetxt(self.iter_record_path, (epoch, self.iters), fmt="%i", delimiter=",")
 
     def _update_per_epoch(self, epoch=None):
         super()._update_per_epoch(epoch)
