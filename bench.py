@@ -319,7 +319,7 @@ def main():
         "losses_last_step": {k: round(v[-1], 5) for kind in tr.losses.values() for k, v in kind.items() if v},
     }
     if fam:
-        hn, hms, hfl = fam["halo"]                       # the dominant kernel: halo_conv_kernel (stride-1 3x3 fwd + dgrad)
+        hn, hms, hfl = fam["halo"]                       # the dominant kernel family: the halo-resident stride-1 3x3 conv (fwd + dgrad)
         on, _, ofl = fam["gather_gemm"]                  # the other conv forward / dgrad kernels (timed region: counts only)
         wn, _, wfl = fam["wgrad"]
         xhn, xhms, xhfl = fam_extra["halo"]              # all families with events, extra steps after the timed region
@@ -334,23 +334,25 @@ def main():
                 if traffic is None and os.path.exists(pmc):
                     with open(pmc) as f:
                         t = json.load(f)
-                    if "halo_conv" in t:
-                        traffic = t["halo_conv"]["hbm_bytes_per_launch"]
+                    hk = "halo16_conv" if "halo16_conv" in t else "halo_conv"
+                    if hk in t:
+                        traffic = t[hk]["hbm_bytes_per_launch"]
                         traffic_src = ("profiles/%s_pmc_traffic.json (profiles/collect.sh + summarize.py): (2*FETCH_SIZE + WRITE_SIZE)"
-                                       "*1024 bytes per halo_conv_kernel launch, separate --pmc passes" % tag)
+                                       "*1024 bytes per %s_kernel launch, separate --pmc passes" % (tag, hk))
                 pmc2 = os.path.join(REPO, "profiles", tag + "_pmc_mfma.json")
                 if mfma_pmc is None and os.path.exists(pmc2):
                     with open(pmc2) as f:
-                        mfma_pmc = json.load(f).get("halo_conv", {}).get("mfma_busy_frac")
+                        t2 = json.load(f)
+                    mfma_pmc = t2.get("halo16_conv", t2.get("halo_conv", {})).get("mfma_busy_frac")
         xn, xms, xfl = xhn + xon, xhms + xoms, xhfl + xofl
-        line["roofline"] = {"bound": "mfma", "kernel": "halo_conv_kernel (stride-1 3x3 conv forward + zero-boundary dgrad; "
-                            "the step's dominant kernel, ~30 % of its device time)",
+        line["roofline"] = {"bound": "mfma", "kernel": "halo16_conv_kernel (halo-resident stride-1 3x3 conv, 16x32-pixel tiles: forward + "
+                            "zero-boundary dgrad; the step's dominant kernel, ~30 % of its device time)",
                             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                             "traffic_source": traffic_src,
                             "mfma_busy_frac_pmc": mfma_pmc,      # same kernel, counters of a separate profiled run (profiles/)
                             "launches_per_step": hn / args.steps, "avg_launch_ms": hms / max(hn, 1),
                             "flops_per_launch": hfl / max(hn, 1),
-                            "timing": "HIP events around every halo_conv_kernel launch inside the timed region, on the launch stream",
+                            "timing": "HIP events around every halo16_conv_kernel / halo_conv_kernel launch inside the timed region, on the launch stream",
                             "all_conv_fwd_dgrad_kernels": {"achieved": xfl / (xms * 1e-3) / 1e12 if xms > 0 else 0.0,
                                                            "launches_per_step": xn / max(extra_steps, 1),
                                                            "avg_launch_ms": xms / max(xn, 1),

@@ -4,7 +4,7 @@
 # domains, and the program itself follows `--` (no env/bash wrappers).  Outputs land under gpurun_out/ and are turned
 # into the committed summaries by profiles/summarize.py.
 set -e
-tag=${1:-r01}
+tag=${1:-r02}
 root=$(pwd)
 mkdir -p "$root/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
