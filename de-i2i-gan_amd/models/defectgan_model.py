@@ -18,10 +18,14 @@ class DefectGanModel(BaseModel):
         super().__init__(opt)
         image_size = opt.image_size
         assert image_size & (image_size - 1) == 0, "Image size must be a power of 2"
-        if opt.style_norm_block_type != "spade":
-            raise NotImplementedError("only style_norm_block_type='spade' (the reference default) is implemented")
+        if opt.style_norm_block_type not in ("spade", "adain"):
+            raise NotImplementedError("style_norm_block_type: 'spade' (the reference default) and 'adain' are implemented; "
+                                      "'sean' is not (SURVEY.md section 8f rank 3)")
         self.netG = DefectGanGenerator(opt).to(opt.device, non_blocking=True)
         self.netD = DefectGanDiscriminator(opt).to(opt.device, non_blocking=True)
+        if opt.style_norm_block_type == "adain":         # style embedding network, trained by the G loss (defectgan_model.py:46-47)
+            from ..networks.extractor import StyleExtractor
+            self.netE = StyleExtractor(opt).to(opt.device, non_blocking=True)
         if self.opt.is_train or hasattr(opt, "clf_loss_type"):
             assert opt.clf_loss_type is not None, "clf_loss_type should be initialized in dataset"
             self.clf_loss_type = opt.clf_loss_type
@@ -146,13 +150,14 @@ class DefectGanModel(BaseModel):
     def _compute_generator_loss(self, bg_data, df_labels, df_data):
         """defectgan_model.py:173-249"""
         nm_labels, df_labels = self._get_labels(df_labels)
+        nm_feat, df_feat = self._style_feats(bg_data, nm_labels, df_labels, df_data)
         self.netG.clear_spade_cache()
-        if not os.environ.get("DEI2I_SPLIT_D"):
+        if not os.environ.get("DEI2I_SPLIT_D") and nm_feat is None:
             self.netG.prime_spade((df_labels, nm_labels))        # both label sets' SPADE tables in one pass
-        fake_defects, df_prob = self.netG(bg_data, df_labels)
-        recover_normals, rec_df_prob = self.netG(fake_defects, nm_labels)
-        fake_normals, nm_prob = self.netG(df_data, nm_labels)
-        recover_defects, rec_nm_prob = self.netG(fake_normals, df_labels)
+        fake_defects, df_prob = self.netG(bg_data, df_labels, df_feat)
+        recover_normals, rec_df_prob = self.netG(fake_defects, nm_labels, nm_feat)
+        fake_normals, nm_prob = self.netG(df_data, nm_labels, nm_feat)
+        recover_defects, rec_nm_prob = self.netG(fake_normals, df_labels, df_feat)
 
         # The reference lets autograd compute (and then discards) the discriminator's weight gradients here; the
         # G optimizer never reads them and optimizers['D'].zero_grad() drops them, so they are skipped.
@@ -180,6 +185,7 @@ class DefectGanModel(BaseModel):
     def _compute_discriminator_loss(self, bg_data, df_labels, df_data):
         """defectgan_model.py:251-292"""
         nm_labels, df_labels = self._get_labels(df_labels)
+        nm_feat, df_feat = self._style_feats(bg_data, nm_labels, df_labels, df_data)
         self.netG.clear_spade_cache()
         with torch.no_grad():
             # (--add_noise with an INJECTED noise source -- the parity tests: keep the reference's two calls so that the
@@ -187,12 +193,13 @@ class DefectGanModel(BaseModel):
             #  draws the same i.i.d. N(0,1) field, just in one call)
             injected_noise = getattr(self.opt, "add_noise", False) and ops.noise_source is not None
             if self.netG.training or os.environ.get("DEI2I_SPLIT_D") or injected_noise:
-                fake_defects, _ = self.netG(bg_data, df_labels)
-                fake_normals, _ = self.netG(df_data, nm_labels)
+                fake_defects, _ = self.netG(bg_data, df_labels, df_feat)
+                fake_normals, _ = self.netG(df_data, nm_labels, nm_feat)
             else:
-                # netG is in eval mode here (defectgan_model.py:87-90): BatchNorm uses running statistics and SPADE's
+                # netG is in eval mode here (defectgan_model.py:87-90): BatchNorm uses running statistics and SPADE's / AdaIN's
                 # InstanceNorm is per sample, so one pass over both batches is the same function as two passes
-                fakes, _ = self.netG(torch.cat([bg_data, df_data], 0), torch.cat([df_labels, nm_labels], 0))
+                feats = None if nm_feat is None else torch.cat([df_feat, nm_feat], 0)
+                fakes, _ = self.netG(torch.cat([bg_data, df_data], 0), torch.cat([df_labels, nm_labels], 0), feats)
                 fake_defects, fake_normals = fakes.split([bg_data.shape[0], df_data.shape[0]])
         policy = getattr(self.opt, "diff_aug", "")            # defectgan_model.py:266-270: fakes first, then the real batches
         fake_defects, fake_normals = diff_augment(fake_defects.detach(), policy), diff_augment(fake_normals.detach(), policy)
@@ -213,6 +220,8 @@ class DefectGanModel(BaseModel):
     def _generate_fake(self, data, labels):
         """defectgan_model.py:302-314 (spade branch): labels (N,C) or a spatial (N,C,h,w) map"""
         self.netG.clear_spade_cache()
+        if self.opt.style_norm_block_type == "adain":            # defectgan_model.py:310-312
+            return self.netG(data, labels, self.netE(data, labels))
         return self.netG(data, self._expand_seg(labels))
 
     @staticmethod
@@ -229,3 +238,11 @@ class DefectGanModel(BaseModel):
         nm_labels = torch.zeros_like(df_labels)
         nm_labels[:, 0] = 1
         return self._expand_seg(nm_labels), self._expand_seg(df_labels)
+
+    def _style_feats(self, bg_data, nm_labels, df_labels, df_data):
+        """-> (nm_label_feat, df_label_feat): netE(bg, nm_labels) then netE(df, df_labels) for the AdaIN decoder
+        (defectgan_model.py:423-425), (None, None) for SPADE."""
+        if self.opt.style_norm_block_type != "adain":
+            return None, None
+        n = nm_labels.shape[0]
+        return self.netE(bg_data, nm_labels.reshape(n, -1)), self.netE(df_data, df_labels.reshape(n, -1))

@@ -380,11 +380,57 @@ class SPADE(nn.Module):
             off += n
 
 
+class AdaIN(nn.Module):
+    """normalization.py:40-73 (denorm_type 'linear'): ``IN(x) * (1 + gamma) + beta`` with per-(n, c) gamma / beta from two
+    Linear layers on the style feature (N, hidden_nc) of the StyleExtractor.  That is SPADE with a gamma / beta that does
+    not vary over space, so it runs on the SPADE kernels: the (N, 5, 5, 2C) border-class table holds the same (gamma | beta)
+    in all 25 classes (autograd sums the table's gradient back over them); ReLU and a preceding upsample are fused like in
+    ``SPADE``.  The two Linear layers -- (N x hidden_nc) by (hidden_nc x C) -- go through torch's library GEMM."""
+
+    def __init__(self, norm_nc, hidden_nc=None, norm_layer=None, denorm_type="linear"):
+        super().__init__()
+        if denorm_type != "linear":
+            raise NotImplementedError("AdaIN: only denorm_type 'linear' is used by the reference's decoder blocks")
+        assert hidden_nc is not None, "hidden_nc should be set when denorm_type is linear."
+        self.norm_nc, self.hidden_nc, self.denorm_type = norm_nc, hidden_nc, denorm_type
+        self.param_free_norm = Act("instance_norm(affine=False)")
+        self.mlp_gamma = nn.Linear(hidden_nc, norm_nc)
+        self.mlp_beta = nn.Linear(hidden_nc, norm_nc)
+
+    def _class_table(self, style_feat, prec, c_stride):
+        n = style_feat.size(0)
+        assert style_feat.size(1) == self.hidden_nc, "The channel of style feature is not equal to hidden_nc."
+        feat = style_feat.view(n, self.hidden_nc).float()
+        gb = torch.cat([nn.functional.pad(self.mlp_gamma(feat), (0, c_stride - self.norm_nc)),
+                        nn.functional.pad(self.mlp_beta(feat), (0, c_stride - self.norm_nc))], dim=1)     # (N, 2 * c_stride)
+        return gb.to(prec.dtype).view(n, 1, 1, 2 * c_stride).expand(n, 5, 5, 2 * c_stride).contiguous()
+
+    def fused_conv(self, x, style_feat, conv, up=False, skip=False, stats=False):
+        """conv(self(x, style_feat, up)) -- with skip: (that, x) -- see SPADE.fused_conv"""
+        prec = ops.precision_of(x)
+        gb = self._class_table(style_feat, prec, x.shape[-1])
+        if type(conv) is Conv2d and conv.bias is None:
+            wt, geom = conv.weight, conv.geom(up)
+            need_grad = torch.is_grad_enabled() and (x.requires_grad or wt.requires_grad or gb.requires_grad)
+            mode = ops.spade_conv_supported(x, wt, geom, need_grad)
+            if mode is not None:
+                return ops.spade_conv(x, gb, wt, conv._packed, geom, skip=skip, stats=stats, mode=mode)
+        if skip:
+            z, xs = ops.spade_relu(x, gb, up, 1, skip=True)
+            return conv(z, stats=stats), xs
+        return conv(ops.spade_relu(x, gb, up, 1), stats=stats)
+
+    def forward(self, x, style_feat, up=False, skip=False):
+        return ops.spade_relu(x, self._class_table(style_feat, ops.precision_of(x), x.shape[-1]), up, 1, skip=skip)
+
+
 def _style_norm(style_norm_block_type, label_nc, f, hidden_nc):
-    if style_norm_block_type != "spade":
-        raise NotImplementedError(f"style_norm_block_type [{style_norm_block_type}] is not implemented yet "
-                                  "(SURVEY.md section 8f rank 3: SEAN / AdaIN)")
-    return SPADE(label_nc, f, hidden_nc=hidden_nc)
+    if style_norm_block_type == "spade":
+        return SPADE(label_nc, f, hidden_nc=hidden_nc)
+    if style_norm_block_type == "adain":
+        return AdaIN(f, hidden_nc=hidden_nc)
+    raise NotImplementedError(f"style_norm_block_type [{style_norm_block_type}] is not implemented yet "
+                              "(SURVEY.md section 8f rank 3: SEAN)")
 
 
 class NormConvBlock(nn.Module):
@@ -406,7 +452,8 @@ class NormConvBlock(nn.Module):
 
     def forward(self, x, labels, style_feat=None, out_stats=False):
         """``out_stats``: another norm layer reads the output next (the following NormConvBlock's SPADE)."""
-        return self.noise(self.norm.fused_conv(x, labels, self.conv, up=self.up_scale, stats=out_stats))
+        cond = style_feat if self.style_norm_block_type == "adain" else labels     # norm_forward, architecture.py:246-254
+        return self.noise(self.norm.fused_conv(x, cond, self.conv, up=self.up_scale, stats=out_stats))
 
 
 class NormResBlock(nn.Module):
@@ -436,12 +483,13 @@ class NormResBlock(nn.Module):
 
     def forward(self, x, labels, style_feat=None, out_stats=False):
         # norm_0 hands x through (xs) so that the identity branch's gradient is added inside its backward kernel
+        cond = style_feat if self.style_norm_block_type == "adain" else labels     # norm_forward, architecture.py:363-371
         if x.is_contiguous():
-            h, xs = self.norm_0.fused_conv(x, labels, self.conv_0, skip=True, stats=True)
+            h, xs = self.norm_0.fused_conv(x, cond, self.conv_0, skip=True, stats=True)
         else:
-            h, xs = self.norm_0.fused_conv(x, labels, self.conv_0, stats=True), x
+            h, xs = self.norm_0.fused_conv(x, cond, self.conv_0, stats=True), x
         h = self.noise_0(h)
-        h = self.noise_1(self.norm_1.fused_conv(h, labels, self.conv_1))
+        h = self.noise_1(self.norm_1.fused_conv(h, cond, self.conv_1))
         return ops.add(h, xs, stats=out_stats)
 
 

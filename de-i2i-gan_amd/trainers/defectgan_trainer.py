@@ -37,13 +37,20 @@ class DefectGanTrainer(BaseTrainer):
     def _train_generator_once(self, bg_data, df_labels, df_data):
         """defectgan_trainer.py:138-168"""
         self.optimizers["G"].zero_grad()
+        with_e = "E" in self.optimizers                  # adain: the StyleExtractor is trained by the G loss (:140-141,161-163)
+        if with_e:
+            self.optimizers["E"].zero_grad()
         gan_loss, clf_loss, rec_loss, sd_cyc_loss, sd_con_loss = self.model("generator", bg_data, df_labels, df_data)
         g_loss = gan_loss + clf_loss * self.loss_weights["clf_g"] + rec_loss * self.loss_weights["rec"] + \
             sd_cyc_loss * self.loss_weights["sd_cyc"] + sd_con_loss * self.loss_weights["sd_con"]
         g_loss.backward()
         if self.reducer is not None:
             self.reducer.reduce(self.model.netG)
+            if with_e:
+                self.reducer.reduce(self.model.netE)
         self.optimizers["G"].step()
+        if with_e:
+            self.optimizers["E"].step()
         if self.reducer is not None:
             self.reducer.broadcast_buffers(self.model.netG)      # BatchNorm running stats follow rank 0
         self._record([("gan", "G"), ("clf", "G"), ("aux", "rec"), ("aux", "cyc"), ("aux", "con")],

@@ -47,6 +47,8 @@ class Cfg:
     use_spectral: bool = False                          # --use_spectral (architecture.py:68-72,109-112,238-239,338-341)
     add_noise: bool = False                             # --add_noise (architecture.py:207-211,283-288,374-389)
     diff_aug: str = ""                                  # --diff_aug policy list (utils/diffaug.py; defectgan_model.py:200-203,266-270)
+    style_norm: str = "spade"                           # --style_norm_block_type: spade | adain (generator.py:140-152,179-191)
+    latent_dim: int = 16                                # adain: StyleExtractor input = [labels | N(0,1) noise] (extractor.py:36-96)
 
 
 # --------------------------------------------------------------------------- #
@@ -180,6 +182,37 @@ def spade(S: Dict[str, Tensor], prefix: str, x: Tensor, seg: Tensor) -> Tensor:
     return normalized * (1 + gamma) + beta
 
 
+def adain(S: Dict[str, Tensor], prefix: str, x: Tensor, style_feat: Tensor) -> Tensor:
+    """normalization.py:40-73 (denorm_type 'linear') -- IN(x)*(1+gamma)+beta with per-(n,c) gamma / beta from two Linear
+    layers on the style feature (N, hidden_nc)."""
+    normalized = instancenorm(x)
+    n, c = x.shape[:2]
+    gamma = F.linear(style_feat, S[prefix + ".mlp_gamma.weight"], S[prefix + ".mlp_gamma.bias"]).view(n, c, 1, 1)
+    beta = F.linear(style_feat, S[prefix + ".mlp_beta.weight"], S[prefix + ".mlp_beta.bias"]).view(n, c, 1, 1)
+    return normalized * (1 + gamma) + beta
+
+
+def style_norm(S: Dict[str, Tensor], prefix: str, x: Tensor, labels: Tensor, style_feat: Optional[Tensor]) -> Tensor:
+    """norm_forward of the decoder blocks (architecture.py:246-254,363-371): SPADE on the label map, or AdaIN on the
+    style feature -- told apart by the parameters the block owns."""
+    if prefix + ".mlp_shared.0.weight" in S:
+        return spade(S, prefix, x, labels)
+    return adain(S, prefix, x, style_feat)
+
+
+def style_extractor(SE: Dict[str, Tensor], x: Tensor, labels: Tensor, cfg: "Cfg") -> Tensor:
+    """StyleExtractor.forward with sean_alpha == 0 (extractor.py:44-49,88-92): five Linear layers (ReLU between them) on
+    [labels | noise], noise ~ N(0,1) of width latent_dim - label_nc (NOISE_SOURCE replaces the draw in the goldens)."""
+    shape = (labels.shape[0], cfg.latent_dim - cfg.label_nc)
+    noise = NOISE_SOURCE(shape) if NOISE_SOURCE is not None else torch.randn(shape)
+    h = torch.cat([labels.reshape(labels.shape[0], -1), noise.to(labels.dtype)], dim=1)
+    for i in range(5):
+        h = F.linear(h, SE[f"shared.{2 * i}.weight"], SE[f"shared.{2 * i}.bias"])
+        if i < 4:
+            h = torch.relu(h)
+    return h
+
+
 # --------------------------------------------------------------------------- #
 # blocks
 # --------------------------------------------------------------------------- #
@@ -231,7 +264,7 @@ def conv_block_bn(S, prefix: str, x: Tensor, *, k: int, stride: int, pad: int, a
 
 
 def generator_forward(S: Dict[str, Tensor], x: Tensor, labels: Tensor, cfg: Cfg,
-                      training: bool) -> Tuple[Tensor, Tensor]:
+                      training: bool, style_feat: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """DefectGanGenerator.forward -- generator.py:243-275 (skip_conn=False, cycle_gan=False).
 
     labels: (N, label_nc, h, w) float -- (N,label_nc,1,1) in training (defectgan_model.py:385-392).
@@ -250,10 +283,10 @@ def generator_forward(S: Dict[str, Tensor], x: Tensor, labels: Tensor, cfg: Cfg,
     # NormResBlocks (up_scale=False: norm_s/conv_s never run) -- architecture.py:343-357
     for i in range(cfg.num_res // 2):
         p = f"dec_res_blk.{i}"
-        h = conv2d(relu(spade(S, p + ".norm_0", feat, labels)), weight_of(S, p + ".conv_0.weight", training),
+        h = conv2d(relu(style_norm(S, p + ".norm_0", feat, labels, style_feat)), weight_of(S, p + ".conv_0.weight", training),
                    pad=1, mode="reflect")
         h = inject_noise(S, p + ".noise_0.weight", h)
-        h = conv2d(relu(spade(S, p + ".norm_1", h, labels)), weight_of(S, p + ".conv_1.weight", training),
+        h = conv2d(relu(style_norm(S, p + ".norm_1", h, labels, style_feat)), weight_of(S, p + ".conv_1.weight", training),
                    pad=1, mode="reflect")
         h = inject_noise(S, p + ".noise_1.weight", h)
         feat = h + feat
@@ -261,7 +294,7 @@ def generator_forward(S: Dict[str, Tensor], x: Tensor, labels: Tensor, cfg: Cfg,
     for i in range(cfg.num_scales):
         p = f"dec_blk.{i}"
         feat = upsample2x(feat)
-        feat = conv2d(relu(spade(S, p + ".norm", feat, labels)), weight_of(S, p + ".conv.weight", training),
+        feat = conv2d(relu(style_norm(S, p + ".norm", feat, labels, style_feat)), weight_of(S, p + ".conv.weight", training),
                       pad=1, mode="reflect")
         feat = inject_noise(S, p + ".noise.weight", feat)
     # NaN guard -- generator.py:266-267
@@ -351,13 +384,25 @@ def diff_augment(x: Tensor, policy: str) -> Tensor:
     return x
 
 
-def discriminator_losses(SG, SD, bg: Tensor, df_labels: Tensor, df: Tensor, cfg: Cfg):
+def _style_feats(SE, bg: Tensor, df_labels: Tensor, df: Tensor, cfg: Cfg):
+    """_get_label_and_style_feat, adain branch (defectgan_model.py:423-425): netE(bg, nm_labels) first, then netE(df, df_labels)."""
+    if SE is None:
+        return None, None
+    nm = torch.zeros_like(df_labels)
+    nm[:, 0] = 1
+    nm_feat = style_extractor(SE, bg, nm, cfg)
+    df_feat = style_extractor(SE, df, df_labels, cfg)
+    return nm_feat, df_feat
+
+
+def discriminator_losses(SG, SD, bg: Tensor, df_labels: Tensor, df: Tensor, cfg: Cfg, SE=None):
     """DefectGanModel._compute_discriminator_loss -- defectgan_model.py:251-292.
-    netD.train(); netG.eval() (:87-90) -> G's BatchNorm uses running stats."""
+    netD.train(); netG.eval() (:87-90) -> G's BatchNorm uses running stats.  SE: the StyleExtractor's state (adain)."""
     nm_l, df_l = _labels(df_labels)
+    nm_f, df_f = _style_feats(SE, bg, df_labels, df, cfg)
     with torch.no_grad():
-        fake_defects, _ = generator_forward(SG, bg, df_l, cfg, training=False)
-        fake_normals, _ = generator_forward(SG, df, nm_l, cfg, training=False)
+        fake_defects, _ = generator_forward(SG, bg, df_l, cfg, training=False, style_feat=df_f)
+        fake_normals, _ = generator_forward(SG, df, nm_l, cfg, training=False, style_feat=nm_f)
     fake_defects, fake_normals = diff_augment(fake_defects, cfg.diff_aug), diff_augment(fake_normals, cfg.diff_aug)
     df, bg = diff_augment(df, cfg.diff_aug), diff_augment(bg, cfg.diff_aug)          # defectgan_model.py:266-270
     fd_src, _ = discriminator_forward(SD, fake_defects, cfg, training=True)      # netD.train(): 4 calls, in this order
@@ -372,14 +417,15 @@ def discriminator_losses(SG, SD, bg: Tensor, df_labels: Tensor, df: Tensor, cfg:
     return gan, clf
 
 
-def generator_losses(SG, SD, bg: Tensor, df_labels: Tensor, df: Tensor, cfg: Cfg):
+def generator_losses(SG, SD, bg: Tensor, df_labels: Tensor, df: Tensor, cfg: Cfg, SE=None):
     """DefectGanModel._compute_generator_loss -- defectgan_model.py:173-249.
     netD.eval(); netG.train() (:83-86) -> BatchNorm uses batch stats, running stats updated 4x."""
     nm_l, df_l = _labels(df_labels)
-    fake_defects, df_prob = generator_forward(SG, bg, df_l, cfg, training=True)
-    recover_normals, rec_df_prob = generator_forward(SG, fake_defects, nm_l, cfg, training=True)
-    fake_normals, nm_prob = generator_forward(SG, df, nm_l, cfg, training=True)
-    recover_defects, rec_nm_prob = generator_forward(SG, fake_normals, df_l, cfg, training=True)
+    nm_f, df_f = _style_feats(SE, bg, df_labels, df, cfg)
+    fake_defects, df_prob = generator_forward(SG, bg, df_l, cfg, training=True, style_feat=df_f)
+    recover_normals, rec_df_prob = generator_forward(SG, fake_defects, nm_l, cfg, training=True, style_feat=nm_f)
+    fake_normals, nm_prob = generator_forward(SG, df, nm_l, cfg, training=True, style_feat=nm_f)
+    recover_defects, rec_nm_prob = generator_forward(SG, fake_normals, df_l, cfg, training=True, style_feat=df_f)
     fd_src, fd_cls = discriminator_forward(SD, diff_augment(fake_defects, cfg.diff_aug), cfg)     # defectgan_model.py:200-205
     fn_src, fn_cls = discriminator_forward(SD, diff_augment(fake_normals, cfg.diff_aug), cfg)
     ones = torch.ones_like(fd_src)
@@ -442,23 +488,32 @@ def _grads(loss: Tensor, S: Dict[str, Tensor]) -> Dict[str, Optional[Tensor]]:
     return dict(zip(keys, gs))
 
 
-def train_discriminator_once(SG, SD, stD: AdamState, bg, df_labels, df, cfg: Cfg, scale: float = 1.0):
+def train_discriminator_once(SG, SD, stD: AdamState, bg, df_labels, df, cfg: Cfg, scale: float = 1.0, SE=None):
     """_train_discriminator_once -- defectgan_trainer.py:170-180. Returns (gan, clf, grads)."""
     for k in param_keys(SD):
         SD[k].requires_grad_(True)
-    gan, clf = discriminator_losses(SG, SD, bg, df_labels, df, cfg)
+    gan, clf = discriminator_losses(SG, SD, bg, df_labels, df, cfg, SE)
     d_loss = gan + clf * cfg.loss_weight[0]
     grads = _grads(d_loss * scale, SD)
     return gan.detach(), clf.detach(), grads
 
 
-def train_generator_once(SG, SD, stG: AdamState, bg, df_labels, df, cfg: Cfg, scale: float = 1.0):
-    """_train_generator_once -- defectgan_trainer.py:138-168. Returns (5 losses, grads)."""
+def train_generator_once(SG, SD, stG: AdamState, bg, df_labels, df, cfg: Cfg, scale: float = 1.0, SE=None):
+    """_train_generator_once -- defectgan_trainer.py:138-168. Returns (5 losses, grads); with SE (adain: the StyleExtractor
+    is trained by the G loss through optimizers['E']) -> (5 losses, grads of G, grads of E)."""
     for k in param_keys(SG):
         SG[k].requires_grad_(True)
-    gan, clf, rec, cyc, con = generator_losses(SG, SD, bg, df_labels, df, cfg)
+    if SE is not None:
+        for k in param_keys(SE):
+            SE[k].requires_grad_(True)
+    gan, clf, rec, cyc, con = generator_losses(SG, SD, bg, df_labels, df, cfg, SE)
     w = cfg.loss_weight
     g_loss = gan + clf * w[1] + rec * w[2] + cyc * w[3] + con * w[4]
+    if SE is not None:
+        keys_g, keys_e = param_keys(SG), param_keys(SE)
+        gs = torch.autograd.grad(g_loss * scale, [SG[k] for k in keys_g] + [SE[k] for k in keys_e], allow_unused=True)
+        return (tuple(t.detach() for t in (gan, clf, rec, cyc, con)), dict(zip(keys_g, gs[:len(keys_g)])),
+                dict(zip(keys_e, gs[len(keys_g):])))
     grads = _grads(g_loss * scale, SG)
     return tuple(t.detach() for t in (gan, clf, rec, cyc, con)), grads
 
@@ -489,6 +544,12 @@ def generator_state_shapes(cfg: Cfg) -> Dict[str, Tuple[int, ...]]:
         sh[prefix + ".num_batches_tracked"] = ()
 
     def sp(prefix, c):
+        if cfg.style_norm == "adain":                   # normalization.py:52-53: two Linear(hidden_nc, norm_nc)
+            sh[prefix + ".mlp_gamma.weight"] = (c, cfg.hidden_nc)
+            sh[prefix + ".mlp_gamma.bias"] = (c,)
+            sh[prefix + ".mlp_beta.weight"] = (c, cfg.hidden_nc)
+            sh[prefix + ".mlp_beta.bias"] = (c,)
+            return
         sh[prefix + ".mlp_shared.0.weight"] = (cfg.hidden_nc, cfg.label_nc, 3, 3)
         sh[prefix + ".mlp_shared.0.bias"] = (cfg.hidden_nc,)
         sh[prefix + ".mlp_gamma.weight"] = (c, cfg.hidden_nc, 3, 3)
@@ -533,6 +594,17 @@ def generator_state_shapes(cfg: Cfg) -> Dict[str, Tuple[int, ...]]:
         c //= 2
     sh["foreground_head.de_conv_block.0.weight"] = (3, c, 3, 3)
     sh["distribution_head.de_conv_block.0.weight"] = (1, c, 3, 3)
+    return sh
+
+
+def extractor_state_shapes(cfg: Cfg) -> Dict[str, Tuple[int, ...]]:
+    """StyleExtractor.state_dict() with sean_alpha == 0 (extractor.py:44-49): Linear(latent_dim, 256), 3 x Linear(256, 256),
+    Linear(256, hidden_nc) at Sequential indices 0, 2, 4, 6, 8."""
+    dims = [cfg.latent_dim, 256, 256, 256, 256, cfg.hidden_nc]
+    sh: Dict[str, Tuple[int, ...]] = {}
+    for i in range(5):
+        sh[f"shared.{2 * i}.weight"] = (dims[i + 1], dims[i])
+        sh[f"shared.{2 * i}.bias"] = (dims[i + 1],)
     return sh
 
 
@@ -581,6 +653,11 @@ def formula_tensor(key: str, shape: Tuple[int, ...], gain: float = 1.0) -> Tenso
     if len(shape) == 4:
         fan_in = shape[1] * shape[2] * shape[3]
         scale = gain * math.sqrt(2.0 / fan_in) * 1.25
+        if ".mlp_gamma." in key or ".mlp_beta." in key:
+            scale *= 0.5
+        return (scale * base).float().reshape(shape)
+    if len(shape) == 2:                                    # Linear weights (AdaIN's mlp_gamma / mlp_beta, the StyleExtractor)
+        scale = gain * math.sqrt(2.0 / shape[1])
         if ".mlp_gamma." in key or ".mlp_beta." in key:
             scale *= 0.5
         return (scale * base).float().reshape(shape)

@@ -1,0 +1,107 @@
+"""The AdaIN decoder variant (--style_norm_block_type adain with the MLP StyleExtractor, sean_alpha = 0; SURVEY.md
+section 8f rank 3; reference: models/networks/normalization.py:40-73, extractor.py:36-96, defectgan_model.py:46-47,310-312,
+423-425, defectgan_trainer.py:140-141,161-163) against the fixture made by the reference's own trainer
+(tests/golden/gen_adain_golden.py -> t5_img64_b2_adain): state_dict keys of G / D / E, the inference-mode forward, and two
+D+G steps (losses, post-step parameter norms of all three networks).  The CPU half pins the oracle to the same fixture."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import formula_fill, make_opt
+from oracle import defectgan_oracle as O
+
+GOLD = Path(__file__).resolve().parent / "golden"
+NAME = "t5_img64_b2_adain"
+DEV = "cuda:0"
+
+
+def load():
+    meta = json.loads((GOLD / f"{NAME}.json").read_text())
+    arr = np.load(GOLD / f"{NAME}.npz")
+    c = meta["config"]
+    cfg = O.Cfg(image_size=c["image_size"], ngf=c["ngf"], ndf=c["ndf"], num_layers=c["num_layers"], hidden_nc=c["hidden_nc"],
+                style_norm="adain", latent_dim=c["latent_dim"])
+    return meta, arr, c, cfg
+
+
+def maxrel(a, b):
+    a, b = torch.as_tensor(np.asarray(a)).double(), torch.as_tensor(np.asarray(b)).double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+def test_oracle_adain_matches_the_reference_fixture():
+    meta, arr, c, cfg = load()
+    O.NOISE_SOURCE = O.shape_noise
+    try:
+        SG, SD, SE = (O.make_state(f(cfg)) for f in (O.generator_state_shapes, O.discriminator_state_shapes, O.extractor_state_shapes))
+        assert list(SG.keys()) == meta["G_keys"] and list(SE.keys()) == meta["E_keys"]
+        bg, labels, df = O.synthetic_batch(c["batch"], c["image_size"])
+        with torch.no_grad():
+            feat = O.style_extractor(SE, bg, labels, cfg)
+            out, prob = O.generator_forward(SG, bg, labels.reshape(c["batch"], 6, 1, 1), cfg, training=False, style_feat=feat)
+            src, cls = O.discriminator_forward(SD, out, cfg)
+        for got, key in ((feat, "E_feat"), (out, "G_out_eval"), (prob, "G_prob_eval"), (src, "D_src"), (cls, "D_cls")):
+            assert maxrel(got, arr[key]) < 1e-4, key
+        stG, stD, stE = O.AdamState(), O.AdamState(), O.AdamState()
+        d_gan, d_clf, gD = O.train_discriminator_once(SG, SD, stD, bg, labels, df, cfg, SE=SE)
+        O.adam_update(SD, gD, stD, cfg)
+        gl, gG, gE = O.train_generator_once(SG, SD, stG, bg, labels, df, cfg, SE=SE)
+        got = [float(d_gan), float(d_clf)] + [float(v) for v in gl]
+        assert maxrel(np.array(got), arr["losses"][0]) < 1e-5
+        assert all(gE[k] is not None for k in meta["E_grad_keys"])
+    finally:
+        O.NOISE_SOURCE = None
+
+
+def _build(pname):
+    from de_i2i_gan_amd import ops
+    from de_i2i_gan_amd.trainers.defectgan_trainer import DefectGanTrainer
+    meta, arr, c, cfg = load()
+    ops.noise_source = O.shape_noise
+    tr = DefectGanTrainer(make_opt(c, DEV, pname, style_norm_block_type="adain", sean_alpha=0, latent_dim=c["latent_dim"]))
+    for net in (tr.model.netG, tr.model.netD, tr.model.netE):
+        formula_fill(net)
+    return tr, meta, arr, c
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pname", ["f32", "bf16"])
+def test_adain_forward_and_two_steps_match_the_reference_fixture(pname):
+    from de_i2i_gan_amd import ops
+    try:
+        tr, meta, arr, c = _build(pname)
+        G, D, E = tr.model.netG, tr.model.netD, tr.model.netE
+        assert list(G.state_dict().keys()) == meta["G_keys"] and list(D.state_dict().keys()) == meta["D_keys"]
+        assert list(E.state_dict().keys()) == meta["E_keys"] and sorted(tr.optimizers) == ["D", "E", "G"]
+        bg, labels, df = O.synthetic_batch(c["batch"], c["image_size"])
+        out, prob = tr.model("inference", bg, labels)
+        with torch.no_grad():
+            src, cls = D(out)
+        for got, key in ((out, "G_out_eval"), (prob, "G_prob_eval"), (src, "D_src"), (cls, "D_cls")):
+            if pname == "f32":
+                assert maxrel(got.cpu(), arr[key]) < 1e-3, key
+            else:       # bf16 on the formula-filled 8-channel nets (see test_model_gpu.py): rms 0.3, single elements 4.2 x that
+                a, b = got.double().cpu(), torch.as_tensor(arr[key]).double()
+                if key.startswith("G_"):
+                    assert ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item() < 0.3 and maxrel(a, b) < 1.26, key
+                else:   # a handful of near-zero logits computed on the bf16 G output: absolute
+                    assert float((a - b).abs().max()) < 0.1, key
+        losses = []
+        for it in range(2):
+            tr.step(bg, labels, df)
+            L = tr.losses
+            losses.append([L["gan"]["D"][-1], L["clf"]["D"][-1], L["gan"]["G"][-1], L["clf"]["G"][-1], L["aux"]["rec"][-1],
+                           L["aux"]["cyc"][-1], L["aux"]["con"][-1]])
+        t1, t2 = (1e-4, 8e-2) if pname == "f32" else (6e-2, 0.4)
+        assert maxrel(np.array(losses[0]), arr["losses"][0]) < t1, (losses[0], arr["losses"][0].tolist())
+        assert maxrel(np.array(losses[1]), arr["losses"][1]) < t2, (losses[1], arr["losses"][1].tolist())
+        if pname == "f32":
+            for tag, net in (("G", G), ("D", D), ("E", E)):
+                sd = net.state_dict()
+                mine = np.array([float(sd[k].double().norm()) for k in meta[f"{tag}_check_keys"]])
+                assert maxrel(mine, arr[f"{tag}_post_norm"]) < 5e-2, tag
+    finally:
+        ops.noise_source = None
