@@ -338,6 +338,12 @@ int dei2i_conv2d_dgrad_input(const dei2i_conv* c, const void* dy, const void* wd
     const GatherDesc ring_frame = make_dgrad_desc(sh, c->CoutS, 0, 0);        // reflect: the padded frame
     sh.pad_mode = PAD_ZERO;
     const GatherDesc interior = make_dgrad_desc(sh, c->CoutS, 0, 0);          // zero: the input grid itself
+    if (c->dtype == DT_BF16 && c->kh == 3 && c->kw == 3 && p == 1) {
+      // large grids: the 16 x 32 tile kernel folds the ring itself (conv_halo16.hip FOLD); only the 4 corners remain
+      hipError_t ef = halo16_conv(interior, dy, wd_packed, c->Cin, nullptr, dx, c->CinS, ACT_NONE, num_cu(), st, nullptr, nullptr, true);
+      if (ef == hipSuccess) return (int)reflect_corners(dy, wd_packed, dx, c->N, c->H, c->W, c->CoutS, c->Cin, c->CinS, st);
+      if (ef != hipErrorNotSupported) return (int)ef;
+    }
     hipError_t e = gather_gemm(c->dtype, interior, dy, wd_packed, c->Cin, nullptr, dx, ws, ws_bytes, c->CinS, ACT_NONE, st);
     if (e != hipSuccess) return (int)e;
     const int OH = c->H + 2 * p, OW = c->W + 2 * p;

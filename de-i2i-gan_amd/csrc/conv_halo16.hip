@@ -57,7 +57,16 @@ DEI2I_D int sw16(int row) { return ((row >> 2) & 1) << 1; }
 // DIAG: a diagnostic build (option "v2_ablate" = 6) that accumulates s_memtime stamps per wave into `dbg`:
 //   [0] loop cycles  [1] loop s_memrealtime ticks  [2] k-steps  [3] whole-kernel cycles
 //   [4] M: fragment reads issued  [5] M: vmcnt wait  [6] M: lgkmcnt wait  [7] M: barrier  [8] C: MFMA + DMA issue  [9] C: barrier
-template <int BN, int STAGES, bool DIAG = false>
+// FOLD: this launch is the input gradient of a REFLECT-padded conv (architecture.py:51-56: pad 1).  The zero-boundary dgrad
+// on the input grid misses what the padded frame's ring (row -1 / H, column -1 / W) reflects back onto rows 1 / H-2 and
+// columns 1 / W-2 -- conv_api.hip computes that ring as a second small GEMM + split-K finalize + border fold (three
+// launches, ~30 us per conv).  Here the tiles that touch the image border compute their piece of the ring themselves:
+// ring row -1 over the tile's 32 columns is dx[-1][x] = sum_tx W[ky=0][kx=tx]^T dy[0][x+1-tx] -- the tile's own halo,
+// addressed one tile row above row 0, with the ONE tap row that still reads inside dy -- as two extra 16-pixel blocks
+// (waves wm = 0, 1), ring column -1 / W over the tile's 16 rows as one extra block of 16 rows x 1 column (waves wm = 2 /
+// 3); each is 4 extra MFMAs per wave in 3 of the 9 taps, accumulated apart and added to rows 1 / 14 or columns 1 / 30 of
+// the LDS-staged tile before it is written.  The four frame CORNERS (one pixel each) are left to reflect_corner_kernel.
+template <int BN, int STAGES, bool DIAG = false, bool FOLD = false>
 __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, const bf16_t* __restrict__ src,
                                                           const bf16_t* __restrict__ wgt, const int wrows,
                                                           const float* __restrict__ bias, bf16_t* __restrict__ out,
@@ -187,6 +196,27 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
     const int row = wn * WTN + j * 16 + l16;
     b_addr[j] = row * 64 + ((kg ^ sw16(row)) << 4);
   }
+  // FOLD: this wave's ring block (wave-uniform kind: 0 none, 1 top row, 2 bottom row, 3 left column, 4 right column)
+  int ring_kind = 0, ring_pix0 = 0;
+  acc_t racc[CB];
+  u32x4 ring_frag;
+  bool ring_live = false;
+  if constexpr (FOLD) {
+#pragma unroll
+    for (int j = 0; j < CB; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) racc[j][e] = 0.f;
+    if (wm < 2) {
+      if (y0 == 0) { ring_kind = 1; ring_pix0 = -hwd + wm * 16 + l16; }
+      else if (y0 + H16_TH == g.Ho) { ring_kind = 2; ring_pix0 = H16_TH * hwd + wm * 16 + l16; }
+    } else if (wm == 2) {
+      if (x0 == 0) { ring_kind = 3; ring_pix0 = l16 * hwd - 1; }
+    } else if (x0 + H16_TW == g.Wo) {
+      ring_kind = 4;
+      ring_pix0 = l16 * hwd + H16_TW;
+    }
+    ring_kind = __builtin_amdgcn_readfirstlane(ring_kind);
+  }
   int ld_tx = 0, ld_ty = 0, ld_slice = 0, ld_stage = 0;
   const int step_x = g.xs > 0 ? 1 : -1, step_y = g.ys > 0 ? hwd : -hwd;
   int ld_toff = (g.ys > 0 ? 0 : (g.th - 1) * hwd) + (g.xs > 0 ? 0 : g.tw - 1);     // halo pixel offset of tap (0,0)
@@ -199,6 +229,14 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
     for (int i = 0; i < PB; ++i) {
       const int pix = a_pix0[i] + ld_toff;
       f.a[i] = *reinterpret_cast<const u32x4*>(hb + pix * 64 + ((kg ^ sw16(pix)) << 4));
+    }
+    if constexpr (FOLD) {
+      // the ring row / column only sees the tap row / column that still reads inside dy (dgrad taps: dy row = oy + 1 - ty)
+      ring_live = ring_kind == 1 ? ld_ty == 0 : (ring_kind == 2 ? ld_ty == 2 : (ring_kind == 3 ? ld_tx == 0 : (ring_kind == 4 && ld_tx == 2)));
+      if (ring_live) {
+        const int pix = ring_pix0 + ld_toff;
+        ring_frag = *reinterpret_cast<const u32x4*>(hb + pix * 64 + ((kg ^ sw16(pix)) << 4));
+      }
     }
 #pragma unroll
     for (int j = 0; j < CB; ++j) f.b[j] = *reinterpret_cast<const u32x4*>(sb + b_addr[j]);
@@ -258,6 +296,14 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
       for (int jj = 0; jj < CB; ++jj)
         acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.b[jj]), __builtin_bit_cast(bf16x8, f.a[i]),
                                                              acc[i][jj], 0, 0, 0);
+    if constexpr (FOLD) {
+      if (ring_live) {
+#pragma unroll
+        for (int jj = 0; jj < CB; ++jj)
+          racc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.b[jj]), __builtin_bit_cast(bf16x8, ring_frag),
+                                                             racc[jj], 0, 0, 0);
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
     const unsigned long long q1 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
     __builtin_amdgcn_s_barrier();
@@ -325,6 +371,27 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
       }
     }
     __syncthreads();
+    if constexpr (FOLD) {
+      // the ring's reflection: row ring -> tile row 1 (top) / 14 (bottom), then -- after a barrier: pixel (1,1) takes both --
+      // column ring -> column 1 (left) / 30 (right) of each row
+      auto ring_add = [&](int row) {
+#pragma unroll
+        for (int j = 0; j < CB; ++j) {
+          u32x2* p = reinterpret_cast<u32x2*>(ctile + row * CROW + (wn * WTN + j * 16 + 4 * kg) * 2);
+          const u32x2 v = *p;
+          u32x2 o;
+          o.x = (uint32_t)f32_to_bf16(__uint_as_float(v.x << 16) + racc[j][0]) |
+                ((uint32_t)f32_to_bf16(__uint_as_float(v.x & 0xffff0000u) + racc[j][1]) << 16);
+          o.y = (uint32_t)f32_to_bf16(__uint_as_float(v.y << 16) + racc[j][2]) |
+                ((uint32_t)f32_to_bf16(__uint_as_float(v.y & 0xffff0000u) + racc[j][3]) << 16);
+          *p = o;
+        }
+      };
+      if ((ring_kind == 1 && half == 0) || (ring_kind == 2 && half == 1)) ring_add((ring_kind == 1 ? 1 : 6) * 32 + wm * 16 + l16);
+      __syncthreads();
+      if (ring_kind >= 3 && (l16 >> 3) == half) ring_add((l16 & 7) * 32 + (ring_kind == 3 ? 1 : H16_TW - 2));
+      __syncthreads();
+    }
     if (ncol < ldc) {
 #pragma unroll
       for (int p = 0; p < 256 / RPP; ++p) {
@@ -726,25 +793,57 @@ static hipError_t launch_halo16w4(const GatherDesc& g, const void* src, const vo
   return hipGetLastError();
 }
 
+// The four corners of the padded frame of a reflect-padded 3x3 conv's input gradient: frame pixel (-1,-1) is the image of
+// input pixel (1,1) and only output (0,0) reads it, through kernel tap (0,0): dx[1][1] += W[:,:,0,0]^T dy[0][0]; likewise
+// (-1,W) -> dx[1][W-2] += W[..,0,2]^T dy[0][W-1], (H,-1) -> dx[H-2][1] += W[..,2,0]^T dy[H-1][0], (H,W) -> dx[H-2][W-2] +=
+// W[..,2,2]^T dy[H-1][W-1].  wd: the dgrad-packed weights [Cin][9][CoutS].  grid (4, N); runs after the FOLD launch.
+__global__ __launch_bounds__(256) void reflect_corner_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ wd,
+                                                             bf16_t* __restrict__ dx, int H, int W, int CoutS, int Cin, int CinS) {
+  extern __shared__ float dyv[];
+  const int corner = blockIdx.x, n = blockIdx.y;
+  const int ky = corner >> 1 ? 2 : 0, kx = corner & 1 ? 2 : 0;
+  const int sy = ky ? H - 1 : 0, sx = kx ? W - 1 : 0;             // dy pixel read
+  const int ty = ky ? H - 2 : 1, tx = kx ? W - 2 : 1;             // dx pixel written
+  const bf16_t* src = dy + ((size_t)(n * H + sy) * W + sx) * CoutS;
+  for (int c = threadIdx.x; c < CoutS; c += 256) dyv[c] = bf16_to_f32(src[c]);
+  __syncthreads();
+  bf16_t* dst = dx + ((size_t)(n * H + ty) * W + tx) * CinS;
+  for (int ci = threadIdx.x; ci < Cin; ci += 256) {
+    const bf16_t* wrow = wd + ((size_t)ci * 9 + ky * 3 + kx) * CoutS;
+    float s = 0.f;
+    for (int c = 0; c < CoutS; c += 8) {
+      float w8[8];
+      Elem<bf16_t>::unpack(*reinterpret_cast<const u32x4*>(wrow + c), w8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s = fmaf(w8[e], dyv[c + e], s);
+    }
+    dst[ci] = f32_to_bf16(bf16_to_f32(dst[ci]) + s);
+  }
+}
+
 extern int g_halo_bn, g_halo_stages;
-int g_halo16 = 1;              // A/B option "halo16": 0 = always the 8 x 32 tile kernel (conv_halo.hip)
+int g_halo16 = 1;
+int g_halo16_fold = 1;         // A/B option "halo16_fold": 0 = ring GEMM + finalize + border fold as separate launches              // A/B option "halo16": 0 = always the 8 x 32 tile kernel (conv_halo.hip)
 int g_halo16_stages = 8;
 
 template <int BN, int STAGES>
 static hipError_t launch_halo16(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out,
-                                int ldc, int act, hipStream_t st, float* stats, const void* ring = nullptr) {
+                                int ldc, int act, hipStream_t st, float* stats, const void* ring = nullptr, bool fold = false) {
   const int tiles_m = g.N * (g.Ho / H16_TH) * (g.Wo / H16_TW);
   const int tiles_n = (ldc + BN - 1) / BN;
   constexpr size_t loop_lds = 2 * (size_t)H16_HBYTES + (size_t)STAGES * BN * 64 + H16_GROUPS * 16 * sizeof(int);
   constexpr size_t epi_lds = 256 * (size_t)(BN * 2 + 16) + 512 * 16 * sizeof(float);
   const size_t lds = std::max(loop_lds, epi_lds);
-  const bool diag = g_v2_ablate == 6 && g_v2_dbg != nullptr && STAGES == 8;
+  const bool diag = g_v2_ablate == 6 && g_v2_dbg != nullptr && STAGES == 8 && !fold;
   auto kern = diag ? halo16_conv_kernel<BN, STAGES, STAGES == 8> : halo16_conv_kernel<BN, STAGES, false>;
-  static bool attr_done[2] = {false, false};
-  if (!attr_done[diag]) {
+  if (fold) kern = halo16_conv_kernel<BN, STAGES, false, STAGES == 8>;        // (instantiated for the shipped ring depth only)
+  if (fold && STAGES != 8) return hipErrorNotSupported;
+  static bool attr_done[3] = {false, false, false};
+  const int which = fold ? 2 : (diag ? 1 : 0);
+  if (!attr_done[which]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_done[diag] = true;
+    attr_done[which] = true;
   }
   count_launch(K_HALO16_CONV);
   prof_begin(PROF_HALO_CONV, 2.0 * (double)g.M * (double)(g.th * g.tw) * (double)g.Clog * (double)wrows, st);
@@ -757,8 +856,13 @@ static hipError_t launch_halo16(const GatherDesc& g, const void* src, const void
 
 // returns hipErrorNotSupported when the shape does not qualify (the caller goes on to the 8 x 32 tile kernel)
 // ring: see the kernel (SPADE -> upsample -> conv with z kept at the source resolution); only the 8-wave kernel takes it
+// fold: the launch is the interior input gradient of a reflect-padded 3x3 conv and also folds the frame's ring (not its
+// corners: reflect_corners) into the border rows / columns -- see the kernel
 hipError_t halo16_conv(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out, int ldc,
-                       int act, int num_cu, hipStream_t st, float* stats, const void* ring) {
+                       int act, int num_cu, hipStream_t st, float* stats, const void* ring, bool fold) {
+  if (fold && (!g_halo16_fold || g.ys >= 0 || g.xs >= 0 || g.pad_mode != PAD_ZERO || g.up || g.Ho < 2 * H16_TH || g.Wo < 2 * H16_TW ||
+               bias != nullptr || act != ACT_NONE || stats != nullptr || ring != nullptr || g_halo16 == 2))
+    return hipErrorNotSupported;
   if (!g_halo16 || g_halo_bn != 0 || g_halo_stages != 0) return hipErrorNotSupported;   // (the tile sweep is the 8 x 32 kernel's)
   if (g.sh != 1 || g.sw != 1 || (g.ys != 1 && g.ys != -1) || (g.xs != 1 && g.xs != -1)) return hipErrorNotSupported;
   if (g.th != 3 || g.tw != 3 || g.wK != g.K || g.wtw != g.tw) return hipErrorNotSupported;
@@ -774,13 +878,21 @@ hipError_t halo16_conv(const GatherDesc& g, const void* src, const void* wgt, in
     if (ldc >= 128) return launch_halo16w4<128, 8>(g, src, wgt, wrows, bias, out, ldc, act, st, stats);
     return launch_halo16w4<64, 8>(g, src, wgt, wrows, bias, out, ldc, act, st, stats);
   }
+  if (fold && g_halo16_stages != 8) return hipErrorNotSupported;
   if (ldc >= 128) {
     if (g_halo16_stages == 4) return launch_halo16<128, 4>(g, src, wgt, wrows, bias, out, ldc, act, st, stats);
     if (g_halo16_stages == 6) return launch_halo16<128, 6>(g, src, wgt, wrows, bias, out, ldc, act, st, stats);
-    return launch_halo16<128, 8>(g, src, wgt, wrows, bias, out, ldc, act, st, stats, ring);
+    return launch_halo16<128, 8>(g, src, wgt, wrows, bias, out, ldc, act, st, stats, ring, fold);
   }
   if (g_halo16_stages == 4) return launch_halo16<64, 4>(g, src, wgt, wrows, bias, out, ldc, act, st, stats);
-  return launch_halo16<64, 8>(g, src, wgt, wrows, bias, out, ldc, act, st, stats, ring);
+  return launch_halo16<64, 8>(g, src, wgt, wrows, bias, out, ldc, act, st, stats, ring, fold);
+}
+
+hipError_t reflect_corners(const void* dy, const void* wd_packed, void* dx, int N, int H, int W, int CoutS, int Cin, int CinS,
+                           hipStream_t st) {
+  hipLaunchKernelGGL(reflect_corner_kernel, dim3(4, N), dim3(256), (size_t)CoutS * sizeof(float), st, (const bf16_t*)dy,
+                     (const bf16_t*)wd_packed, (bf16_t*)dx, H, W, CoutS, Cin, CinS);
+  return hipGetLastError();
 }
 
 }  // namespace dei2i

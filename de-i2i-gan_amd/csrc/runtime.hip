@@ -16,7 +16,7 @@ extern int g_use_wgrad_thin;
 extern int g_wt_splits_per_cu;
 extern int g_halo_mfma32;
 extern int g_halo_bn, g_halo_stages;
-extern int g_halo16, g_halo16_stages;
+extern int g_halo16, g_halo16_stages, g_halo16_fold;
 extern unsigned long long* g_v2_dbg;
 static int g_cus = 256;
 void set_num_cu_rt(int n) { g_cus = n > 0 ? n : 256; }
@@ -98,6 +98,7 @@ int dei2i_set_option(const char* name, int value) {
     return 0;
   }
   if (std::string(name) == "halo16") { g_halo16 = value; return 0; }
+  if (std::string(name) == "halo16_fold") { g_halo16_fold = value; return 0; }
   if (std::string(name) == "halo16_stages") {
     if (value != 4 && value != 6 && value != 8) return DEI2I_ERR_BAD_ARG;
     g_halo16_stages = value;
