@@ -250,24 +250,29 @@ def main():
     sync()
     if red is not None:
         red.overlap_report()                          # drop the warm-up steps' events
-    # Inside the timed region only the DOMINANT kernel (halo_conv_kernel) is bracketed with HIP events -- two event records
-    # per launch break the back-to-back dispatch of the stream, and bracketing all ~600 conv launches of a step cost
-    # 2.4 ms of a 44.2 ms step (measured round 2, same box: 46.6 vs 44.2 ms/step); the other conv families only count
-    # launches and FLOPs there (no events) and are timed in a few EXTRA steps after the timed region.
+    # Inside the timed region only the DOMINANT kernel family (the halo-resident 3x3 conv) is bracketed with HIP events, and
+    # only every 5th of its launches (126 per step: 5 is coprime, so over the timed steps every launch of the step's sequence
+    # is sampled equally often) -- two event records per launch break the back-to-back dispatch of the stream: bracketing all
+    # ~600 conv launches of a step cost 2.4 ms of a 44.2 ms step, all 126 halo launches 0.9 ms (measured round 2, same box).
+    # The other conv families only count launches and FLOPs there (no events) and are timed in a few EXTRA steps afterwards.
+    HALO_SAMPLE = 5
     fams = (("gather_gemm", _lib.PROF_GATHER_GEMM), ("wgrad", _lib.PROF_WGRAD), ("halo", _lib.PROF_HALO_CONV))
 
     def collect():
+        """-> {family: (launches, FLOPs of all launches, event-bracketed launches, their ms, their FLOPs)}"""
         out = {}
         for name, fid in fams:
+            tn, tfl = ctypes.c_int64(), ctypes.c_double()
+            _lib.check(lib.dei2i_prof_collect_timed(fid, ctypes.byref(tn), ctypes.byref(tfl)), "prof_collect_timed")
             n, ms, fl = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
             _lib.check(lib.dei2i_prof_collect(fid, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)), "prof_collect")
-            out[name] = (n.value, ms.value, fl.value)
+            out[name] = (n.value, fl.value, tn.value, ms.value, tfl.value)
             lib.dei2i_prof_enable(fid, 0)
         return out
 
     if not args.no_roofline:
         for name, fid in fams:
-            lib.dei2i_prof_enable(fid, 1 if name == "halo" else 2)
+            lib.dei2i_prof_enable(fid, HALO_SAMPLE if name == "halo" else 2)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -319,14 +324,14 @@ def main():
         "losses_last_step": {k: round(v[-1], 5) for kind in tr.losses.values() for k, v in kind.items() if v},
     }
     if fam:
-        hn, hms, hfl = fam["halo"]                       # the dominant kernel family: the halo-resident stride-1 3x3 conv (fwd + dgrad)
-        on, _, ofl = fam["gather_gemm"]                  # the other conv forward / dgrad kernels (timed region: counts only)
-        wn, _, wfl = fam["wgrad"]
-        xhn, xhms, xhfl = fam_extra["halo"]              # all families with events, extra steps after the timed region
-        xon, xoms, xofl = fam_extra["gather_gemm"]
-        xwn, xwms, xwfl = fam_extra["wgrad"]
+        hn, hfl, htn, hms, htfl = fam["halo"]            # the dominant kernel family: the halo-resident stride-1 3x3 conv (fwd + dgrad)
+        on, ofl = fam["gather_gemm"][:2]                 # the other conv forward / dgrad kernels (timed region: counts only)
+        wn, wfl = fam["wgrad"][:2]
+        xhn, _, _, xhms, xhfl = fam_extra["halo"]        # all families with events on every launch, extra steps after the timed region
+        xon, _, _, xoms, xofl = fam_extra["gather_gemm"]
+        xwn, _, _, xwms, xwfl = fam_extra["wgrad"]
         peak = PEAK_TFLOPS[args.dtype]
-        ach = hfl / (hms * 1e-3) / 1e12 if hms > 0 else 0.0
+        ach = htfl / (hms * 1e-3) / 1e12 if hms > 0 else 0.0
         traffic, traffic_src, mfma_pmc = None, None, None
         if args.dtype == "bf16" and args.image_size == 256 and args.batch == 16:
             for tag in ("r02", "r01_g"):                  # newest committed rocprofv3 --pmc summaries (profiles/)
@@ -350,9 +355,10 @@ def main():
                             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                             "traffic_source": traffic_src,
                             "mfma_busy_frac_pmc": mfma_pmc,      # same kernel, counters of a separate profiled run (profiles/)
-                            "launches_per_step": hn / args.steps, "avg_launch_ms": hms / max(hn, 1),
-                            "flops_per_launch": hfl / max(hn, 1),
-                            "timing": "HIP events around every halo16_conv_kernel / halo_conv_kernel launch inside the timed region, on the launch stream",
+                            "launches_per_step": hn / args.steps, "avg_launch_ms": hms / max(htn, 1),
+                            "flops_per_launch": htfl / max(htn, 1), "event_bracketed_launches": htn,
+                            "timing": "HIP events around every %dth halo16_conv_kernel / halo_conv_kernel launch inside the timed region, "
+                                      "on the launch stream (%d of %d launches)" % (HALO_SAMPLE, htn, hn),
                             "all_conv_fwd_dgrad_kernels": {"achieved": xfl / (xms * 1e-3) / 1e12 if xms > 0 else 0.0,
                                                            "launches_per_step": xn / max(extra_steps, 1),
                                                            "avg_launch_ms": xms / max(xn, 1),

@@ -94,6 +94,7 @@ SIGNATURES = {
     "dei2i_adam_step": (c_int, [_P, c_int, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_float, _P]),
     "dei2i_prof_enable": (c_int, [c_int, c_int]),
     "dei2i_prof_collect": (c_int, [c_int, POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),
+    "dei2i_prof_collect_timed": (c_int, [c_int, POINTER(c_int64), POINTER(c_double)]),
     "dei2i_conv2d_fused_supported": (c_int, [_CD, c_int]),
     "dei2i_conv2d_stats_chunks": (c_int, [_CD]),
     "dei2i_conv2d_fwd_fused": (c_int, [_CD, _P, _P, _P, c_int, _P, _PD, _P, _P]),

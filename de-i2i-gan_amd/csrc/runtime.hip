@@ -25,6 +25,9 @@ int num_cu() { return g_cus; }
 struct ProfState {
   bool on = false;
   bool events = true;          // false: count launches and FLOPs only (no HIP events: nothing is added to the stream)
+  int every = 1;               // events around every `every`-th launch only (a sample: two event records break back-to-back dispatch)
+  bool armed = false;          // the current launch is bracketed
+  double flops_timed = 0.0;    // FLOPs of the bracketed launches
   size_t counted = 0;
   std::vector<hipEvent_t> starts, stops;
   size_t used = 0;
@@ -41,7 +44,10 @@ void prof_begin(int family, double flops, hipStream_t st) {
   ProfState& p = g_prof[family];
   if (!p.on) return;
   p.counted++;
-  if (!p.events) { p.flops += flops; return; }
+  p.flops += flops;
+  p.armed = p.events && (p.counted - 1) % (size_t)p.every == 0;
+  if (!p.armed) return;
+  p.flops_timed += flops;
   if (p.used == p.starts.size()) {
     hipEvent_t a, b;
     hipEventCreate(&a);
@@ -49,13 +55,12 @@ void prof_begin(int family, double flops, hipStream_t st) {
     p.starts.push_back(a);
     p.stops.push_back(b);
   }
-  p.flops += flops;
   hipEventRecord(p.starts[p.used], st);
 }
 
 void prof_end(int family, hipStream_t st) {
   ProfState& p = g_prof[family];
-  if (!p.on || !p.events) return;
+  if (!p.on || !p.armed) return;
   hipEventRecord(p.stops[p.used], st);
   p.used++;
 }
@@ -126,9 +131,18 @@ int dei2i_prof_enable(int family, int on) {
   ProfState& p = g_prof[family];
   p.on = on != 0;
   p.events = on != 2;
+  p.every = on >= 3 ? on : 1;
   p.used = 0;
   p.counted = 0;
   p.flops = 0.0;
+  p.flops_timed = 0.0;
+  return 0;
+}
+
+int dei2i_prof_collect_timed(int family, int64_t* timed_launches, double* timed_flops) {
+  if (family < 0 || family >= PROF_FAMILIES) return DEI2I_ERR_BAD_ARG;
+  if (timed_launches) *timed_launches = (int64_t)g_prof[family].used;
+  if (timed_flops) *timed_flops = g_prof[family].flops_timed;
   return 0;
 }
 
@@ -150,6 +164,7 @@ int dei2i_prof_collect(int family, int64_t* launches, double* total_ms, double* 
   p.used = 0;
   p.counted = 0;
   p.flops = 0.0;
+  p.flops_timed = 0.0;
   return 0;
 }
 

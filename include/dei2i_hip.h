@@ -234,8 +234,12 @@ int dei2i_spectral_bwd(int Cout, int K, const float* G, const float* w_eff, cons
 #define DEI2I_PROF_WGRAD 1
 #define DEI2I_PROF_HALO_CONV 2   /* halo_conv_kernel alone (its launches are not part of family 0) */
 /* on = 1: HIP events around every launch of the family + FLOP count; on = 2: launch and FLOP count only (no events: the
- * stream sees nothing extra, total_ms reads 0); on = 0: off */
+ * stream sees nothing extra, total_ms reads 0); on = k >= 3: events around every k-th launch only (a sample -- two event
+ * records per launch break the stream's back-to-back dispatch); on = 0: off */
 int dei2i_prof_enable(int family, int on);
+/* (call BEFORE dei2i_prof_collect) how many launches were bracketed with events since enable, and their FLOPs: total_ms of
+ * dei2i_prof_collect belongs to these */
+int dei2i_prof_collect_timed(int family, int64_t* timed_launches, double* timed_flops);
 /* synchronises the recorded events; returns launches, total ms and total algorithmic FLOPs since enable */
 int dei2i_prof_collect(int family, int64_t* launches, double* total_ms, double* total_flops);
 
