@@ -52,6 +52,19 @@ constexpr int H16_HBYTES = H16_GROUPS * 1024;         // 39,936
 constexpr int H16_HL = 5;                             // halo LDS-DMA instructions per wave per slice (40 >= 39 groups)
 
 template <int N> DEI2I_D void wait_vm16() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> DEI2I_D void lgkm_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+// LDS reads the compiler does not track (no automatic s_waitcnt: every use needs a hand-placed lgkm_wait)
+template <int OFF, bool SKIP = false> DEI2I_D u32x4 lds_read128_asm(int addr) {
+  u32x4 v;
+  if constexpr (SKIP) asm volatile("; no read %0 %1" : "=v"(v) : "v"(addr));        // (timing-only ablation)
+  else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+DEI2I_D int lds_read32_asm(int addr) {
+  int v;
+  asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
 DEI2I_D int sw16(int row) { return ((row >> 2) & 1) << 1; }
 
 // DIAG: a diagnostic build (option "v2_ablate" = 6) that accumulates s_memtime stamps per wave into `dbg`:
@@ -66,7 +79,11 @@ DEI2I_D int sw16(int row) { return ((row >> 2) & 1) << 1; }
 // (waves wm = 0, 1), ring column -1 / W over the tile's 16 rows as one extra block of 16 rows x 1 column (waves wm = 2 /
 // 3); each is 4 extra MFMAs per wave in 3 of the 9 taps, accumulated apart and added to rows 1 / 14 or columns 1 / 30 of
 // the LDS-staged tile before it is written.  The four frame CORNERS (one pixel each) are left to reflect_corner_kernel.
-template <int BN, int STAGES, bool DIAG = false, bool FOLD = false>
+// DIAG 2 / 3 / 4: stamps + a TIMING-ONLY ablation (results are wrong): 2 = no LDS-DMA inside the loop, 3 = no fragment reads,
+// 4 = no MFMAs (options v2_ablate = 7 / 8 / 9)
+// ABL (options v2_ablate = 10 + ABL, no stamps): the same as a bit mask -- 1 no LDS-DMA in the loop, 2 no fragment reads, 4 no MFMAs
+// PIPE: the software-pipelined main loop (see there) instead of the two-phase one
+template <int BN, int STAGES, int DIAG = 0, bool FOLD = false, int ABL = 0, bool PIPE = false>
 __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, const bf16_t* __restrict__ src,
                                                           const bf16_t* __restrict__ wgt, const int wrows,
                                                           const float* __restrict__ bias, bf16_t* __restrict__ out,
@@ -187,9 +204,11 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
 
   const int l16 = lane & 15, kg = lane >> 4;
   struct Frags { u32x4 a[PB]; u32x4 b[CB]; };
-  int a_pix0[PB];                                      // halo pixel of this lane's pixel for tap offset 0
+  // byte address (tap offset 0, before the swizzle) of this lane's chunk of its pixel in tile row 4 * wm + r, columns 0..15;
+  // columns 16..31 sit 1024 bytes further in the same slot (16 rows on: the swizzle bit (row >> 2) & 1 repeats)
+  int a_base[PB / 2];
 #pragma unroll
-  for (int i = 0; i < PB; ++i) a_pix0[i] = (wm * 4 + (i >> 1)) * hwd + (i & 1) * 16 + l16;
+  for (int r = 0; r < PB / 2; ++r) a_base[r] = ((wm * 4 + r) * hwd + l16) * 64 + kg * 16;
   int b_addr[CB];                                      // byte address of this lane's weight chunk within a stage
 #pragma unroll
   for (int j = 0; j < CB; ++j) {
@@ -225,10 +244,13 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
   auto read_frags = [&](Frags& f) {
     const unsigned char* hb = halo + (ld_slice & 1) * H16_HBYTES;
     const unsigned char* sb = ring + ld_stage * B_STAGE;
+    const int s_off = ld_toff * 64 + (ld_slice & 1) * H16_HBYTES;     // wave-uniform; H16_HBYTES is a multiple of 1024
 #pragma unroll
-    for (int i = 0; i < PB; ++i) {
-      const int pix = a_pix0[i] + ld_toff;
-      f.a[i] = *reinterpret_cast<const u32x4*>(hb + pix * 64 + ((kg ^ sw16(pix)) << 4));
+    for (int r = 0; r < PB / 2; ++r) {
+      const int t = a_base[r] + s_off;
+      const int addr = t ^ ((t >> 3) & 32);             // slot = chunk ^ (((row >> 2) & 1) << 1): row bit 2 = address bit 8
+      f.a[2 * r] = *reinterpret_cast<const u32x4*>(halo + addr);
+      f.a[2 * r + 1] = *reinterpret_cast<const u32x4*>(halo + addr + 1024);
     }
     if constexpr (FOLD) {
       // the ring row / column only sees the tap row / column that still reads inside dy (dgrad taps: dy row = oy + 1 - ty)
@@ -250,91 +272,369 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
     if (++ld_stage == STAGES) ld_stage = 0;
   };
 
-  // ---- main loop: two wave groups in anti-phase (see conv_halo.hip) ----
-  //   C(j) issues weights(j-1+STAGES) into stage (j-1) % STAGES (last read by the trailing group's M(j-1), two phases
-  //        earlier) and, at tap 1 of a slice, the NEXT slice's halo (into the buffer of the previous slice).
-  //   M(j) ends with "my share of weights(j+1) has landed" + barrier.  weights(j+1) was issued in C(j+2-STAGES); issued
-  //        after it: the weights of C(j+3-STAGES .. j-1) = (STAGES-3) stages, and the halo of C(tap 1) while
-  //        2 <= tap <= STAGES-1 -- exactly those may stay in flight.  The last STAGES-2 k-steps drain everything.
-  const int grp = wave >> 2;
-  int tap = 0, slice = 0;                              // k-step of this wave's current M / C phase
-  Frags f;
-  auto phase_m = [&](int j) {
-    const unsigned long long q0 = now();
-    read_frags(f);
-    __builtin_amdgcn_sched_barrier(0);
-    const unsigned long long q1 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
-    const bool halo_young = tap >= 2 && tap <= STAGES - 1 && slice + 1 < nslices;
-    if (j + STAGES - 2 >= nk) wait_vm16<0>();
-    else if (halo_young) wait_vm16<(STAGES - 3) * LB + H16_HL>();
-    else wait_vm16<(STAGES - 3) * LB>();
-    const unsigned long long q2 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const unsigned long long q3 = now();
-    __builtin_amdgcn_s_barrier();
-    if (DIAG) {
-      const unsigned long long q4 = now();
-      dg[0] += q1 - q0; dg[1] += q2 - q1; dg[2] += q3 - q2; dg[3] += q4 - q3;
-    }
-  };
-  auto phase_c = [&](int j) {
-    const unsigned long long q0 = now();
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int jj = 0; jj < CB; ++jj)
-        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.b[jj]), __builtin_bit_cast(bf16x8, f.a[i]),
-                                                             acc[i][jj], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (j - 1 + STAGES < nk) issue_b((j + STAGES - 1) % STAGES);
-    __builtin_amdgcn_sched_barrier(0);
-    if (tap == 1 && slice + 1 < nslices) issue_halo(slice + 1);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 2; i < PB; ++i)
-#pragma unroll
-      for (int jj = 0; jj < CB; ++jj)
-        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.b[jj]), __builtin_bit_cast(bf16x8, f.a[i]),
-                                                             acc[i][jj], 0, 0, 0);
-    if constexpr (FOLD) {
-      if (ring_live) {
-#pragma unroll
-        for (int jj = 0; jj < CB; ++jj)
-          racc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.b[jj]), __builtin_bit_cast(bf16x8, ring_frag),
-                                                             racc[jj], 0, 0, 0);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    const unsigned long long q1 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
-    __builtin_amdgcn_s_barrier();
-    if (DIAG) {
-      const unsigned long long q2 = now();
-      dg[4] += q1 - q0; dg[5] += q2 - q1;
-    }
-    if (++tap == ntaps) { tap = 0; ++slice; }
-  };
-
-  const unsigned long long st0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
-  const unsigned long long sr0 = DIAG ? __builtin_amdgcn_s_memrealtime() : 0ull;
-  // prologue: halo slice 0 and weights(0 .. STAGES-2); weights(STAGES-1) is issued by C(0).  nk >= 9 > STAGES-1.
-  issue_halo(0);
-  for (int s2 = 0; s2 < STAGES - 1; ++s2) issue_b(s2);
-  wait_vm16<(STAGES - 2) * LB>();                       // everything older than weights(1): halo 0 and weights(0)
-  __builtin_amdgcn_s_barrier();
-  if (grp == 1) __builtin_amdgcn_s_barrier();           // group 1 starts one phase late
-#pragma unroll 1
-  for (int j = 0; j < nk; ++j) {
-    phase_m(j);
-    phase_c(j);
-  }
-  if (grp == 0) __builtin_amdgcn_s_barrier();           // pairs with group 1's last phase
   unsigned long long* drec = nullptr;
-  if (DIAG && dbg != nullptr && lane == 0) {
-    drec = dbg + ((size_t)blockIdx.x * 8 + wave) * 10;
-    drec[0] = __builtin_amdgcn_s_memtime() - st0;
-    drec[1] = __builtin_amdgcn_s_memrealtime() - sr0;
-    drec[2] = (unsigned long long)nk;
-    for (int q = 0; q < 6; ++q) drec[4 + q] = dg[q];
+  unsigned long long st0 = 0;
+  if constexpr (PIPE) {
+    // ---- main loop, software-pipelined (option "halo16" = 1): every wave runs MFMAs all the time -----------------------------
+    // The anti-phase loop below gives a wave EITHER its 12 fragment reads OR its 32 MFMAs per phase; a DMA piece among the
+    // MFMAs stalls the in-order wave ~100-300 cycles behind the other waves' pieces and the SIMD's matrix pipe idles with it
+    // (its partner wave is in a read phase).  Timing-only ablations of that loop, res-block shape, kernel wall: full 71.7 us |
+    // MFMA only 51.3 | reads only 40.9 | DMA only 35.8 | empty loop 18.0 -- the three streams run one after the other much more
+    // than beside each other.  Here a k-step (one tap x 32 channels) is two halves of 16 MFMAs:
+    //   H0(j): issue the reads of pixel rows 2,3 of k-step j                      | MFMAs of rows 0,1
+    //   H1(j): issue the reads of rows 0,1 and of the weights of k-step j+1       | 4 MFMAs | DMA slot j | 12 MFMAs (rows 2,3)
+    // so both waves of a SIMD always hold MFMAs for the pipe and one wave's read latency or DMA issue stall is the other's
+    // issue time.  Waves 0-3 put the k-step's ONE workgroup barrier between H0 and H1, waves 4-7 after H1 (half a k-step
+    // apart: the two waves of a SIMD do not meet the barrier, or their read bursts, at the same moment).
+    //   DMA slot j = halo piece `tap` of the NEXT slice (taps 0..4: this wave's 5 pieces, into the buffer of the previous
+    //        slice, last read in H0 of that slice's tap 8) then weights(j+7) into stage (j+7) % 8 (last read in H1(j-2)).
+    //   barrier #j needs every wave's piece of weights(j+2) landed (waves 4-7 read stage j+2 in H1(j+1) with no barrier in
+    //        between) and, at tap 7, all of the next slice's halo (read from H1(tap 8) on).  weights(j+2) went out in slot j-5;
+    //        younger at barrier #j: for waves 0-3 (slot j not issued yet) the weights of slots j-4..j-1 and the halo pieces
+    //        of the taps tap-4..tap-1 that lie in 0..4; for waves 4-7 those of slots j-4..j / taps tap-4..tap.
+    static_assert(!PIPE || (STAGES == 8 && BN == 128), "the read schedule and wait counts below are written for 8 stages and 4 channel blocks");
+    constexpr int HWD = H16_TW + 2;
+    const int grp = wave >> 2;
+    const bool flip_y = g.ys < 0, flip_x = g.xs < 0;
+    // The fragment reads are inline asm with HAND-COUNTED lgkmcnt waits: the compiler's own wait insertion falls back to
+    // lgkmcnt(0) at every branch merge of this body, i.e. it would wait for the reads it has just issued.  LDS operations
+    // return in issue order; per k-step a wave issues
+    //   H0: ah x4                                  H1: [piece offset (taps 0..4)] al' x4 [ring' (FOLD)] | bc'[0] | bc'[1] | bc'[2] | bc'[3]
+    // (the ring and piece-offset reads are issued whether or not they are used, so that the counts are static).
+    u32x4 al[4], ah[4], bc[CB];
+    auto tap_off = [&](int t) -> int {                  // byte offset of tap t's halo pixel (ty, tx of the LOOP order)
+      const int ty = t / 3, tx = t % 3;
+      return ((flip_y ? 2 - ty : ty) * HWD + (flip_x ? 2 - tx : tx)) * 64;
+    };
+    auto read_a = [&](u32x4* dst, int r0, int soff) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int t = a_base[r0 + r] + soff;
+        const int addr = t ^ ((t >> 3) & 32);
+        dst[2 * r] = lds_read128_asm<0, (ABL & 2) != 0>(addr);
+        dst[2 * r + 1] = lds_read128_asm<1024, (ABL & 2) != 0>(addr);
+      }
+    };
+    const int b_addr0 = b_addr[0] + 2 * H16_HBYTES;     // (block jj sits 16 rows = 1024 bytes after block jj-1, same slot)
+    auto read_b1 = [&](int jj, int stage) -> u32x4 {
+      const int a = b_addr0 + stage * B_STAGE;
+      return jj == 0 ? lds_read128_asm<0, (ABL & 2) != 0>(a) : jj == 1 ? lds_read128_asm<1024, (ABL & 2) != 0>(a) : jj == 2 ? lds_read128_asm<2048, (ABL & 2) != 0>(a) : lds_read128_asm<3072, (ABL & 2) != 0>(a);
+    };
+    auto read_ring = [&](int t, int par) {              // FOLD: the ring block's fragment of loop tap t (read whether or not it is live)
+      if constexpr (FOLD) {
+        const int ty = t / 3, tx = t % 3;
+        ring_live = (ring_kind == 1 && ty == 0) || (ring_kind == 2 && ty == 2) || (ring_kind == 3 && tx == 0) || (ring_kind == 4 && tx == 2);
+        const int pix = ring_live ? ring_pix0 + (tap_off(t) >> 6) : 0;
+        ring_frag = lds_read128_asm<0, (ABL & 2) != 0>(par + pix * 64 + ((kg ^ sw16(pix)) << 4));
+      }
+    };
+    // (the opaque asm statements below keep per-tap copies of loop-invariant addresses -- 9 weight pointers, 5 table
+    //  addresses -- from being hoisted into registers the loop does not have: they were spilled, and a scratch reload is a
+    //  vector-memory operation with an s_waitcnt vmcnt(0) behind it, i.e. a drain of the whole LDS-DMA queue)
+    const bf16_t* b_src = b_ptr != nullptr ? b_ptr : zero;
+    const int b_live = b_ptr != nullptr ? 1 : 0;
+    auto issue_w = [&](int tapw, int slicew, int stage) {
+      const bf16_t* bp = b_src;
+      asm volatile("" : "+v"(bp));
+      const int kb = (tapw * g.Cs + (slicew << 5)) * b_live;
+      glds16x(bp + kb, ring + stage * B_STAGE + rg * 1024);
+    };
+    // a wave's halo piece jp = 16-pixel group 8 * jp + wave (mod 39): the pixel's source offset is read back from the offset
+    // table when the piece is issued (five per-lane offsets -- or the 64-bit pointers the compiler makes of them -- would
+    // not fit beside the accumulators and two fragment sets)
+    const int hl_addr = (int)(reinterpret_cast<unsigned char*>(htab) - smem) + lrow * 4;
+    const int so_lane = (lslot ^ sw16(lrow)) << 3;      // (group bases are multiples of 16 pixels: the swizzle bit is the lane's)
+    auto piece_group = [&](int jp) -> int {
+      int gq = jp * 8 + wave;
+      if (gq >= H16_GROUPS) gq -= H16_GROUPS;
+      return gq;
+    };
+    auto read_piece_off = [&](int jp) -> int {
+      int a = hl_addr;
+      asm volatile("" : "+v"(a));
+      return lds_read32_asm(a + piece_group(jp) * 64);
+    };
+    auto issue_halo_piece = [&](int slicew, int jp, int o) {
+      const int ci0 = slicew << 5;
+      const bf16_t* p = o >= 0 ? src + ((size_t)(unsigned)(o + so_lane) + (unsigned)ci0) : zero;
+      if (o < -1) p = zring + ((size_t)(unsigned)(-2 - o + so_lane) + (unsigned)ci0);
+      glds16x(p, halo + (slicew & 1) * H16_HBYTES + piece_group(jp) * 1024);
+    };
+    // 4 MFMAs: pixel blocks a[0..3] (accumulators i0..i0+3) x channel block jj
+    auto mfma4 = [&](const u32x4* a, int i0, int jj) {
+      if constexpr (!(ABL & 4)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[i0 + i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bc[jj]), __builtin_bit_cast(bf16x8, a[i]),
+                                                                    acc[i0 + i][jj], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(a[i]));
+        asm volatile("" ::"v"(bc[jj]));
+      }
+    };
+    constexpr int NF = FOLD ? 1 : 0;
+
+    // (cycle count of the loop for every build of this path, when a debug buffer is set: tools/diag_halo16_stamps.py)
+    st0 = dbg != nullptr ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long sr0p = dbg != nullptr ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    // prologue: halo slice 0 and weights(0..6); halo 0, weights(0) and weights(1) landed (waves 4-7 read stage 1 in H1(0))
+    {
+      int po[H16_HL];
+#pragma unroll
+      for (int jp = 0; jp < H16_HL; ++jp) po[jp] = read_piece_off(jp);
+      lgkm_wait<0>();
+#pragma unroll
+      for (int jp = 0; jp < H16_HL; ++jp) issue_halo_piece(0, jp, po[jp]);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < STAGES - 1; ++s2) issue_w(s2, 0, s2);
+    wait_vm16<STAGES - 3>();
+    __builtin_amdgcn_s_barrier();
+    read_a(al, 0, tap_off(0));
+    read_ring(0, 0);
+#pragma unroll
+    for (int jj = 0; jj < CB; ++jj) bc[jj] = read_b1(jj, 0);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // one fragment read of rows r0.. : row r (0/1 of the pair), column half c
+    auto read_a1 = [&](u32x4* dst, int r0, int q, int soff) {      // q = 2 * r + c
+      const int t = a_base[r0 + (q >> 1)] + soff;
+      const int addr = t ^ ((t >> 3) & 32);
+      dst[q] = (q & 1) ? lds_read128_asm<1024, (ABL & 2) != 0>(addr) : lds_read128_asm<0, (ABL & 2) != 0>(addr);
+    };
+    auto kstep = [&](auto tap_c, int sl) {
+      constexpr int T = decltype(tap_c)::value;
+      const int j = sl * 9 + T;
+      const int par = (sl & 1) * H16_HBYTES;
+      const bool has_halo = sl + 1 < nslices;
+      const int soff = tap_off(T) + par;
+      // The reads are spread between the MFMA groups (4 MFMAs each), at most three in a row: eight waves that each issue 5-6
+      // reads at once right after a barrier fill the LDS queue, every wave stalls at its next read and the MFMAs behind it
+      // wait (reads issued up front: MFMAs and reads took the SUM of their times).  Issue order per k-step:
+      //   H0: ah0 G0 ah1 G1 ah2 G2 ah3 G3      H1: [P] al'0 al'1 G0 bc'0 al'2 (DMA) G1 bc'1 al'3 G2 bc'2 [ring'] G3 bc'3
+      // ---- H0(j): rows 0,1 multiply (groups by channel block jj), rows 2,3 of this k-step are fetched
+      read_a1(ah, 2, 0, soff);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!(ABL & 16)) lgkm_wait<2>();          // all of al', ring' and bc'[0..2] are in; bc'[3] and ah0 may be in flight
+#pragma unroll
+      for (int jj = 0; jj < CB; ++jj) {
+        if (jj == CB - 1) {
+          if constexpr (!(ABL & 16)) lgkm_wait<4>();      // bc'[3] is in (ah0..3 may be in flight)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma4(al, 0, jj);
+        if constexpr (FOLD) {
+          if (ring_live)
+            racc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bc[jj]), __builtin_bit_cast(bf16x8, ring_frag),
+                                                               racc[jj], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (jj < 3) read_a1(ah, 2, jj + 1, soff);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (grp == 0) {
+        if constexpr (!(ABL & 1)) {
+          constexpr int NH = T == 7 ? 3 : 4 + (T == 0 ? 0 : T == 1 ? 1 : T == 2 ? 2 : T == 3 ? 3 : T == 4 ? 4 : T == 5 ? 4 : T == 6 ? 3 : 1);
+          if (j + STAGES - 2 >= nk) wait_vm16<0>();
+          else if (has_halo) wait_vm16<NH>();
+          else wait_vm16<4>();
+        }
+        // (tap 8: these were the last reads of this slice's halo buffer, which the DMA refills after the next barrier)
+        if constexpr (T == 8 && !(ABL & 16)) lgkm_wait<0>();
+        if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- H1(j): rows 2,3 multiply; rows 0,1 of k-step j+1 are fetched, and its weight block jj as soon as this k-step's
+      //      MFMAs with block jj are out (after the last k-step these reads fetch bytes nobody uses)
+      constexpr int TN = (T + 1) % 9;
+      constexpr int NP = T <= 4 ? 1 : 0;
+      const int par_n = T == 8 ? ((sl + 1) & 1) * H16_HBYTES : par;
+      const int soff_n = tap_off(TN) + par_n;
+      const int stage_n = (j + 1) & (STAGES - 1);
+      int piece_off = -1;
+      if constexpr (NP) piece_off = read_piece_off(T);
+      read_a1(al, 0, 0, soff_n);
+      read_a1(al, 0, 1, soff_n);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!(ABL & 16)) lgkm_wait<NP + 2>();     // ah0..3 are in
+#pragma unroll
+      for (int jj = 0; jj < CB; ++jj) {
+        __builtin_amdgcn_sched_barrier(0);
+        mfma4(ah, 4, jj);
+        __builtin_amdgcn_sched_barrier(0);
+        bc[jj] = read_b1(jj, stage_n);
+        if (jj == 0) read_a1(al, 0, 2, soff_n);
+        if (jj == 1) read_a1(al, 0, 3, soff_n);
+        if (jj == 2) read_ring(TN, par_n);
+        __builtin_amdgcn_sched_barrier(0);
+        if (jj == 0) {
+          if constexpr (!(ABL & 1)) {
+            if constexpr (NP) {
+              if constexpr (!(ABL & 16)) lgkm_wait<4>();  // the piece offset (oldest of this half's reads) is in
+              if (has_halo) issue_halo_piece(sl + 1, T, piece_off);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int TW = (T + STAGES - 1) % 9, DS = (T + STAGES - 1) / 9;
+            if (sl + DS < nslices) issue_w(TW, sl + DS, (j + STAGES - 1) & (STAGES - 1));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (grp == 1) {
+        if constexpr (!(ABL & 1)) {
+          constexpr int NH = T == 7 ? 4 : 5 + (T == 0 ? 1 : T == 1 ? 2 : T == 2 ? 3 : T == 3 ? 4 : T == 4 ? 5 : T == 5 ? 4 : T == 6 ? 3 : 1);
+          if (j + STAGES - 1 >= nk) wait_vm16<0>();
+          else if (has_halo) wait_vm16<NH>();
+          else wait_vm16<5>();
+        }
+        if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+#pragma unroll 1
+    for (int sl = 0; sl < nslices; ++sl) {
+      // (opaque: without it the 9 taps' read addresses -- a_base + tap offset, 36 registers -- are hoisted out of the loop)
+#pragma unroll
+      for (int r = 0; r < PB / 2; ++r) asm volatile("" : "+v"(a_base[r]));
+      kstep(std::integral_constant<int, 0>{}, sl);
+      kstep(std::integral_constant<int, 1>{}, sl);
+      kstep(std::integral_constant<int, 2>{}, sl);
+      kstep(std::integral_constant<int, 3>{}, sl);
+      kstep(std::integral_constant<int, 4>{}, sl);
+      kstep(std::integral_constant<int, 5>{}, sl);
+      kstep(std::integral_constant<int, 6>{}, sl);
+      kstep(std::integral_constant<int, 7>{}, sl);
+      kstep(std::integral_constant<int, 8>{}, sl);
+      // (register copies at the loop's back-edge must not meet a fragment register whose read is still in flight)
+      lgkm_wait<0>();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (dbg != nullptr && lane == 0) {
+      unsigned long long* rec = dbg + ((size_t)blockIdx.x * 8 + wave) * 10;
+      rec[0] = __builtin_amdgcn_s_memtime() - st0;
+      rec[1] = __builtin_amdgcn_s_memrealtime() - sr0p;
+      rec[2] = (unsigned long long)nk;
+    }
+  } else {
+    // ---- main loop: two wave groups in anti-phase (see conv_halo.hip) ----
+    //   M(j) reads its fragments, then issues weights(j-2+STAGES) into stage (j-2) % STAGES (last read by the trailing group's
+    //        M(j-2), three phases earlier) and, at tap 2 of a slice, the NEXT slice's halo (into the buffer of the previous
+    //        slice, last read at tap 8 of that slice), and ends with "my share of weights(j+1) has landed" + barrier.
+    //        weights(j+1) was issued in M(j+3-STAGES); issued after it: the weights of M(j+4-STAGES .. j) = (STAGES-3) pieces,
+    //        and the halo of M(tap 2) while 2 <= tap <= STAGES-1 -- exactly those may stay in flight.  The last STAGES-2
+    //        k-steps drain everything.
+    //   C(j) is the 32 MFMAs and nothing else.
+    const int grp = wave >> 2;
+    int tap = 0, slice = 0;                              // k-step of this wave's current M / C phase
+    Frags f;
+    if constexpr (DIAG == 3 || (ABL & 2)) {
+      read_frags(f);
+      ld_tx = 0; ld_ty = 0; ld_slice = 0; ld_stage = 0; ld_toff = toff_origin;
+    }
+    // DMA slot of k-step jj: weights(jj-2+STAGES) and, when k-step jj is tap 2 of its slice, the next slice's halo.  It sits
+    // after the first 8 MFMAs of C(jj-1).  Measured alternatives (same box, res-block shape, kernel wall 69.4-70.7 us as is):
+    // the slot in M(jj) after the fragment reads 74.5-75.9 us, before them 77.0-77.5, weights in M / halo in C 72.9-73.3, half
+    // of a group's waves before and half after the reads 75.8-78.4 -- a piece costs the wave that issues it ~150-300 cycles
+    // wherever it sits, and the M phase has less room for it than the C phase.
+    auto slot_w = [&](int jj) {
+      if (jj - 2 + STAGES < nk) issue_b((jj + STAGES - 2) % STAGES);
+    };
+    auto slot_h = [&](bool tap2) {
+      if (tap2 && slice + 1 < nslices) issue_halo(slice + 1);
+    };
+    auto phase_m = [&](int j) {
+      const unsigned long long q0 = now();
+      if constexpr (DIAG != 3 && !(ABL & 2)) read_frags(f);
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long q1 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
+      const bool halo_young = tap >= 2 && tap <= STAGES - 1 && slice + 1 < nslices;
+      if constexpr (DIAG != 2 && !(ABL & 1)) {
+        if (j + STAGES - 2 >= nk) wait_vm16<0>();
+        else if (halo_young) wait_vm16<(STAGES - 3) * LB + H16_HL>();
+        else wait_vm16<(STAGES - 3) * LB>();
+      }
+      const unsigned long long q2 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const unsigned long long q3 = now();
+      __builtin_amdgcn_s_barrier();
+      if (DIAG) {
+        const unsigned long long q4 = now();
+        dg[0] += q1 - q0; dg[1] += q2 - q1; dg[2] += q3 - q2; dg[3] += q4 - q3;
+      }
+    };
+    auto phase_c = [&](int j) {
+      const unsigned long long q0 = now();
+      if constexpr (DIAG != 4 && !(ABL & 4)) {
+  #pragma unroll
+        for (int i = 0; i < 2; ++i)
+  #pragma unroll
+          for (int jj = 0; jj < CB; ++jj)
+            acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.b[jj]), __builtin_bit_cast(bf16x8, f.a[i]),
+                                                                 acc[i][jj], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (DIAG != 2 && !(ABL & 1)) {
+        slot_w(j + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        slot_h(tap == 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (DIAG != 4 && !(ABL & 4)) {
+  #pragma unroll
+        for (int i = 2; i < PB; ++i)
+  #pragma unroll
+          for (int jj = 0; jj < CB; ++jj)
+            acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.b[jj]), __builtin_bit_cast(bf16x8, f.a[i]),
+                                                                 acc[i][jj], 0, 0, 0);
+      } else {
+        // keep the fragments live so that the reads are not removed
+  #pragma unroll
+        for (int i = 0; i < PB; ++i) asm volatile("" ::"v"(f.a[i]));
+  #pragma unroll
+        for (int jj = 0; jj < CB; ++jj) asm volatile("" ::"v"(f.b[jj]));
+      }
+      if constexpr (FOLD) {
+        if (ring_live) {
+  #pragma unroll
+          for (int jj = 0; jj < CB; ++jj)
+            racc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.b[jj]), __builtin_bit_cast(bf16x8, ring_frag),
+                                                               racc[jj], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long q1 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
+      __builtin_amdgcn_s_barrier();
+      if (DIAG) {
+        const unsigned long long q2 = now();
+        dg[4] += q1 - q0; dg[5] += q2 - q1;
+      }
+      if (++tap == ntaps) { tap = 0; ++slice; }
+    };
+
+    st0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long sr0 = DIAG ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    // prologue: halo slice 0 and weights(0 .. STAGES-3); weights(STAGES-2) is issued by M(0).  nk >= 9 > STAGES-1.
+    issue_halo(0);
+    for (int s2 = 0; s2 < STAGES - 2; ++s2) issue_b(s2);
+    issue_b(STAGES - 2);                                  // (the slot of k-step 0 would sit in "C(-1)")
+    wait_vm16<(STAGES - 2) * LB>();                       // everything older than weights(1): halo 0 and weights(0)
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();           // group 1 starts one phase late
+  #pragma unroll 1
+    for (int j = 0; j < nk; ++j) {
+      phase_m(j);
+      phase_c(j);
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();           // pairs with group 1's last phase
+    if (DIAG && dbg != nullptr && lane == 0) {
+      drec = dbg + ((size_t)blockIdx.x * 8 + wave) * 10;
+      drec[0] = __builtin_amdgcn_s_memtime() - st0;
+      drec[1] = __builtin_amdgcn_s_memrealtime() - sr0;
+      drec[2] = (unsigned long long)nk;
+      for (int q = 0; q < 6; ++q) drec[4 + q] = dg[q];
+    }
+
   }
 
   // ---- epilogue, in two halves of 8 tile rows: stage the half as bf16 [pixel][BN (+8 pad)] (8-byte writes: a lane
@@ -428,7 +728,7 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
   }
   if (DIAG && drec != nullptr) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    drec[3] = __builtin_amdgcn_s_memtime() - kt0;
+    drec[3] = (__builtin_amdgcn_s_memtime() - kt0) | ((st0 - kt0) << 32);     // whole kernel | prologue (cycles)
   }
 }
 
@@ -822,7 +1122,7 @@ __global__ __launch_bounds__(256) void reflect_corner_kernel(const bf16_t* __res
 }
 
 extern int g_halo_bn, g_halo_stages;
-int g_halo16 = 1;
+int g_halo16 = 3;
 int g_halo16_fold = 1;         // A/B option "halo16_fold": 0 = ring GEMM + finalize + border fold as separate launches              // A/B option "halo16": 0 = always the 8 x 32 tile kernel (conv_halo.hip)
 int g_halo16_stages = 8;
 
@@ -834,13 +1134,66 @@ static hipError_t launch_halo16(const GatherDesc& g, const void* src, const void
   constexpr size_t loop_lds = 2 * (size_t)H16_HBYTES + (size_t)STAGES * BN * 64 + H16_GROUPS * 16 * sizeof(int);
   constexpr size_t epi_lds = 256 * (size_t)(BN * 2 + 16) + 512 * 16 * sizeof(float);
   const size_t lds = std::max(loop_lds, epi_lds);
-  const bool diag = g_v2_ablate == 6 && g_v2_dbg != nullptr && STAGES == 8 && !fold;
-  auto kern = diag ? halo16_conv_kernel<BN, STAGES, STAGES == 8> : halo16_conv_kernel<BN, STAGES, false>;
-  if (fold) kern = halo16_conv_kernel<BN, STAGES, false, STAGES == 8>;        // (instantiated for the shipped ring depth only)
+  const bool diag = g_v2_ablate >= 6 && g_v2_ablate <= 9 && g_v2_dbg != nullptr && STAGES == 8 && !fold;
+  constexpr bool S8 = STAGES == 8 && BN == 128;   // the diagnostic builds exist for the shipped ring depth and the 128-channel tile only
+  auto kern = halo16_conv_kernel<BN, STAGES, 0>;
+  if (diag && S8) {
+    kern = g_v2_ablate == 6 ? halo16_conv_kernel<BN, STAGES, S8 ? 1 : 0> : g_v2_ablate == 7 ? halo16_conv_kernel<BN, STAGES, S8 ? 2 : 0>
+         : g_v2_ablate == 8 ? halo16_conv_kernel<BN, STAGES, S8 ? 3 : 0> : halo16_conv_kernel<BN, STAGES, S8 ? 4 : 0>;
+  }
+  // (the FOLD build of the pipelined loop needs 20 more registers -- ring accumulators and fragment -- than a wave has: it
+  //  spills inside the loop, and a scratch reload drains the LDS-DMA queue.  Those launches keep the two-phase loop.)
+  // (and its read schedule and wait counts are written for 4 channel blocks per wave: the 64-channel tile keeps the two-phase loop too)
+  const bool pipe = g_halo16 == 3 && STAGES == 8 && BN == 128 && !fold;
+  if (pipe) {
+    constexpr bool P8 = STAGES == 8 && BN == 128;
+    kern = halo16_conv_kernel<BN, STAGES, 0, false, 0, P8>;
+    if (!fold && BN == 128 && g_v2_ablate > 20 && g_v2_ablate <= 51) {
+      constexpr bool Q = P8 && BN == 128;
+      switch (g_v2_ablate - 20) {
+        case 8: kern = halo16_conv_kernel<BN, STAGES, 0, false, Q ? 8 : 0, Q>; break;
+        case 16: kern = halo16_conv_kernel<BN, STAGES, 0, false, Q ? 16 : 0, Q>; break;
+        case 24: kern = halo16_conv_kernel<BN, STAGES, 0, false, Q ? 24 : 0, Q>; break;
+        case 12: kern = halo16_conv_kernel<BN, STAGES, 0, false, Q ? 12 : 0, Q>; break;
+        case 9: kern = halo16_conv_kernel<BN, STAGES, 0, false, Q ? 9 : 0, Q>; break;
+        case 25: kern = halo16_conv_kernel<BN, STAGES, 0, false, Q ? 25 : 0, Q>; break;
+        case 27: kern = halo16_conv_kernel<BN, STAGES, 0, false, Q ? 27 : 0, Q>; break;
+        case 26: kern = halo16_conv_kernel<BN, STAGES, 0, false, Q ? 26 : 0, Q>; break;
+        case 2: kern = halo16_conv_kernel<BN, STAGES, 0, false, Q ? 2 : 0, Q>; break;
+        case 31: kern = halo16_conv_kernel<BN, STAGES, 0, false, Q ? 31 : 0, Q>; break;
+        case 1: kern = halo16_conv_kernel<BN, STAGES, 0, false, Q ? 1 : 0, Q>; break;
+        case 4: kern = halo16_conv_kernel<BN, STAGES, 0, false, Q ? 4 : 0, Q>; break;
+        case 5: kern = halo16_conv_kernel<BN, STAGES, 0, false, Q ? 5 : 0, Q>; break;
+        default: break;
+      }
+    }
+    static const void* attr_set[16] = {};               // (per template instance of this launcher: the kernels it has prepared)
+    bool seen = false;
+    for (const void* q : attr_set) seen = seen || q == reinterpret_cast<const void*>(kern);
+    if (!seen) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      for (const void*& q : attr_set)
+        if (q == nullptr) { q = reinterpret_cast<const void*>(kern); break; }
+    }
+  }
+  const bool abl = !pipe && g_v2_ablate > 10 && g_v2_ablate <= 17 && S8 && !fold;
+  if (abl) {
+    switch (g_v2_ablate - 10) {
+      case 1: kern = halo16_conv_kernel<BN, STAGES, 0, false, S8 ? 1 : 0>; break;
+      case 2: kern = halo16_conv_kernel<BN, STAGES, 0, false, S8 ? 2 : 0>; break;
+      case 3: kern = halo16_conv_kernel<BN, STAGES, 0, false, S8 ? 3 : 0>; break;
+      case 4: kern = halo16_conv_kernel<BN, STAGES, 0, false, S8 ? 4 : 0>; break;
+      case 5: kern = halo16_conv_kernel<BN, STAGES, 0, false, S8 ? 5 : 0>; break;
+      case 6: kern = halo16_conv_kernel<BN, STAGES, 0, false, S8 ? 6 : 0>; break;
+      default: kern = halo16_conv_kernel<BN, STAGES, 0, false, S8 ? 7 : 0>; break;
+    }
+  }
+  if (fold && !pipe) kern = halo16_conv_kernel<BN, STAGES, 0, STAGES == 8>;   // (instantiated for the shipped ring depth only)
   if (fold && STAGES != 8) return hipErrorNotSupported;
-  static bool attr_done[3] = {false, false, false};
-  const int which = fold ? 2 : (diag ? 1 : 0);
-  if (!attr_done[which]) {
+  static bool attr_done[16] = {};
+  const int which = fold ? 2 : (abl ? 7 + (g_v2_ablate - 10) : (diag && S8 ? g_v2_ablate - 3 : 0));
+  if (!pipe && !attr_done[which]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_done[which] = true;

@@ -409,7 +409,7 @@ def test_halo_conv_tile_variants_bit_identical(ops):
     finally:
         lib.dei2i_set_option(b"halo_bn", 0)
         lib.dei2i_set_option(b"halo_stages", 0)
-        lib.dei2i_set_option(b"halo16", 1)
+        lib.dei2i_set_option(b"halo16", 3)      # (the shipped default: pipelined loop)
 
 
 @pytest.mark.parametrize("pname", ["f32", "bf16"])
