@@ -77,6 +77,62 @@ __global__ void pack_all_kernel(const float* __restrict__ w, T* __restrict__ fwd
   }
 }
 
+// The same for the weights that matter (the per-element kernel above reads w with a stride of `taps` floats per lane and
+// stores 2 bytes per lane: 0.76 ms per step over ~43 weights, 6x its bytes at HBM speed).  A workgroup takes 32 output
+// channels x 32 input channels x all taps: the OIHW rows of its tile are contiguous runs of 32 * taps floats (coalesced
+// loads into LDS), both packed layouts go out as 16-byte stores -- forward rows [co][tap][ci0 .. ci0+31] (64-byte runs),
+// dgrad rows [ci][class tap][co0 .. co0+31] (64-byte runs).  Padding channels are written as zeros by the tiles that
+// reach past Cin / Cout.
+constexpr int PT_CO = 16, PT_CI = 32, PT_MAXTAPS = 16, PT_ROW = PT_CI + 1;
+template <typename T>
+__global__ __launch_bounds__(256) void pack_tiled_kernel(const float* __restrict__ w, T* __restrict__ fwd, T* __restrict__ dgrad,
+                                                         const PackAll pa, int Cout, int Cin, int CinS, int CoutS, int kh, int kw, int s) {
+  constexpr int VEC = Elem<T>::VEC;
+  // [co_l][tap][ci_l (+1 pad)]: the loads (tap fastest along a lane run) store at a stride of 33 floats, the forward rows read
+  // 8 consecutive floats, the dgrad rows 8 floats at a stride of taps * 33
+  extern __shared__ float tile[];
+  const int taps = kh * kw;
+  const int ci0 = blockIdx.x * PT_CI, co0 = blockIdx.y * PT_CO;
+  const int run = PT_CI * taps;                                // floats of one output channel's piece of the tile
+  for (int i = threadIdx.x; i < PT_CO * run; i += 256) {
+    const int col = i / run, r = i - col * run;                // r = ci_l * taps + tap
+    const int cil = r / taps, t = r - cil * taps;
+    const int co = co0 + col, ci = ci0 + cil;
+    tile[(col * taps + t) * PT_ROW + cil] = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci0) * taps + r] : 0.f;
+  }
+  __syncthreads();
+  // forward layout [co][tap][CinS]
+  constexpr int FCH = PT_CI / VEC;                             // 16-byte chunks per (co, tap) run
+  for (int i = threadIdx.x; i < PT_CO * taps * FCH; i += 256) {
+    const int ch = i % FCH, r = i / FCH;                       // r = col * taps + t
+    const int col = r / taps, t = r - col * taps;
+    const int co = co0 + col, ci = ci0 + ch * VEC;
+    if (co >= Cout || ci >= CinS) continue;                    // (the forward layout has Cout rows; CinS is a multiple of VEC)
+    float v[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = tile[r * PT_ROW + ch * VEC + e];
+    *reinterpret_cast<u32x4*>(fwd + ((size_t)co * taps + t) * CinS + ci) = Elem<T>::pack(v);
+  }
+  // dgrad layout, per parity class k: [Cin][th*tw][CoutS]
+  constexpr int DCH = PT_CO / VEC;
+  for (int k = 0; k < pa.ncls; ++k) {
+    const int th = pa.th[k], tw = pa.tw[k], nt = th * tw;
+    T* dst = dgrad + pa.cls_begin[k];
+    for (int i = threadIdx.x; i < PT_CI * nt * DCH; i += 256) {
+      const int ch = i % DCH, r = i / DCH;
+      const int t = r % nt, cil = r / nt;
+      const int ci = ci0 + cil, co = co0 + ch * VEC;
+      if (ci >= Cin || co >= CoutS) continue;                  // (the dgrad layout has Cin rows)
+      const int jy = t / tw, jx = t - jy * tw;
+      const int tap = (pa.ay[k] + s * jy) * kw + (pa.ax[k] + s * jx);
+      float v[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] = tile[((ch * VEC + e) * taps + tap) * PT_ROW + cil];
+      *reinterpret_cast<u32x4*>(dst + ((size_t)ci * nt + t) * CoutS + co) = Elem<T>::pack(v);
+    }
+  }
+}
+
 __global__ void unpack_wgrad_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin, int CinS,
                                     int taps, float beta) {
   const size_t total = (size_t)Cout * Cin * taps;
@@ -248,6 +304,25 @@ int dei2i_pack_weight_both(const dei2i_conv* c, const float* w, void* packed_fwd
     }
   pa.cls_begin[pa.ncls] = off;
   for (int k = pa.ncls + 1; k < 17; ++k) pa.cls_begin[k] = off;
+  if (c->kh * c->kw <= PT_MAXTAPS && (long long)c->Cout * c->Cin * c->kh * c->kw >= (1 << 16) && c->CoutS % 8 == 0) {
+    const dim3 tg((c->CinS + PT_CI - 1) / PT_CI, (c->CoutS + PT_CO - 1) / PT_CO);
+    const size_t plds = (size_t)PT_CO * c->kh * c->kw * PT_ROW * sizeof(float);       // <= 67.6 KB
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(pack_tiled_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          PT_CO * PT_MAXTAPS * PT_ROW * (int)sizeof(float));
+      hipFuncSetAttribute(reinterpret_cast<const void*>(pack_tiled_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          PT_CO * PT_MAXTAPS * PT_ROW * (int)sizeof(float));
+      attr_done = true;
+    }
+    if (c->dtype == DT_BF16)
+      hipLaunchKernelGGL(pack_tiled_kernel<bf16_t>, tg, dim3(256), plds, (hipStream_t)s, w, (bf16_t*)packed_fwd, (bf16_t*)packed_dgrad, pa,
+                         c->Cout, c->Cin, c->CinS, c->CoutS, c->kh, c->kw, c->stride);
+    else
+      hipLaunchKernelGGL(pack_tiled_kernel<float>, tg, dim3(256), plds, (hipStream_t)s, w, (float*)packed_fwd, (float*)packed_dgrad, pa,
+                         c->Cout, c->Cin, c->CinS, c->CoutS, c->kh, c->kw, c->stride);
+    return (int)hipGetLastError();
+  }
   const unsigned grid = grid_for((size_t)(pa.fwd_total + off), 256);
   if (c->dtype == DT_BF16)
     hipLaunchKernelGGL(pack_all_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, w, (bf16_t*)packed_fwd, (bf16_t*)packed_dgrad,

@@ -3,6 +3,7 @@
 f32 mode is the exact-f32 MFMA parity path (tolerance 2e-4 of the tensor's max); bf16 mode is compared with a
 reference evaluated on bf16-rounded operands (tolerance 1.5e-2 of the max: bf16 output rounding is 2^-9)."""
 import math
+from ctypes import byref
 
 import numpy as np
 import pytest
@@ -492,3 +493,30 @@ def test_weight_used_twice_activation_gradient_only_and_with_foreign_contributio
     xg, y = graph()                                                 # (b): a foreign contribution to the same parameter
     torch.autograd.backward([y, (wg * 3.0).sum()], [gyh, torch.ones((), device=dev())])
     assert maxrel(wg.grad, gw_ref + 3.0) < tol and maxrel(xg.grad, gx_ref) < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pname", ["bf16", "f32"])
+@pytest.mark.parametrize("shape", [(256, 256, 3, 1), (128, 64, 4, 2), (136, 72, 3, 1), (2048, 1024, 4, 2), (64, 250, 3, 1),
+                                   (48, 33, 4, 2)])
+def test_pack_weight_both_matches_the_separate_packers(ops, pname, shape):
+    """dei2i_pack_weight_both (one launch; LDS-tiled for the large weights) writes exactly the bytes of dei2i_pack_weight_fwd +
+    dei2i_pack_weight_dgrad (the per-element kernels whose index functions geom.h documents)."""
+    from de_i2i_gan_amd import _lib as L
+    cout, cin, k, s = shape
+    prec = ops.get_precision(pname)
+    lib = L.load()
+    geom = ops.ConvGeom(cin, cout, k, s, 1, True, False)
+    d = ops._desc(prec, geom, 1, 8, 8, prec.pad(cin), prec.pad(cout))
+    torch.manual_seed(cout + cin)
+    w = torch.randn(cout, cin, k, k, device=dev())
+    nf, nd = lib.dei2i_packed_fwd_elems(byref(d)), lib.dei2i_packed_dgrad_elems(byref(d))
+    f1 = torch.full((nf,), 7.0, dtype=prec.dtype, device=dev())
+    g1 = torch.full((nd,), 7.0, dtype=prec.dtype, device=dev())
+    f2, g2 = torch.full_like(f1, 5.0), torch.full_like(g1, 5.0)
+    L.check(lib.dei2i_pack_weight_both(byref(d), ops._p(w), ops._p(f1), ops._p(g1), ops._stream()), "both")
+    L.check(lib.dei2i_pack_weight_fwd(byref(d), ops._p(w), ops._p(f2), ops._stream()), "fwd")
+    L.check(lib.dei2i_pack_weight_dgrad(byref(d), ops._p(w), ops._p(g2), ops._stream()), "dgrad")
+    torch.cuda.synchronize()
+    assert torch.equal(f1, f2)
+    assert torch.equal(g1, g2)
