@@ -414,9 +414,8 @@ int dei2i_conv2d_dgrad_input(const dei2i_conv* c, const void* dy, const void* wd
     sh.pad_mode = PAD_ZERO;
     const GatherDesc interior = make_dgrad_desc(sh, c->CoutS, 0, 0);          // zero: the input grid itself
     if (c->dtype == DT_BF16 && c->kh == 3 && c->kw == 3 && p == 1) {
-      // large grids: the 16 x 32 tile kernel folds the ring itself (conv_halo16.hip FOLD); only the 4 corners remain
+      // large grids: the 16 x 32 tile kernel folds the ring AND the four corners itself (conv_halo16.hip FOLD): one launch
       hipError_t ef = halo16_conv(interior, dy, wd_packed, c->Cin, nullptr, dx, c->CinS, ACT_NONE, num_cu(), st, nullptr, nullptr, true);
-      if (ef == hipSuccess) return (int)reflect_corners(dy, wd_packed, dx, c->N, c->H, c->W, c->CoutS, c->Cin, c->CinS, st);
       if (ef != hipErrorNotSupported) return (int)ef;
     }
     hipError_t e = gather_gemm(c->dtype, interior, dy, wd_packed, c->Cin, nullptr, dx, ws, ws_bytes, c->CinS, ACT_NONE, st);

@@ -78,7 +78,7 @@ DEI2I_D int sw16(int row) { return ((row >> 2) & 1) << 1; }
 // addressed one tile row above row 0, with the ONE tap row that still reads inside dy -- as two extra 16-pixel blocks
 // (waves wm = 0, 1), ring column -1 / W over the tile's 16 rows as one extra block of 16 rows x 1 column (waves wm = 2 /
 // 3); each is 4 extra MFMAs per wave in 3 of the 9 taps, accumulated apart and added to rows 1 / 14 or columns 1 / 30 of
-// the LDS-staged tile before it is written.  The four frame CORNERS (one pixel each) are left to reflect_corner_kernel.
+// the LDS-staged tile before it is written; the four frame CORNERS (one pixel each) are dot products in the epilogue.
 // DIAG 2 / 3 / 4: stamps + a TIMING-ONLY ablation (results are wrong): 2 = no LDS-DMA inside the loop, 3 = no fragment reads,
 // 4 = no MFMAs (options v2_ablate = 7 / 8 / 9)
 // ABL (options v2_ablate = 10 + ABL, no stamps): the same as a bit mask -- 1 no LDS-DMA in the loop, 2 no fragment reads, 4 no MFMAs
@@ -691,6 +691,42 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
       __syncthreads();
       if (ring_kind >= 3 && (l16 >> 3) == half) ring_add((l16 & 7) * 32 + (ring_kind == 3 ? 1 : H16_TW - 2));
       __syncthreads();
+      // the frame's CORNER pixel, if this half holds its image: frame (-1,-1) is read by output (0,0) only, through kernel tap
+      // (0,0), and reflects onto input pixel (1,1): dx[1][1] += W[:,:,0,0]^T dy[0][0]; likewise (-1,W) -> dx[1][W-2] through
+      // tap (0,2) with dy[0][W-1], (H,-1) -> dx[H-2][1] through (2,0) with dy[H-1][0], (H,W) -> dx[H-2][W-2] through (2,2)
+      // with dy[H-1][W-1].  One dot product of length Cs per output channel: 4 threads per channel, summed through LDS.
+      {
+        const bool lef = x0 == 0, rig = x0 + H16_TW == g.Wo;
+        const bool has = (half == 0 ? y0 == 0 : y0 + H16_TH == g.Ho) && (lef || rig);      // workgroup-uniform
+        if (has) {
+          const int ky = half == 0 ? 0 : 2, kx = lef ? 0 : 2;
+          const int sy = ky ? g.Ho - 1 : 0, sx = kx ? g.Wo - 1 : 0;
+          const int crow = (half == 0 ? 1 : 6) * 32 + (kx ? H16_TW - 2 : 1);
+          const int c = tid % BN, part = tid / BN;
+          const int per = g.Cs >> 2;                            // Cs % 32 == 0: a multiple of 8
+          float sum = 0.f;
+          if (part < 4 && n0 + c < wrows) {
+            const bf16_t* wrow = wgt + (size_t)(n0 + c) * g.K + (ky * 3 + kx) * g.Cs + part * per;
+            const bf16_t* dyp = src + ((size_t)(img * g.Hs + sy) * g.Ws + sx) * g.Cs + part * per;
+            for (int q = 0; q < per; q += 8) {
+              float w8[8], d8[8];
+              Elem<bf16_t>::unpack(*reinterpret_cast<const u32x4*>(wrow + q), w8);
+              Elem<bf16_t>::unpack(*reinterpret_cast<const u32x4*>(dyp + q), d8);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) sum = fmaf(w8[e], d8[e], sum);
+            }
+          }
+          float* cred = reinterpret_cast<float*>(smem + 256 * CROW);
+          if (part < 4) cred[part * BN + c] = sum;
+          __syncthreads();
+          if (tid < BN) {
+            const float tot = (cred[c] + cred[BN + c]) + (cred[2 * BN + c] + cred[3 * BN + c]);
+            bf16_t* p = reinterpret_cast<bf16_t*>(ctile + crow * CROW) + c;
+            *p = f32_to_bf16(bf16_to_f32(*p) + tot);
+          }
+          __syncthreads();
+        }
+      }
     }
     if (ncol < ldc) {
 #pragma unroll
@@ -1093,34 +1129,6 @@ static hipError_t launch_halo16w4(const GatherDesc& g, const void* src, const vo
   return hipGetLastError();
 }
 
-// The four corners of the padded frame of a reflect-padded 3x3 conv's input gradient: frame pixel (-1,-1) is the image of
-// input pixel (1,1) and only output (0,0) reads it, through kernel tap (0,0): dx[1][1] += W[:,:,0,0]^T dy[0][0]; likewise
-// (-1,W) -> dx[1][W-2] += W[..,0,2]^T dy[0][W-1], (H,-1) -> dx[H-2][1] += W[..,2,0]^T dy[H-1][0], (H,W) -> dx[H-2][W-2] +=
-// W[..,2,2]^T dy[H-1][W-1].  wd: the dgrad-packed weights [Cin][9][CoutS].  grid (4, N); runs after the FOLD launch.
-__global__ __launch_bounds__(256) void reflect_corner_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ wd,
-                                                             bf16_t* __restrict__ dx, int H, int W, int CoutS, int Cin, int CinS) {
-  extern __shared__ float dyv[];
-  const int corner = blockIdx.x, n = blockIdx.y;
-  const int ky = corner >> 1 ? 2 : 0, kx = corner & 1 ? 2 : 0;
-  const int sy = ky ? H - 1 : 0, sx = kx ? W - 1 : 0;             // dy pixel read
-  const int ty = ky ? H - 2 : 1, tx = kx ? W - 2 : 1;             // dx pixel written
-  const bf16_t* src = dy + ((size_t)(n * H + sy) * W + sx) * CoutS;
-  for (int c = threadIdx.x; c < CoutS; c += 256) dyv[c] = bf16_to_f32(src[c]);
-  __syncthreads();
-  bf16_t* dst = dx + ((size_t)(n * H + ty) * W + tx) * CinS;
-  for (int ci = threadIdx.x; ci < Cin; ci += 256) {
-    const bf16_t* wrow = wd + ((size_t)ci * 9 + ky * 3 + kx) * CoutS;
-    float s = 0.f;
-    for (int c = 0; c < CoutS; c += 8) {
-      float w8[8];
-      Elem<bf16_t>::unpack(*reinterpret_cast<const u32x4*>(wrow + c), w8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) s = fmaf(w8[e], dyv[c + e], s);
-    }
-    dst[ci] = f32_to_bf16(bf16_to_f32(dst[ci]) + s);
-  }
-}
-
 extern int g_halo_bn, g_halo_stages;
 int g_halo16 = 3;
 int g_halo16_fold = 1;         // A/B option "halo16_fold": 0 = ring GEMM + finalize + border fold as separate launches              // A/B option "halo16": 0 = always the 8 x 32 tile kernel (conv_halo.hip)
@@ -1209,8 +1217,8 @@ static hipError_t launch_halo16(const GatherDesc& g, const void* src, const void
 
 // returns hipErrorNotSupported when the shape does not qualify (the caller goes on to the 8 x 32 tile kernel)
 // ring: see the kernel (SPADE -> upsample -> conv with z kept at the source resolution); only the 8-wave kernel takes it
-// fold: the launch is the interior input gradient of a reflect-padded 3x3 conv and also folds the frame's ring (not its
-// corners: reflect_corners) into the border rows / columns -- see the kernel
+// fold: the launch is the interior input gradient of a reflect-padded 3x3 conv and also folds the frame's ring and corners
+// into the border rows / columns -- see the kernel
 hipError_t halo16_conv(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out, int ldc,
                        int act, int num_cu, hipStream_t st, float* stats, const void* ring, bool fold) {
   if (fold && (!g_halo16_fold || g.ys >= 0 || g.xs >= 0 || g.pad_mode != PAD_ZERO || g.up || g.Ho < 2 * H16_TH || g.Wo < 2 * H16_TW ||
@@ -1239,13 +1247,6 @@ hipError_t halo16_conv(const GatherDesc& g, const void* src, const void* wgt, in
   }
   if (g_halo16_stages == 4) return launch_halo16<64, 4>(g, src, wgt, wrows, bias, out, ldc, act, st, stats);
   return launch_halo16<64, 8>(g, src, wgt, wrows, bias, out, ldc, act, st, stats, ring, fold);
-}
-
-hipError_t reflect_corners(const void* dy, const void* wd_packed, void* dx, int N, int H, int W, int CoutS, int Cin, int CinS,
-                           hipStream_t st) {
-  hipLaunchKernelGGL(reflect_corner_kernel, dim3(4, N), dim3(256), (size_t)CoutS * sizeof(float), st, (const bf16_t*)dy,
-                     (const bf16_t*)wd_packed, (bf16_t*)dx, H, W, CoutS, Cin, CinS);
-  return hipGetLastError();
 }
 
 }  // namespace dei2i

@@ -57,7 +57,7 @@ def maxrel(a, b):
 # DESIGN.md as open): D's first-conv dgrad (64 -> 3 channels, stride 2), the wgrads of the 64-channel-input stride-2 convs
 # and of D's first and last conv, D's last conv forward (M = 1024 rows: split-K generic GEMM).
 R, V2, V1 = {"halo_conv": 1, "gather_v1": 1}, {"gather_v2": 1}, {"gather_v1": 1}
-R16 = {"halo16_conv": 1}                            # 16 x 32 tile kernel: interior AND the reflect ring folded in-kernel (+ a corner kernel)
+R16 = {"halo16_conv": 1}                            # 16 x 32 tile kernel: interior, reflect ring and the four frame corners in ONE launch
 HOT = [
     ("res 256->256 3x3 @64^2 N=16", 256, 256, 3, 1, 1, False, 64, 64, 16, "none", "halo16_conv", R16, "wgrad_halo"),
     ("res 256->256 3x3 @64^2 N=8", 256, 256, 3, 1, 1, False, 64, 64, 8, "none", "halo_conv", R, "wgrad_halo"),
