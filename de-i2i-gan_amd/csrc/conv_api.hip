@@ -94,11 +94,25 @@ __global__ __launch_bounds__(256) void pack_tiled_kernel(const float* __restrict
   const int taps = kh * kw;
   const int ci0 = blockIdx.x * PT_CI, co0 = blockIdx.y * PT_CO;
   const int run = PT_CI * taps;                                // floats of one output channel's piece of the tile
-  for (int i = threadIdx.x; i < PT_CO * run; i += 256) {
-    const int col = i / run, r = i - col * run;                // r = ci_l * taps + tap
-    const int cil = r / taps, t = r - cil * taps;
-    const int co = co0 + col, ci = ci0 + cil;
-    tile[(col * taps + t) * PT_ROW + cil] = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci0) * taps + r] : 0.f;
+  // (run <= 512: a thread owns the positions r = tid and tid + 256 of every output channel's run -- no divisions in the
+  //  loop, and the 32 loads of a thread are issued before the first LDS store)
+  {
+    const int r0 = threadIdx.x, r1 = threadIdx.x + 256;
+    const int cil0 = r0 / taps, t0 = r0 - cil0 * taps, cil1 = r1 / taps, t1 = r1 - cil1 * taps;
+    const bool in0 = r0 < run && ci0 + cil0 < Cin, in1 = r1 < run && ci0 + cil1 < Cin;
+    float v0[PT_CO], v1[PT_CO];
+#pragma unroll
+    for (int col = 0; col < PT_CO; ++col) {
+      const float* wr = w + ((size_t)(co0 + col) * Cin + ci0) * taps;
+      const bool row = co0 + col < Cout;
+      v0[col] = (row && in0) ? wr[r0] : 0.f;
+      v1[col] = (row && in1) ? wr[r1] : 0.f;
+    }
+#pragma unroll
+    for (int col = 0; col < PT_CO; ++col) {
+      if (r0 < run) tile[(col * taps + t0) * PT_ROW + cil0] = v0[col];
+      if (r1 < run) tile[(col * taps + t1) * PT_ROW + cil1] = v1[col];
+    }
   }
   __syncthreads();
   // forward layout [co][tap][CinS]
