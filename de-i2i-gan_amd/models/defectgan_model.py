@@ -1,6 +1,7 @@
 """DefectGanModel (models/defectgan_model.py:18-171,173-314,361-383): the loss graphs of the D step and the G step of the
 defectGAN stage, and of the MAE-GAN pre-training stage (modes ``mae_*``)."""
 import os
+import random
 
 import torch
 
@@ -18,11 +19,22 @@ class DefectGanModel(BaseModel):
         super().__init__(opt)
         image_size = opt.image_size
         assert image_size & (image_size - 1) == 0, "Image size must be a power of 2"
-        if opt.style_norm_block_type not in ("spade", "adain"):
-            raise NotImplementedError("style_norm_block_type: 'spade' (the reference default) and 'adain' are implemented; "
-                                      "'sean' is not (SURVEY.md section 8f rank 3)")
+        if opt.style_norm_block_type not in ("spade", "adain", "sean"):
+            raise ValueError(f"|style_norm_block_type {opt.style_norm_block_type}| is invalid")
         self.netG = DefectGanGenerator(opt).to(opt.device, non_blocking=True)
         self.netD = DefectGanDiscriminator(opt).to(opt.device, non_blocking=True)
+        if opt.style_norm_block_type == "sean":          # style embeddings (defectgan_model.py:34-45)
+            if getattr(opt, "use_running_stats", False):
+                raise NotImplementedError("SEAN: --use_running_stats is not implemented")
+            if opt.sean_alpha is not None:
+                self.netG.set_sean_alpha(opt.sean_alpha)
+            if opt.sean_alpha != 0:
+                assert opt.embed_path is not None, ("embed_path should be initialized if style_norm_block_type is sean and "
+                                                    "sean_alpha is not 0")
+                # {label tuple: [embedding (embed_nc,), ...]} -- the user's own file; loaded without executing anything from it
+                self.embeddings = torch.load(opt.embed_path, weights_only=True)
+                for label, embeds in self.embeddings.items():
+                    self.embeddings[label] = [e.to(opt.device, non_blocking=True) for e in embeds]
         if opt.style_norm_block_type == "adain":         # style embedding network, trained by the G loss (defectgan_model.py:46-47)
             from ..networks.extractor import StyleExtractor
             self.netE = StyleExtractor(opt).to(opt.device, non_blocking=True)
@@ -99,7 +111,12 @@ class DefectGanModel(BaseModel):
             row0, col0, keep = draw_shifted_mask(imgs.size(), self.opt.patch_size, self.opt.mask_ratio)
             masks = expand_shifted_mask(self._upload_mask(keep), row0, col0, self.opt.patch_size, imgs.size(2), imgs.size(3))
         self.netG.clear_spade_cache()
-        predicted, _ = self.netG(self.mask_token(imgs, masks), self._expand_seg(labels))
+        if self.opt.style_norm_block_type == "sean":             # defectgan_model.py:370-372
+            predicted, _ = self.netG(self.mask_token(imgs, masks), labels, self._get_style_embeds(labels))
+        elif self.opt.style_norm_block_type == "adain":          # :377-379
+            predicted, _ = self.netG(self.mask_token(imgs, masks), labels, self.netE(imgs, labels))
+        else:
+            predicted, _ = self.netG(self.mask_token(imgs, masks), self._expand_seg(labels))
         return predicted, masks
 
     def _upload_mask(self, masks):
@@ -222,7 +239,25 @@ class DefectGanModel(BaseModel):
         self.netG.clear_spade_cache()
         if self.opt.style_norm_block_type == "adain":            # defectgan_model.py:310-312
             return self.netG(data, labels, self.netE(data, labels))
+        if self.opt.style_norm_block_type == "sean":             # :304-306
+            return self.netG(data, labels, self._get_style_embeds(labels))
         return self.netG(data, self._expand_seg(labels))
+
+    def _get_style_embeds(self, labels):
+        """defectgan_model.py:394-411: per sample ``num_embeds`` embeddings drawn (python's ``random.choices``, like the
+        reference) from the list stored for its label tuple -- zeros when that list is empty; None with --sean_alpha 0."""
+        if self.opt.sean_alpha == 0:
+            return None
+        num_embeds = self.opt.num_embeds
+        embed_list = []
+        for label in labels.reshape(labels.size(0), -1):
+            tuple_label = tuple(label.int().tolist())
+            if not self.embeddings[tuple_label]:
+                mean_embed = torch.zeros(num_embeds, self.opt.embed_nc, device=self.opt.device)
+            else:
+                mean_embed = torch.stack(random.choices(self.embeddings[tuple_label], k=num_embeds))
+            embed_list.append(mean_embed)
+        return torch.stack(embed_list)
 
     @staticmethod
     def _expand_seg(labels):
@@ -242,6 +277,8 @@ class DefectGanModel(BaseModel):
     def _style_feats(self, bg_data, nm_labels, df_labels, df_data):
         """-> (nm_label_feat, df_label_feat): netE(bg, nm_labels) then netE(df, df_labels) for the AdaIN decoder
         (defectgan_model.py:423-425), (None, None) for SPADE."""
+        if self.opt.style_norm_block_type == "sean":             # :417-419: the normal labels' embeddings are drawn first
+            return self._get_style_embeds(nm_labels), self._get_style_embeds(df_labels)
         if self.opt.style_norm_block_type != "adain":
             return None, None
         n = nm_labels.shape[0]

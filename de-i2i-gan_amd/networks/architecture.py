@@ -424,13 +424,86 @@ class AdaIN(nn.Module):
         return ops.spade_relu(x, self._class_table(style_feat, ops.precision_of(x), x.shape[-1]), up, 1, skip=skip)
 
 
-def _style_norm(style_norm_block_type, label_nc, f, hidden_nc):
+def label_to_str(label):
+    """utils/util.py:178-180: the indices of the set bits, joined by '-' ('' for the all-zero label)"""
+    return "-".join(str(i) for i, v in enumerate(label) if v == 1)
+
+
+class SEAN(nn.Module):
+    """normalization.py:76-202: ``IN(x) * (1 + gamma) + beta`` with per-(n, c) gamma / beta from Linear layers on a mixed
+    style code: ``latent = ReLU(Linear(labels))``; without style embeddings (``feat is None``: --sean_alpha 0) the code IS the
+    latent; with embeddings ``feat`` (N, num_embeds, embed_nc) it is ``mean_e(ReLU(Linear(feat)) + latent)``, rows that come
+    out all-zero replaced by the latent (:177-179).  Like AdaIN the modulation does not vary over space, so it runs on the
+    SPADE kernels with a constant (N, 5, 5, 2C) table; the Linear layers ((N * num_embeds) x embed_nc x hidden_nc and smaller)
+    go through torch's library GEMM.  The ``mean_<labels>`` / ``std_<labels>`` buffers of every multi-label combination
+    (:104-109) exist for state_dict compatibility; ``--use_running_stats`` (inference from them) and ``--style_distill`` are
+    not implemented.  ``alpha`` is stored by ``set_alpha`` and, as in the reference, read by nothing."""
+
+    def __init__(self, embed_nc, norm_nc, label_nc, hidden_nc=128, latent_dim=16, norm_layer=None, style_distill=False):
+        super().__init__()
+        if style_distill:
+            raise NotImplementedError("SEAN: --style_distill (the distillation losses with their own backward) is not implemented")
+        self.style_distill = False
+        self.latent_dim, self.label_nc, self.hidden_nc, self.norm_nc = latent_dim, label_nc, hidden_nc, norm_nc
+        self.noise_dim = latent_dim - label_nc
+        self.alpha = 1.0
+        self.param_free_norm = Act("instance_norm(affine=False)")
+        self.mlp_shared = nn.Sequential(nn.Linear(embed_nc, hidden_nc), nn.ReLU(inplace=True))
+        self.mlp_gamma = nn.Linear(hidden_nc, norm_nc)
+        self.mlp_beta = nn.Linear(hidden_nc, norm_nc)
+        self.mlp_latent = nn.Sequential(nn.Linear(label_nc, hidden_nc), nn.ReLU(inplace=True))
+        for bits in range(1 << label_nc):             # torch.cartesian_prod order: the first label is the slowest digit
+            label = [(bits >> (label_nc - 1 - i)) & 1 for i in range(label_nc)]
+            self.register_buffer("mean_" + label_to_str(label), torch.zeros(hidden_nc))
+            self.register_buffer("std_" + label_to_str(label), torch.zeros(hidden_nc))
+        self.inference_running_stats = False
+        self.track_running_stats = False
+
+    def set_alpha(self, alpha):
+        self.alpha = alpha
+
+    def _class_table(self, cond, prec, c_stride):
+        labels, feat = cond
+        n = labels.size(0)
+        labels = labels.reshape(n, -1).float()
+        latent_code = self.mlp_latent(labels)
+        if feat is None:
+            mix_feat = latent_code
+        else:
+            if self.inference_running_stats or self.track_running_stats:
+                raise NotImplementedError("SEAN: --use_running_stats is not implemented")
+            enc_feat = self.mlp_shared(feat.float())
+            mix_feat = enc_feat + latent_code.view(n, 1, -1)
+            if mix_feat.dim() == 3:
+                mix_feat = mix_feat.mean(dim=1)
+            mask = (mix_feat == 0).all(dim=1).view(-1, 1)
+            mix_feat = mix_feat * ~mask + latent_code * mask
+        gb = torch.cat([nn.functional.pad(self.mlp_gamma(mix_feat), (0, c_stride - self.norm_nc)),
+                        nn.functional.pad(self.mlp_beta(mix_feat), (0, c_stride - self.norm_nc))], dim=1)     # (N, 2 * c_stride)
+        return gb.to(prec.dtype).view(n, 1, 1, 2 * c_stride).expand(n, 5, 5, 2 * c_stride).contiguous()
+
+    fused_conv = AdaIN.fused_conv            # (cond = (labels, feat) instead of the style feature: only _class_table reads it)
+    forward = AdaIN.forward
+
+
+def _style_norm(style_norm_block_type, label_nc, f, hidden_nc, embed_nc=None, style_distill=False):
     if style_norm_block_type == "spade":
         return SPADE(label_nc, f, hidden_nc=hidden_nc)
     if style_norm_block_type == "adain":
         return AdaIN(f, hidden_nc=hidden_nc)
-    raise NotImplementedError(f"style_norm_block_type [{style_norm_block_type}] is not implemented yet "
-                              "(SURVEY.md section 8f rank 3: SEAN)")
+    if style_norm_block_type == "sean":
+        assert embed_nc is not None, "embed_nc must be specified for SEAN"
+        return SEAN(embed_nc, f, label_nc, hidden_nc=hidden_nc, style_distill=style_distill)
+    raise NotImplementedError(f"style_norm_block_type [{style_norm_block_type}] is not implemented")
+
+
+def _norm_cond(style_norm_block_type, labels, style_feat):
+    """norm_forward of the decoder blocks (architecture.py:246-254,363-371): what the block's norm layer is given"""
+    if style_norm_block_type == "adain":
+        return style_feat
+    if style_norm_block_type == "sean":
+        return (labels, style_feat)
+    return labels
 
 
 class NormConvBlock(nn.Module):
@@ -446,13 +519,13 @@ class NormConvBlock(nn.Module):
         self.up = Act("nearest x2" if up_scale else None)
         self.noise = _noise(add_noise)
         self.style_norm_block_type = style_norm_block_type
-        self.norm = _style_norm(style_norm_block_type, label_nc, f_in, hidden_nc)
+        self.norm = _style_norm(style_norm_block_type, label_nc, f_in, hidden_nc, embed_nc, style_distill)
         self.conv = make_conv(use_spectral, f_in, f_out, kernel_size, stride, padding, padding_mode, bias)
         self.act = get_act_layer(act_layer)
 
     def forward(self, x, labels, style_feat=None, out_stats=False):
         """``out_stats``: another norm layer reads the output next (the following NormConvBlock's SPADE)."""
-        cond = style_feat if self.style_norm_block_type == "adain" else labels     # norm_forward, architecture.py:246-254
+        cond = _norm_cond(self.style_norm_block_type, labels, style_feat)
         return self.noise(self.norm.fused_conv(x, cond, self.conv, up=self.up_scale, stats=out_stats))
 
 
@@ -473,9 +546,9 @@ class NormResBlock(nn.Module):
         self.noise_0, self.noise_1 = _noise(add_noise), _noise(add_noise)
         f_mid = min(f_in, f_out)
         self.style_norm_block_type = style_norm_block_type
-        self.norm_0 = _style_norm(style_norm_block_type, label_nc, f_in, hidden_nc)
-        self.norm_1 = _style_norm(style_norm_block_type, label_nc, f_mid, hidden_nc)
-        self.norm_s = _style_norm(style_norm_block_type, label_nc, f_in, hidden_nc)
+        self.norm_0 = _style_norm(style_norm_block_type, label_nc, f_in, hidden_nc, embed_nc, style_distill)
+        self.norm_1 = _style_norm(style_norm_block_type, label_nc, f_mid, hidden_nc, embed_nc, style_distill)
+        self.norm_s = _style_norm(style_norm_block_type, label_nc, f_in, hidden_nc, embed_nc, style_distill)
         self.act = get_act_layer(act_layer)
         self.conv_0 = make_conv(use_spectral, f_in, f_mid, kernel_size, stride, padding, padding_mode, bias)
         self.conv_1 = make_conv(use_spectral, f_mid, f_out, kernel_size, stride, padding, padding_mode, bias)
@@ -483,7 +556,7 @@ class NormResBlock(nn.Module):
 
     def forward(self, x, labels, style_feat=None, out_stats=False):
         # norm_0 hands x through (xs) so that the identity branch's gradient is added inside its backward kernel
-        cond = style_feat if self.style_norm_block_type == "adain" else labels     # norm_forward, architecture.py:363-371
+        cond = _norm_cond(self.style_norm_block_type, labels, style_feat)
         if x.is_contiguous():
             h, xs = self.norm_0.fused_conv(x, cond, self.conv_0, skip=True, stats=True)
         else:

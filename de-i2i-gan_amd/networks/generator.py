@@ -105,5 +105,15 @@ class DefectGanGenerator(BaseNetwork):
                 m._gb_cache.clear()
 
     def update_per_epoch(self, epoch):
+        """generator.py:277-284"""
         super().update_per_epoch(epoch)
-        _ = (1 + math.cos(math.pi * epoch / self.opt.num_epochs)) / 2      # SEAN alpha schedule; SPADE has no use for it
+        alpha = (1 + math.cos(math.pi * epoch / self.opt.num_epochs)) / 2
+        if self.opt.style_norm_block_type == "sean" and self.opt.sean_alpha is None:
+            self.set_sean_alpha(alpha)
+
+    def set_sean_alpha(self, alpha):
+        """generator.py:286-289"""
+        from .architecture import SEAN
+        for m in self.modules():
+            if isinstance(m, SEAN):
+                m.set_alpha(alpha)

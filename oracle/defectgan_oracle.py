@@ -49,6 +49,8 @@ class Cfg:
     diff_aug: str = ""                                  # --diff_aug policy list (utils/diffaug.py; defectgan_model.py:200-203,266-270)
     style_norm: str = "spade"                           # --style_norm_block_type: spade | adain (generator.py:140-152,179-191)
     latent_dim: int = 16                                # adain: StyleExtractor input = [labels | N(0,1) noise] (extractor.py:36-96)
+    embed_nc: int = 768                                 # sean: width of the style embeddings (defectgan_options.py:65)
+    num_embeds: int = 5                                 # sean: embeddings drawn per sample (defectgan_options.py:68)
 
 
 # --------------------------------------------------------------------------- #
@@ -192,12 +194,71 @@ def adain(S: Dict[str, Tensor], prefix: str, x: Tensor, style_feat: Tensor) -> T
     return normalized * (1 + gamma) + beta
 
 
+def sean(S: Dict[str, Tensor], prefix: str, x: Tensor, labels: Tensor, feat: Optional[Tensor]) -> Tensor:
+    """SEAN.forward -- normalization.py:139-202 (style_distill off, no running-stats inference): latent code from the labels;
+    without embeddings (feat None: sean_alpha 0) it is the style code, with embeddings (N, num_embeds, embed_nc) the code is
+    the mean over the embeddings of ReLU(Linear(feat)) + latent, all-zero rows replaced by the latent (:177-179)."""
+    n, c = x.shape[:2]
+    normalized = instancenorm(x)
+    labels = labels.reshape(n, -1)
+    latent = relu(F.linear(labels, S[prefix + ".mlp_latent.0.weight"], S[prefix + ".mlp_latent.0.bias"]))
+    if feat is None:
+        mix = latent
+    else:
+        enc = relu(F.linear(feat, S[prefix + ".mlp_shared.0.weight"], S[prefix + ".mlp_shared.0.bias"]))
+        mix = enc + latent.view(n, 1, -1)
+        if mix.dim() == 3:
+            mix = mix.mean(dim=1)
+        mask = (mix == 0).all(dim=1).view(-1, 1)
+        mix = mix * ~mask + latent * mask
+    gamma = F.linear(mix, S[prefix + ".mlp_gamma.weight"], S[prefix + ".mlp_gamma.bias"]).view(n, c, 1, 1)
+    beta = F.linear(mix, S[prefix + ".mlp_beta.weight"], S[prefix + ".mlp_beta.bias"]).view(n, c, 1, 1)
+    return normalized * (1 + gamma) + beta
+
+
 def style_norm(S: Dict[str, Tensor], prefix: str, x: Tensor, labels: Tensor, style_feat: Optional[Tensor]) -> Tensor:
-    """norm_forward of the decoder blocks (architecture.py:246-254,363-371): SPADE on the label map, or AdaIN on the
-    style feature -- told apart by the parameters the block owns."""
+    """norm_forward of the decoder blocks (architecture.py:246-254,363-371): SPADE on the label map, AdaIN on the style
+    feature, SEAN on labels + style embeddings -- told apart by the parameters the block owns."""
+    if prefix + ".mlp_latent.0.weight" in S:
+        return sean(S, prefix, x, labels, style_feat)
     if prefix + ".mlp_shared.0.weight" in S:
         return spade(S, prefix, x, labels)
     return adain(S, prefix, x, style_feat)
+
+
+def label_to_str(label) -> str:
+    """utils/util.py:178-180"""
+    return "-".join(str(i) for i, v in enumerate(label) if v == 1)
+
+
+def multilabel_combinations(label_nc: int):
+    """utils/util.py:183-186 (torch.cartesian_prod of [0, 1] x label_nc: the first label is the slowest digit)"""
+    return [tuple((bits >> (label_nc - 1 - i)) & 1 for i in range(label_nc)) for bits in range(1 << label_nc)]
+
+
+def synthetic_embeddings(cfg: "Cfg", per_label: int = 3) -> Dict[tuple, list]:
+    """A synthetic style-embedding file for the SEAN goldens ({label tuple: [embedding (embed_nc,), ...]}, the structure
+    defectgan_model.py:43-45 loads): formula-filled embeddings for the one-hot labels and for the label pairs the synthetic
+    batch uses, an EMPTY list for every other combination (the reference then feeds zeros, :405-406)."""
+    emb = {}
+    for lab in multilabel_combinations(cfg.label_nc):
+        k = sum(lab)
+        emb[lab] = [formula_tensor("embed." + label_to_str(lab) + f".{j}", (cfg.embed_nc,)) for j in range(per_label)] if 1 <= k <= 2 else []
+    return emb
+
+
+def get_style_embeds(embeddings, labels: Tensor, cfg: "Cfg", rng) -> Optional[Tensor]:
+    """DefectGanModel._get_style_embeds -- defectgan_model.py:394-411; rng: python's ``random`` module (or a random.Random)."""
+    if embeddings is None:
+        return None
+    out = []
+    for label in labels.reshape(labels.shape[0], -1):
+        key = tuple(label.int().tolist())
+        if not embeddings[key]:
+            out.append(torch.zeros(cfg.num_embeds, cfg.embed_nc, dtype=labels.dtype))
+        else:
+            out.append(torch.stack(rng.choices(embeddings[key], k=cfg.num_embeds)).to(labels.dtype))
+    return torch.stack(out)
 
 
 def style_extractor(SE: Dict[str, Tensor], x: Tensor, labels: Tensor, cfg: "Cfg") -> Tensor:
@@ -390,6 +451,8 @@ def _style_feats(SE, bg: Tensor, df_labels: Tensor, df: Tensor, cfg: Cfg):
         return None, None
     nm = torch.zeros_like(df_labels)
     nm[:, 0] = 1
+    if isinstance(SE, tuple):                           # sean: (embeddings, rng) -- :417-419, the normal labels are drawn first
+        return get_style_embeds(SE[0], nm, cfg, SE[1]), get_style_embeds(SE[0], df_labels, cfg, SE[1])
     nm_feat = style_extractor(SE, bg, nm, cfg)
     df_feat = style_extractor(SE, df, df_labels, cfg)
     return nm_feat, df_feat
@@ -478,8 +541,11 @@ def adam_update(S: Dict[str, Tensor], grads: Dict[str, Optional[Tensor]], st: Ad
 # the step (trainers/defectgan_trainer.py:138-180)
 # --------------------------------------------------------------------------- #
 def param_keys(S: Dict[str, Tensor]) -> List[str]:
-    return [k for k in S if not (k.endswith("running_mean") or k.endswith("running_var")
-                                 or k.endswith("num_batches_tracked") or k.endswith("weight_u") or k.endswith("weight_v"))]
+    def buffer(k):
+        leaf = k.rsplit(".", 1)[-1]
+        return (leaf in ("running_mean", "running_var", "num_batches_tracked", "weight_u", "weight_v")
+                or leaf.startswith("mean_") or leaf.startswith("std_"))       # SEAN's per-label statistics buffers
+    return [k for k in S if not buffer(k)]
 
 
 def _grads(loss: Tensor, S: Dict[str, Tensor]) -> Dict[str, Optional[Tensor]]:
@@ -503,13 +569,14 @@ def train_generator_once(SG, SD, stG: AdamState, bg, df_labels, df, cfg: Cfg, sc
     is trained by the G loss through optimizers['E']) -> (5 losses, grads of G, grads of E)."""
     for k in param_keys(SG):
         SG[k].requires_grad_(True)
-    if SE is not None:
+    trained_e = SE is not None and not isinstance(SE, tuple)      # (sean: SE = (embeddings, rng), nothing to train)
+    if trained_e:
         for k in param_keys(SE):
             SE[k].requires_grad_(True)
     gan, clf, rec, cyc, con = generator_losses(SG, SD, bg, df_labels, df, cfg, SE)
     w = cfg.loss_weight
     g_loss = gan + clf * w[1] + rec * w[2] + cyc * w[3] + con * w[4]
-    if SE is not None:
+    if trained_e:
         keys_g, keys_e = param_keys(SG), param_keys(SE)
         gs = torch.autograd.grad(g_loss * scale, [SG[k] for k in keys_g] + [SE[k] for k in keys_e], allow_unused=True)
         return (tuple(t.detach() for t in (gan, clf, rec, cyc, con)), dict(zip(keys_g, gs[:len(keys_g)])),
@@ -544,6 +611,19 @@ def generator_state_shapes(cfg: Cfg) -> Dict[str, Tuple[int, ...]]:
         sh[prefix + ".num_batches_tracked"] = ()
 
     def sp(prefix, c):
+        if cfg.style_norm == "sean":                    # normalization.py:92-109 (state_dict order: the module's own buffers, then its children)
+            for lab in multilabel_combinations(cfg.label_nc):
+                sh[prefix + ".mean_" + label_to_str(lab)] = (cfg.hidden_nc,)
+                sh[prefix + ".std_" + label_to_str(lab)] = (cfg.hidden_nc,)
+            sh[prefix + ".mlp_shared.0.weight"] = (cfg.hidden_nc, cfg.embed_nc)
+            sh[prefix + ".mlp_shared.0.bias"] = (cfg.hidden_nc,)
+            sh[prefix + ".mlp_gamma.weight"] = (c, cfg.hidden_nc)
+            sh[prefix + ".mlp_gamma.bias"] = (c,)
+            sh[prefix + ".mlp_beta.weight"] = (c, cfg.hidden_nc)
+            sh[prefix + ".mlp_beta.bias"] = (c,)
+            sh[prefix + ".mlp_latent.0.weight"] = (cfg.hidden_nc, cfg.label_nc)
+            sh[prefix + ".mlp_latent.0.bias"] = (cfg.hidden_nc,)
+            return
         if cfg.style_norm == "adain":                   # normalization.py:52-53: two Linear(hidden_nc, norm_nc)
             sh[prefix + ".mlp_gamma.weight"] = (c, cfg.hidden_nc)
             sh[prefix + ".mlp_gamma.bias"] = (c,)

@@ -1,0 +1,149 @@
+"""The SEAN decoder variant (--style_norm_block_type sean, --sean_alpha 1: style embeddings from an embeddings file mixed with
+the label latent; reference: models/networks/normalization.py:76-202, defectgan_model.py:34-45,
+304-306,394-419, generator.py:277-289) against the fixture made by the reference's own trainer
+(tests/golden/gen_sean_golden.py -> t6_img64_b2_sean): state_dict keys of G / D (including SEAN's per-label statistics
+buffers, in the reference's order), the inference-mode forward, and two D+G steps (losses, post-step parameter norms).
+The embeddings file is synthetic (oracle.synthetic_embeddings) and python's ``random`` -- which draws the embeddings, as
+in the reference -- is seeded as the fixture's generator seeded it.  The CPU half pins the oracle to the same fixture."""
+import json
+import random
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import formula_fill, make_opt
+from oracle import defectgan_oracle as O
+
+GOLD = Path(__file__).resolve().parent / "golden"
+NAME = "t6_img64_b2_sean"
+DEV = "cuda:0"
+
+
+def load():
+    meta = json.loads((GOLD / f"{NAME}.json").read_text())
+    arr = np.load(GOLD / f"{NAME}.npz")
+    c = meta["config"]
+    cfg = O.Cfg(image_size=c["image_size"], ngf=c["ngf"], ndf=c["ndf"], num_layers=c["num_layers"], hidden_nc=c["hidden_nc"],
+                style_norm="sean", embed_nc=c["embed_nc"], num_embeds=c["num_embeds"])
+    return meta, arr, c, cfg
+
+
+def maxrel(a, b):
+    a, b = torch.as_tensor(np.asarray(a)).double(), torch.as_tensor(np.asarray(b)).double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+def test_oracle_sean_matches_the_reference_fixture():
+    meta, arr, c, cfg = load()
+    seed = meta["seed"]
+    SG, SD = (O.make_state(f(cfg)) for f in (O.generator_state_shapes, O.discriminator_state_shapes))
+    assert list(SG.keys()) == meta["G_keys"] and list(SD.keys()) == meta["D_keys"]
+    emb = O.synthetic_embeddings(cfg)
+    bg, labels, df = O.synthetic_batch(c["batch"], c["image_size"])
+    with torch.no_grad():
+        random.seed(seed)
+        feat = O.get_style_embeds(emb, labels, cfg, random)
+        assert maxrel(feat, arr["style_embeds"]) == 0
+        out, prob = O.generator_forward(SG, bg, labels.reshape(c["batch"], 6, 1, 1), cfg, training=False, style_feat=feat)
+        src, cls = O.discriminator_forward(SD, out, cfg)
+    for got, key in ((out, "G_out_eval"), (prob, "G_prob_eval"), (src, "D_src"), (cls, "D_cls")):
+        assert maxrel(got, arr[key]) < 2e-4, key
+    stG, stD = O.AdamState(), O.AdamState()
+    random.seed(seed + 1)
+    d_gan, d_clf, gD = O.train_discriminator_once(SG, SD, stD, bg, labels, df, cfg, SE=(emb, random))
+    O.adam_update(SD, gD, stD, cfg)
+    random.seed(seed + 2)
+    gl, gG = O.train_generator_once(SG, SD, stG, bg, labels, df, cfg, SE=(emb, random))
+    got = [float(d_gan), float(d_clf)] + [float(v) for v in gl]
+    assert maxrel(np.array(got), arr["losses"][0]) < 1e-5
+    # the style MLPs are trained by the G loss; the never-executed norm_s blocks and the statistics buffers are not
+    assert gG["dec_blk.0.norm.mlp_shared.0.weight"] is not None and gG["dec_blk.0.norm.mlp_latent.0.weight"] is not None
+    assert gG["dec_res_blk.0.norm_s.mlp_gamma.weight"] is None
+    assert not any(k.rsplit(".", 1)[-1].startswith(("mean_", "std_")) for k in gG)
+
+
+def test_sean_without_embeddings_is_the_label_latent():
+    """--sean_alpha 0: `_get_style_embeds` returns None and the style code is ReLU(Linear(labels)) (normalization.py:157-158)"""
+    meta, arr, c, cfg = load()
+    SG = O.make_state(O.generator_state_shapes(cfg))
+    bg, labels, _ = O.synthetic_batch(c["batch"], c["image_size"])
+    x = torch.randn(c["batch"], 4 * c["ngf"], 8, 8, generator=torch.Generator().manual_seed(0))      # dec_blk.0 sees 4 * ngf channels
+    y = O.sean(SG, "dec_blk.0.norm", x, labels, None)
+    lat = torch.relu(labels @ SG["dec_blk.0.norm.mlp_latent.0.weight"].t() + SG["dec_blk.0.norm.mlp_latent.0.bias"])
+    g = lat @ SG["dec_blk.0.norm.mlp_gamma.weight"].t() + SG["dec_blk.0.norm.mlp_gamma.bias"]
+    b = lat @ SG["dec_blk.0.norm.mlp_beta.weight"].t() + SG["dec_blk.0.norm.mlp_beta.bias"]
+    ref = O.instancenorm(x) * (1 + g[:, :, None, None]) + b[:, :, None, None]
+    assert maxrel(y, ref) < 1e-6
+
+
+def _build(pname, tmp_path):
+    from de_i2i_gan_amd.trainers.defectgan_trainer import DefectGanTrainer
+    meta, arr, c, cfg = load()
+    path = tmp_path / "embeds.pth"
+    torch.save(O.synthetic_embeddings(cfg), path)
+    tr = DefectGanTrainer(make_opt(c, DEV, pname, style_norm_block_type="sean", sean_alpha=1.0, embed_nc=c["embed_nc"],
+                                   num_embeds=c["num_embeds"], embed_path=path))
+    for net in (tr.model.netG, tr.model.netD):
+        formula_fill(net)
+    return tr, meta, arr, c
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pname", ["f32", "bf16"])
+def test_sean_forward_and_two_steps_match_the_reference_fixture(pname, tmp_path):
+    tr, meta, arr, c = _build(pname, tmp_path)
+    seed = meta["seed"]
+    G, D = tr.model.netG, tr.model.netD
+    assert list(G.state_dict().keys()) == meta["G_keys"] and list(D.state_dict().keys()) == meta["D_keys"]
+    assert sorted(tr.optimizers) == ["D", "G"]
+    bg, labels, df = O.synthetic_batch(c["batch"], c["image_size"])
+    random.seed(seed)
+    out, prob = tr.model("inference", bg, labels)
+    with torch.no_grad():
+        src, cls = D(out)
+    for got, key in ((out, "G_out_eval"), (prob, "G_prob_eval"), (src, "D_src"), (cls, "D_cls")):
+        if pname == "f32":
+            assert maxrel(got.cpu(), arr[key]) < 1e-3, key
+        else:       # bf16 on the formula-filled 8-channel nets (see test_model_gpu.py): rms 0.3, single elements 4.2 x that
+            a, b = got.double().cpu(), torch.as_tensor(arr[key]).double()
+            if key.startswith("G_"):
+                assert ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item() < 0.3 and maxrel(a, b) < 1.26, key
+            else:   # a handful of near-zero logits computed on the bf16 G output: absolute
+                assert float((a - b).abs().max()) < 0.1, key
+    losses = []
+    for it in range(2):
+        tr.iters += 1
+        random.seed(seed + 10 * it + 1)
+        tr._train_discriminator_once(bg, labels, df)
+        random.seed(seed + 10 * it + 2)
+        tr._train_generator_once(bg, labels, df)
+        if hasattr(tr, "flush_losses"):
+            tr.flush_losses()
+        L = tr.losses
+        losses.append([L["gan"]["D"][-1], L["clf"]["D"][-1], L["gan"]["G"][-1], L["clf"]["G"][-1], L["aux"]["rec"][-1],
+                       L["aux"]["cyc"][-1], L["aux"]["con"][-1]])
+    t1, t2 = (1e-4, 8e-2) if pname == "f32" else (6e-2, 0.4)
+    assert maxrel(np.array(losses[0]), arr["losses"][0]) < t1, (losses[0], arr["losses"][0].tolist())
+    assert maxrel(np.array(losses[1]), arr["losses"][1]) < t2, (losses[1], arr["losses"][1].tolist())
+    if pname == "f32":
+        for tag, net in (("G", G), ("D", D)):
+            sd = net.state_dict()
+            mine = np.array([float(sd[k].double().norm()) for k in meta[f"{tag}_check_keys"]])
+            assert maxrel(mine, arr[f"{tag}_post_norm"]) < 5e-2, tag
+
+
+@pytest.mark.gpu
+def test_sean_alpha_zero_runs_without_an_embeddings_file_and_sets_alpha():
+    from de_i2i_gan_amd.networks.architecture import SEAN
+    from de_i2i_gan_amd.trainers.defectgan_trainer import DefectGanTrainer
+    meta, arr, c, cfg = load()
+    tr = DefectGanTrainer(make_opt(c, DEV, "bf16", style_norm_block_type="sean", sean_alpha=0, embed_nc=c["embed_nc"],
+                                   num_embeds=c["num_embeds"], embed_path=None))
+    assert all(m.alpha == 0 for m in tr.model.netG.modules() if isinstance(m, SEAN))
+    bg, labels, df = O.synthetic_batch(c["batch"], c["image_size"])
+    tr.step(bg, labels, df)
+    if hasattr(tr, "flush_losses"):
+        tr.flush_losses()
+    assert all(np.isfinite(v[-1]) for kind in tr.losses.values() for v in kind.values() if v)
