@@ -49,8 +49,6 @@ class DefectGanModel(BaseModel):
         if df_data is not None:
             df_data = df_data.to(self.opt.device, non_blocking=True)
         if mode.startswith("mae"):
-            if getattr(self.opt, "split_training", False):
-                raise NotImplementedError("split_training (training G and D of the MAE stage individually) is not implemented")
             if mode == "mae_generator":
                 self.netD.eval()
                 self.netG.train()
@@ -63,6 +61,10 @@ class DefectGanModel(BaseModel):
                 self.netD.eval()
                 self.netG.eval()
                 with torch.no_grad():
+                    if getattr(self.opt, "split_training", False):       # defectgan_model.py:69-72
+                        rec_loss, gan_loss, _ = self._compute_mae_generator_loss(data, labels)
+                        _, clf_loss = self._compute_mae_discriminator_loss(data, labels)
+                        return rec_loss, gan_loss, clf_loss
                     return self._compute_mae_generator_loss(data, labels)
             raise ValueError(f"|mode {mode}| is invalid")
         if mode == "generator":
@@ -145,6 +147,9 @@ class DefectGanModel(BaseModel):
         """(rec, gan, clf): l1(G(masked), x), bce(D(G(masked)), 1), bce(cls(G(masked)), labels)"""
         predicted, _ = self._repair_mask(imgs, labels)
         rec_loss = self._cal_loss(predicted, imgs, "l1")
+        if getattr(self.opt, "split_training", False):      # --split_training (defectgan_model.py:119-120): G sees only the L1 loss
+            zero = torch.zeros([], device=rec_loss.device)
+            return rec_loss, zero, zero
         d_params = [p for p in self.netD.parameters() if p.requires_grad]     # D's weight gradients are never read here
         for p in d_params:
             p.requires_grad_(False)
@@ -157,6 +162,10 @@ class DefectGanModel(BaseModel):
 
     def _compute_mae_discriminator_loss(self, imgs, labels):
         """(gan, clf): mean(bce(D(G(masked)), 0), bce(D(x), 1)), bce(cls(x), labels); G runs in eval mode, no grad"""
+        if getattr(self.opt, "split_training", False):      # :157-158: D only learns the classifier, on the real images
+            _, real_cls = self.netD(imgs)
+            clf_loss = self._cal_loss(real_cls, labels.view_as(real_cls), self.clf_loss_type)
+            return torch.zeros([], device=clf_loss.device), clf_loss
         with torch.no_grad():
             predicted, _ = self._repair_mask(imgs, labels)
         (real_src, real_cls), (fake_src, _) = self._netD_batched(imgs, predicted.detach())
@@ -193,6 +202,9 @@ class DefectGanModel(BaseModel):
         clf_loss = [self._cal_loss(fake_defects_cls, df_labels.view_as(fake_defects_cls), self.clf_loss_type),
                     self._cal_loss(fake_normals_cls, nm_labels.view_as(fake_normals_cls), self.clf_loss_type)]
         rec_loss = [self._cal_loss(recover_defects, df_data, "l1"), self._cal_loss(recover_normals, bg_data, "l1")]
+        if self.opt.cycle_gan:                              # defectgan_model.py:222-227: no spatial-distribution losses
+            zero = torch.zeros([], device=rec_loss[0].device)
+            return self._mean(gan_loss), self._mean(clf_loss), self._mean(rec_loss), zero, zero
         sd_cyc_loss = [self._cal_loss(df_prob, rec_df_prob, "l1"), self._cal_loss(nm_prob, rec_nm_prob, "l1")]
         sd_con_loss = [self._cal_loss(df_prob, None, "l1"), self._cal_loss(nm_prob, None, "l1"),
                        self._cal_loss(rec_df_prob, None, "l1"), self._cal_loss(rec_nm_prob, None, "l1")]

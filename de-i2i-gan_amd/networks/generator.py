@@ -21,8 +21,6 @@ class DefectGanGenerator(BaseNetwork):
         if opt.skip_conn:
             raise NotImplementedError("skip_conn: the reference's UnetBlock path does not run as written "
                                       "(architecture.py:451,504-513)")
-        if opt.cycle_gan:
-            raise NotImplementedError("cycle_gan output mode is not implemented yet")
         self.prec = ops.get_precision(getattr(opt, "compute_dtype", "bf16"))
         self.fp8 = ops.wants_fp8(getattr(opt, "compute_dtype", "bf16"))     # e4m3 forward GEMMs of the 3x3 convs
 
@@ -85,6 +83,13 @@ class DefectGanGenerator(BaseNetwork):
             ops.nan_guard_(feat)
         # both heads as one 4-output conv (3 tanh channels + 1 sigmoid channel), then the compose kernel
         fg_w, pr_w = self.foreground_head.conv.weight, self.distribution_head.conv.weight
+        if self.cycle_gan:
+            # generator.py:272-273: (foreground, spatial_prob), no composition.  Two separate head convs: the losses of this mode
+            # never read spatial_prob (defectgan_model.py:222-227), and the distribution head then gets NO gradient (None, as
+            # in the reference) rather than the zeros a fused 4-output conv would hand it
+            fg = ops.to_nchw(self.foreground_head.conv(feat), 3)
+            pr = ops.to_nchw(self.distribution_head.conv(feat), 1)
+            return torch.tanh(fg), torch.sigmoid(pr)
         w4 = torch.cat([fg_w, pr_w], 0)
         geom = ops.ConvGeom(self._head_dim, 4, 3, 1, 1, True, False)
         raw = ops.conv2d(feat, w4, None, self._packed_heads, geom, "none", sources=(fg_w, pr_w))

@@ -49,6 +49,7 @@ class Cfg:
     diff_aug: str = ""                                  # --diff_aug policy list (utils/diffaug.py; defectgan_model.py:200-203,266-270)
     style_norm: str = "spade"                           # --style_norm_block_type: spade | adain (generator.py:140-152,179-191)
     latent_dim: int = 16                                # adain: StyleExtractor input = [labels | N(0,1) noise] (extractor.py:36-96)
+    cycle_gan: bool = False                             # --cycle_gan: G returns (foreground, prob), no cyc / con losses (generator.py:272-273)
     embed_nc: int = 768                                 # sean: width of the style embeddings (defectgan_options.py:65)
     num_embeds: int = 5                                 # sean: embeddings drawn per sample (defectgan_options.py:68)
 
@@ -363,6 +364,8 @@ def generator_forward(S: Dict[str, Tensor], x: Tensor, labels: Tensor, cfg: Cfg,
         feat = torch.nan_to_num(feat)
     fg = torch.tanh(conv2d(feat, S["foreground_head.de_conv_block.0.weight"], pad=1, mode="reflect"))
     prob = torch.sigmoid(conv2d(feat, S["distribution_head.de_conv_block.0.weight"], pad=1, mode="reflect"))
+    if cfg.cycle_gan:                                                 # generator.py:272-273
+        return fg, prob
     out = x * (1 - prob) + fg * prob                                  # generator.py:270
     return out, prob
 
@@ -496,6 +499,8 @@ def generator_losses(SG, SD, bg: Tensor, df_labels: Tensor, df: Tensor, cfg: Cfg
     clf = torch.stack([bce_logits(fd_cls, df_l.view_as(fd_cls)),
                        bce_logits(fn_cls, nm_l.view_as(fn_cls))]).mean()
     rec = torch.stack([l1(recover_defects, df), l1(recover_normals, bg)]).mean()
+    if cfg.cycle_gan:                                                 # defectgan_model.py:222-227
+        return gan, clf, rec, torch.zeros([]), torch.zeros([])
     cyc = torch.stack([l1(df_prob, rec_df_prob), l1(nm_prob, rec_nm_prob)]).mean()
     zero = torch.zeros_like(df_prob)
     con = torch.stack([l1(df_prob, zero, False), l1(nm_prob, zero, False), l1(rec_df_prob, zero, False),

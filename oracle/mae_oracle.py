@@ -70,20 +70,26 @@ def repair(SG, token, imgs, labels, masks, cfg, kind, mask_ratio, training):
     return pred
 
 
-def mae_generator_losses(SG, SD, token, imgs, labels, masks, cfg, kind="position", mask_ratio=0.75):
-    """_compute_mae_generator_loss (defectgan_model.py:106-131), G in train mode, D in eval mode -> (rec, gan, clf)."""
+def mae_generator_losses(SG, SD, token, imgs, labels, masks, cfg, kind="position", mask_ratio=0.75, split_training=False):
+    """_compute_mae_generator_loss (defectgan_model.py:106-131), G in train mode, D in eval mode -> (rec, gan, clf);
+    --split_training (:119-120): G only sees the L1 loss, (rec, 0, 0)."""
     pred = repair(SG, token, imgs, labels, masks, cfg, kind, mask_ratio, training=True)
     rec = O.l1(pred, imgs)
+    if split_training:
+        return rec, torch.zeros([]), torch.zeros([])
     src, cls = O.discriminator_forward(SD, pred, cfg)
     gan = O.bce_logits(src, torch.ones_like(src))
     clf = O.bce_logits(cls, labels.view_as(cls))
     return rec, gan, clf
 
 
-def mae_discriminator_losses(SG, SD, token, imgs, labels, masks, cfg, kind="position", mask_ratio=0.75):
-    """_compute_mae_discriminator_loss (defectgan_model.py:150-171), G in eval mode under no_grad -> (gan, clf)."""
+def mae_discriminator_losses(SG, SD, token, imgs, labels, masks, cfg, kind="position", mask_ratio=0.75, split_training=False):
+    """_compute_mae_discriminator_loss (defectgan_model.py:150-171), G in eval mode under no_grad -> (gan, clf);
+    --split_training (:157-158): only the classifier loss on the real images, (0, clf) -- no mask is drawn."""
     real_src, real_cls = O.discriminator_forward(SD, imgs, cfg)
     clf = O.bce_logits(real_cls, labels.view_as(real_cls))
+    if split_training:
+        return torch.zeros([]), clf
     with torch.no_grad():
         pred = repair(SG, token, imgs, labels, masks, cfg, kind, mask_ratio, training=False)
     fake_src, _ = O.discriminator_forward(SD, pred.detach(), cfg)
@@ -116,14 +122,14 @@ def adamw_update(S: Dict[str, Tensor], grads: Dict[str, Optional[Tensor]], st: O
 
 
 def step(SG, SD, token: Dict[str, Tensor], stG, stD, imgs, labels, masks_d, masks_g, cfg, *, lr=1.5e-4,
-         loss_weight=(10, 3, 1), kind="position", mask_ratio=0.75):
+         loss_weight=(10, 3, 1), kind="position", mask_ratio=0.75, split_training=False):
     """One MAE iteration (mae_trainer.py:97-99, 124-158): D update, then G (+ mask token) update.  ``token`` is a
     one-entry dict {'mask_token': tensor} (empty for the parameter-free kinds) so it shares the Adam bookkeeping."""
     w_rec, w_clf_d, w_clf_g = loss_weight
     tok = token.get("mask_token")
     for k in O.param_keys(SD):
         SD[k].requires_grad_(True)
-    d_gan, d_clf = mae_discriminator_losses(SG, SD, tok, imgs, labels, masks_d, cfg, kind, mask_ratio)
+    d_gan, d_clf = mae_discriminator_losses(SG, SD, tok, imgs, labels, masks_d, cfg, kind, mask_ratio, split_training)
     gD = O._grads(d_gan + d_clf * w_clf_d, SD)
     adamw_update(SD, gD, stD, lr)
     for k in O.param_keys(SG):
@@ -132,7 +138,7 @@ def step(SG, SD, token: Dict[str, Tensor], stG, stD, imgs, labels, masks_d, mask
         tok.requires_grad_(True)
     for k in O.param_keys(SD):
         SD[k].requires_grad_(False)
-    rec, gan, clf = mae_generator_losses(SG, SD, tok, imgs, labels, masks_g, cfg, kind, mask_ratio)
+    rec, gan, clf = mae_generator_losses(SG, SD, tok, imgs, labels, masks_g, cfg, kind, mask_ratio, split_training)
     g_loss = gan + rec * w_rec + clf * w_clf_g
     both = dict(SG)
     if tok is not None:

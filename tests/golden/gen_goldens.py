@@ -64,6 +64,9 @@ CONFIGS = {
     # DiffAugment on everything the discriminator sees (host RNG: the seed below reproduces the draws)
     "t4_img32_b2_diffaug": dict(image_size=32, batch=2, num_layers=3, ngf=8, ndf=8, hidden_nc=16,
                                 diff_aug="color,translation,cutout", tol_step2=8e-2, tol_gradnorm=0.3, tol_post=5e-2),
+    # --cycle_gan: the generator returns (foreground, spatial_prob) uncomposed and the G loss has no cyc / con terms
+    # (generator.py:272-273, defectgan_model.py:222-227)
+    "t7_img32_b2_cycle": dict(image_size=32, batch=2, num_layers=3, ngf=8, ndf=8, hidden_nc=16, cycle_gan=True, tol_step2=1e-3),
     "t2_img64_s3_b2": dict(image_size=64, batch=2, num_layers=4, ngf=8, ndf=8, hidden_nc=16, num_scales=3,
                            tol_step2=8e-2, tol_gradnorm=0.3, tol_post=5e-2, tol_running=0.2),
 }
@@ -71,7 +74,7 @@ CONFIGS = {
 
 def make_opt(c):
     return SimpleNamespace(
-        model="defectgan", num_res=6, cycle_gan=False, label_nc=6, skip_conn=False, ngf=c["ngf"], ndf=c["ndf"],
+        model="defectgan", num_res=6, cycle_gan=c.get("cycle_gan", False), label_nc=6, skip_conn=False, ngf=c["ngf"], ndf=c["ndf"],
         input_nc=3, use_spectral=c.get("use_spectral", False), num_scales=c.get("num_scales", 2), style_norm_block_type="spade", hidden_nc=c["hidden_nc"],
         style_distill=False, embed_nc=768, add_noise=c.get("add_noise", False), num_layers=c["num_layers"],
         image_size=c["image_size"], batch_size=c["batch"], device=torch.device("cpu"), is_train=True,
@@ -139,7 +142,7 @@ def rel_dev(a, b, what, tol, floor=1e-4):
 def run_config(name, c):
     cfg = O.Cfg(image_size=c["image_size"], ngf=c["ngf"], ndf=c["ndf"], num_layers=c["num_layers"],
                 hidden_nc=c["hidden_nc"], num_scales=c.get("num_scales", 2), use_spectral=c.get("use_spectral", False),
-                add_noise=c.get("add_noise", False), diff_aug=c.get("diff_aug", ""))
+                add_noise=c.get("add_noise", False), diff_aug=c.get("diff_aug", ""), cycle_gan=c.get("cycle_gan", False))
     opt = make_opt(c)
     tr = DefectGanTrainer(opt)
     if c.get("add_noise"):

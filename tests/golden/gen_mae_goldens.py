@@ -41,6 +41,10 @@ CONFIGS = {
                                  mask_ratio=0.75, mask_token_type="position"),
     "m1_img64_b2_vector": dict(image_size=64, batch=2, num_layers=4, ngf=8, ndf=8, hidden_nc=16, patch_size=8,
                                mask_ratio=0.5, mask_token_type="vector"),
+    # --split_training: G is trained by the L1 loss alone, D by the classifier loss on the real images alone
+    # (defectgan_model.py:119-120,157-158); the D update draws no mask
+    "m2_img32_b2_split": dict(image_size=32, batch=2, num_layers=3, ngf=8, ndf=8, hidden_nc=16, patch_size=8,
+                              mask_ratio=0.75, mask_token_type="position", split_training=True),
 }
 
 
@@ -53,7 +57,7 @@ def make_opt(c):
         init_type="normal", init_variance=0.02, phase="train", ckpt_dir=Path(tempfile.mkdtemp()), log_dir=Path(tempfile.mkdtemp()),
         name="golden", iters_per_epoch=10, num_epochs=8, num_iters=100, lr=[1.5e-4], optimizer="adamw", scheduler="cos",
         lr_decay=0.05, loss_weight=[10, 3, 1], num_critics=1, diff_aug="", sean_alpha=None, use_running_stats=False,
-        save_latest_freq=10 ** 9, save_img_freq=10 ** 9, save_ckpt_freq=10 ** 9, split_training=False,
+        save_latest_freq=10 ** 9, save_img_freq=10 ** 9, save_ckpt_freq=10 ** 9, split_training=c.get("split_training", False),
         mask_token_type=c["mask_token_type"], mask_ratio=c["mask_ratio"], patch_size=c["patch_size"])
 
 
@@ -101,11 +105,12 @@ def run_config(name, c):
     torch.manual_seed(SEED)
     ora_losses = []
     for it in range(2):
-        md = M.generate_shifted_mask(tuple(imgs.shape), c["patch_size"], c["mask_ratio"])
+        split = c.get("split_training", False)
+        md = None if split else M.generate_shifted_mask(tuple(imgs.shape), c["patch_size"], c["mask_ratio"])
         mg = M.generate_shifted_mask(tuple(imgs.shape), c["patch_size"], c["mask_ratio"])
-        masks_sum.append([float(md.sum()), float(mg.sum())])
+        masks_sum.append([0.0 if split else float(md.sum()), float(mg.sum())])
         ol, _, _ = M.step(SG, SD, token, stG, stD, imgs, labels, md, mg, cfg, lr=lr_eff, kind=c["mask_token_type"],
-                          mask_ratio=c["mask_ratio"])
+                          mask_ratio=c["mask_ratio"], split_training=split)
         ora_losses.append([ol[k] for k in ("d_gan", "d_clf", "g_rec", "g_gan", "g_clf")])
     errs["losses_step1"] = close(ora_losses[0], ref_losses[0], "losses step 1", 1e-5)
     errs["losses_step2"] = close(ora_losses[1], ref_losses[1], "losses step 2", 5e-2)      # behind sign-like first AdamW steps

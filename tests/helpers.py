@@ -18,7 +18,7 @@ def load_golden(name):
     c = meta["config"]
     cfg = O.Cfg(image_size=c["image_size"], ngf=c["ngf"], ndf=c["ndf"], num_layers=c["num_layers"], hidden_nc=c["hidden_nc"],
                 num_scales=c.get("num_scales", 2), use_spectral=c.get("use_spectral", False),
-                add_noise=c.get("add_noise", False), diff_aug=c.get("diff_aug", ""))
+                add_noise=c.get("add_noise", False), diff_aug=c.get("diff_aug", ""), cycle_gan=c.get("cycle_gan", False))
     O.NOISE_SOURCE = O.shape_noise if c.get("add_noise") else None      # the goldens' deterministic stand-in for N(0,1)
     return meta, arr, c, cfg
 
@@ -26,7 +26,7 @@ def load_golden(name):
 def make_opt(c, device, compute_dtype="f32", **over):
     """The attribute set the reference's DefectGanTrainer reads, plus compute_dtype."""
     opt = SimpleNamespace(
-        model="defectgan", num_res=6, cycle_gan=False, label_nc=6, skip_conn=False, ngf=c["ngf"], ndf=c["ndf"], input_nc=3,
+        model="defectgan", num_res=6, cycle_gan=c.get("cycle_gan", False), label_nc=6, skip_conn=False, ngf=c["ngf"], ndf=c["ndf"], input_nc=3,
         use_spectral=c.get("use_spectral", False), num_scales=c.get("num_scales", 2), style_norm_block_type="spade",
         hidden_nc=c["hidden_nc"], style_distill=False, embed_nc=768, add_noise=c.get("add_noise", False), num_layers=c["num_layers"], image_size=c["image_size"],
         batch_size=c["batch"], device=torch.device(device), is_train=True, clf_loss_type="bce", continue_training=False,

@@ -11,7 +11,7 @@ from oracle import defectgan_oracle as O
 from oracle import mae_oracle as M
 
 GOLD = Path(__file__).resolve().parent / "golden"
-NAMES = ["m0_img32_b2_position", "m1_img64_b2_vector"]
+NAMES = ["m0_img32_b2_position", "m1_img64_b2_vector", "m2_img32_b2_split"]        # m2: --split_training
 
 
 def load(name):
@@ -33,11 +33,12 @@ def test_mae_two_iterations_match_reference(name):
     torch.manual_seed(meta["seed"])
     got = []
     for it in range(2):
-        md = M.generate_shifted_mask(tuple(imgs.shape), c["patch_size"], c["mask_ratio"])
+        split = c.get("split_training", False)          # (the D update of --split_training draws no mask)
+        md = None if split else M.generate_shifted_mask(tuple(imgs.shape), c["patch_size"], c["mask_ratio"])
         mg = M.generate_shifted_mask(tuple(imgs.shape), c["patch_size"], c["mask_ratio"])
-        assert [float(md.sum()), float(mg.sum())] == arr["mask_sums"][it].tolist()          # the reference's masks
+        assert [0.0 if split else float(md.sum()), float(mg.sum())] == arr["mask_sums"][it].tolist()          # the reference's masks
         ol, _, _ = M.step(SG, SD, token, stG, stD, imgs, labels, md, mg, cfg, lr=meta["lr_effective"],
-                          kind=c["mask_token_type"], mask_ratio=c["mask_ratio"])
+                          kind=c["mask_token_type"], mask_ratio=c["mask_ratio"], split_training=split)
         got.append([ol[k] for k in ("d_gan", "d_clf", "g_rec", "g_gan", "g_clf")])
     ref = arr["losses"]
     assert np.abs(np.array(got[0]) - ref[0]).max() < 1e-5

@@ -154,7 +154,8 @@ def test_step_gradients_match_oracle_fp64(name, c, gtol):
 
 
 @pytest.mark.parametrize("pname", ["f32", "bf16"])
-@pytest.mark.parametrize("name", ["t0_img32_b2", "t1_img64_b4", "t2_img64_s3_b2", "t3_img32_b2_sn_noise", "t4_img32_b2_diffaug"])
+@pytest.mark.parametrize("name", ["t0_img32_b2", "t1_img64_b4", "t2_img64_s3_b2", "t3_img32_b2_sn_noise", "t4_img32_b2_diffaug",
+                                  "t7_img32_b2_cycle"])
 def test_two_train_steps_match_reference_goldens(name, pname):
     meta, arr, c, cfg = load_golden(name)
     tr = build(c, pname)

@@ -10,8 +10,8 @@ import torch
 from oracle import defectgan_oracle as O
 
 GOLD = Path(__file__).resolve().parent / "golden"
-NAMES = ["t0_img32_b2", "t1_img64_b4", "t2_img64_s3_b2", "t3_img32_b2_sn_noise", "t4_img32_b2_diffaug"]
-# t2: num_scales=3; t3: spectral norm + noise; t4: DiffAugment
+NAMES = ["t0_img32_b2", "t1_img64_b4", "t2_img64_s3_b2", "t3_img32_b2_sn_noise", "t4_img32_b2_diffaug", "t7_img32_b2_cycle"]
+# t2: num_scales=3; t3: spectral norm + noise; t4: DiffAugment; t7: --cycle_gan
 
 
 def load(name):
@@ -20,7 +20,7 @@ def load(name):
     c = meta["config"]
     cfg = O.Cfg(image_size=c["image_size"], ngf=c["ngf"], ndf=c["ndf"], num_layers=c["num_layers"],
                 hidden_nc=c["hidden_nc"], num_scales=c.get("num_scales", 2), use_spectral=c.get("use_spectral", False),
-                add_noise=c.get("add_noise", False), diff_aug=c.get("diff_aug", ""))
+                add_noise=c.get("add_noise", False), diff_aug=c.get("diff_aug", ""), cycle_gan=c.get("cycle_gan", False))
     O.NOISE_SOURCE = O.shape_noise if c.get("add_noise") else None      # the goldens' deterministic stand-in for N(0,1)
     return meta, arr, c, cfg
 
