@@ -147,3 +147,34 @@ def test_sean_alpha_zero_runs_without_an_embeddings_file_and_sets_alpha():
     if hasattr(tr, "flush_losses"):
         tr.flush_losses()
     assert all(np.isfinite(v[-1]) for kind in tr.losses.values() for v in kind.values() if v)
+
+
+@pytest.mark.gpu
+def test_readme_sean_recipes_run(tmp_path):
+    """The reference README's SEAN recipes: `train_defectgan.py ... --add_noise --use_spectral --style_norm_block_type sean
+    --embed_path F` and `train_mae.py ... --style_norm_block_type sean --embed_path F` (sean_alpha left at its default None:
+    embeddings are used and alpha follows the per-epoch cosine schedule, generator.py:277-289)."""
+    from de_i2i_gan_amd.networks.architecture import SEAN
+    from de_i2i_gan_amd.trainers.defectgan_trainer import DefectGanTrainer
+    from de_i2i_gan_amd.trainers.mae_trainer import MAETrainer
+    meta, arr, c, cfg = load()
+    path = tmp_path / "embeds.pth"
+    torch.save(O.synthetic_embeddings(cfg), path)
+    common = dict(style_norm_block_type="sean", sean_alpha=None, embed_nc=c["embed_nc"], num_embeds=c["num_embeds"], embed_path=path,
+                  use_spectral=True, add_noise=True, num_epochs=4)
+    bg, labels, df = O.synthetic_batch(c["batch"], c["image_size"])
+    tr = DefectGanTrainer(make_opt(c, DEV, "bf16", **common))
+    random.seed(1)
+    tr.step(bg, labels, df)
+    tr.model.netG.update_per_epoch(1)
+    assert all(abs(m.alpha - (1 + np.cos(np.pi * 1 / 4)) / 2) < 1e-12 for m in tr.model.netG.modules() if isinstance(m, SEAN))
+    if hasattr(tr, "flush_losses"):
+        tr.flush_losses()
+    assert all(np.isfinite(v[-1]) for kind in tr.losses.values() for v in kind.values() if v)
+    mt = MAETrainer(make_opt(c, DEV, "bf16", optimizer="adamw", scheduler="cos", lr=[1.5e-4], lr_decay=0.05, loss_weight=[10, 3, 1],
+                             split_training=False, mask_token_type="position", mask_ratio=0.75, patch_size=8, **common))
+    torch.manual_seed(0)
+    mt.step(bg, labels)
+    if hasattr(mt, "flush_losses"):
+        mt.flush_losses()
+    assert all(np.isfinite(v[-1]) for kind in mt.losses.values() for v in kind.values() if v)
