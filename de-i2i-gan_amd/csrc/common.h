@@ -172,4 +172,20 @@ DEI2I_D float wave_sum(float v) {
 }
 #endif  // __HIPCC__
 
+#if defined(__HIPCC__)
+// LDS-DMA (global -> LDS, 16 bytes per lane, 1 KB per wave instruction) as inline asm: M0 is written in the same statement and
+// restored after it (hipcc reserves M0).  Issued through __builtin_amdgcn_global_load_lds, hipcc knows that LDS is being written
+// and -- unable to tell that a prefetch into the NEXT buffer does not alias the buffer being read -- puts s_waitcnt vmcnt(0) in
+// front of the next LDS read (and into every __syncthreads()): the multi-stage rings of wgrad_halo / wgrad_v2 / the thin convs
+// then drain their prefetch before computing.  With the asm form the kernels' own counted vmcnt waits and barriers are what
+// order the DMA against the reads -- each of them has to be complete: hipcc adds nothing.
+DEI2I_D void glds16_asm(const void* gptr, unsigned char* lds_wave_base) {
+  typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_byte_t*)lds_wave_base);   // wave-uniform by contract
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gptr), "s"(dst) : "memory");
+}
+#endif
+
 }  // namespace dei2i

@@ -27,7 +27,7 @@ typedef __attribute__((address_space(3))) void lds_void_tc;
 typedef __attribute__((address_space(1))) const void gbl_void_tc;
 
 DEI2I_D void glds16tc(const void* gptr, unsigned char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((gbl_void_tc*)gptr, (lds_void_tc*)lds_wave_base, 16, 0, 0);
+  glds16_asm(gptr, lds_wave_base);      // (common.h: hipcc must not see the LDS write, or it drains the ring)
 }
 
 constexpr int TC_TH = 8, TC_TW = 32, TC_N = 64;

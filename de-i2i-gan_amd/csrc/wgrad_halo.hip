@@ -30,9 +30,7 @@ __device__ __attribute__((aligned(256))) unsigned char g_zero_page_hw[256];
 typedef __attribute__((address_space(3))) void lds_void_hw;
 typedef __attribute__((address_space(1))) const void gbl_void_hw;
 
-DEI2I_D void glds16hw(const void* gptr, unsigned char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((gbl_void_hw*)gptr, (lds_void_hw*)lds_wave_base, 16, 0, 0);
-}
+DEI2I_D void glds16hw(const void* gptr, unsigned char* lds_wave_base) { glds16_asm(gptr, lds_wave_base); }      // (common.h)
 
 constexpr int HW_TH = 4, HW_TW = 32;                  // half-tile: 128 pixels
 constexpr int HW_HH = HW_TH + 2, HW_HWD = HW_TW + 2;  // 6 x 34 halo

@@ -31,7 +31,7 @@ typedef __attribute__((address_space(3))) void lds_void_wt;
 typedef __attribute__((address_space(1))) const void gbl_void_wt;
 
 DEI2I_D void glds16wt(const void* gptr, unsigned char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((gbl_void_wt*)gptr, (lds_void_wt*)lds_wave_base, 16, 0, 0);
+  glds16_asm(gptr, lds_wave_base);      // (common.h: hipcc must not see the LDS write, or it drains the ring)
 }
 
 constexpr int WT_TH = 4, WT_TW = 32;                 // half-tile: 128 pixels

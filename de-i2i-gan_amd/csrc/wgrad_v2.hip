@@ -25,7 +25,7 @@ typedef __attribute__((address_space(3))) void lds_void_t2;
 typedef __attribute__((address_space(1))) const void gbl_void_t2;
 
 DEI2I_D void glds16w(const void* gptr, unsigned char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((gbl_void_t2*)gptr, (lds_void_t2*)lds_wave_base, 16, 0, 0);
+  glds16_asm(gptr, lds_wave_base);      // (common.h: hipcc must not see the LDS write, or it drains the ring)
 }
 
 DEI2I_D int xcd_remap3(int bid, int nwg) {
