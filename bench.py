@@ -47,6 +47,8 @@ def parse():
                     help="A/B: separate statistics passes instead of conv-epilogue statistics (ops.fuse_norm = False)")
     ap.add_argument("--no-fuse-ring", action="store_true",
                     help="A/B: SPADE -> upsample -> conv writes the upsampled normalised tensor (ops.fuse_ring = False)")
+    ap.add_argument("--no-wgrad-stream", action="store_true",
+                    help="A/B: leaf-weight gradients on the main stream instead of the side stream (ops.wgrad_side_stream = False)")
     ap.add_argument("--fuse-pro", action="store_true",
                     help="A/B: BatchNorm / SPADE apply on the consumer conv's operand path (ops.fuse_pro = True; measured slower)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child process of the default run
@@ -221,6 +223,7 @@ def main():
     _ops.fuse_norm = not args.no_fuse_norm
     _ops.fuse_pro = bool(args.fuse_pro)
     _ops.fuse_ring = not args.no_fuse_ring
+    _ops.wgrad_side_stream = not args.no_wgrad_stream
     for kv in args.set_option:
         name, val = kv.split("=")
         _lib.check(_lib.load().dei2i_set_option(name.encode(), int(val)), "set_option " + kv)
@@ -320,7 +323,8 @@ def main():
                    "spade_path": "collapsed (5x5 border-class gamma/beta for 1x1 label maps)",
                    "use_spectral": bool(args.use_spectral), "add_noise": bool(args.add_noise),
                    "conv_epilogue_statistics": not args.no_fuse_norm, "operand_path_norm": bool(args.fuse_pro),
-                   "spade_upsample_at_source_resolution": not args.no_fuse_ring},
+                   "spade_upsample_at_source_resolution": not args.no_fuse_ring,
+                   "weight_gradients_on_side_stream": not args.no_wgrad_stream},
         "losses_last_step": {k: round(v[-1], 5) for kind in tr.losses.values() for k, v in kind.items() if v},
     }
     if fam:

@@ -416,25 +416,73 @@ def _conv_dgrad(lib, prec, geom, x_shape, couts, g, weight, cache, sources, per_
     return dx
 
 
-def _wgrad_scratch(lib, d, device):
+def _wgrad_scratch(lib, d, device, slot="wgrad"):
     packed = lib.dei2i_wgrad_slab_elems(byref(d))
     # partial slabs: up to 64, or as many as fit 96 MB (a (co, ci, 9-tap) register block per CU is 256 x 295 KB)
-    return _workspace(device, max(packed * 4, min(max(packed * 4 * 64, 96 << 20), 512 << 20)), slot="wgrad")
+    return _workspace(device, max(packed * 4, min(max(packed * 4 * 64, 96 << 20), 512 << 20)), slot=slot)
 
 
-def _conv_wgrad(lib, prec, geom, x, g, weight, pro=None):
+# ---- weight gradients on a side stream ---------------------------------------------------------------------------
+# Nothing inside a backward pass reads the gradient of a LEAF weight: it goes into the tensor autograd's AccumulateGrad will
+# hand to ``param.grad`` (see _grad_target), and the optimizer reads it after the pass.  So those wgrad launches (and their slab
+# reduces) need not sit between the dgrad of their layer and the normalisation backward of the previous one on the one
+# stream: they run on a second stream, behind an event on the main stream (their operands), with their own split-K scratch;
+# the main stream waits for the side stream once, in a callback the engine runs at the end of the pass -- before anyone can
+# look at ``param.grad``.  One-workgroup-per-CU MFMA kernels (the wgrads) then overlap the HBM-bound normalisation /
+# activation backward kernels and the tails / prologues of the dgrads instead of queueing behind them.  Gradients of
+# non-leaf weights (spectral norm's effective weight, concatenated heads / gamma|beta weights) ARE read inside the pass by
+# the next autograd node and stay on the main stream.  The data-parallel reducer makes its all-reduce stream wait for the
+# side stream as well (parallel.GradReducer._launch).
+wgrad_side_stream = True
+_wgrad_streams = {}
+_wgrad_join_pending = set()
+
+
+def wgrad_stream(device):
+    """The side stream the leaf-weight gradients of the current / last backward pass were computed on (None: none yet)."""
+    return _wgrad_streams.get(torch.device(device))
+
+
+def _wgrad_join(device):
+    def join():
+        _wgrad_join_pending.discard(device)
+        torch.cuda.current_stream(device).wait_stream(_wgrad_streams[device])
+    return join
+
+
+def _conv_wgrad(lib, prec, geom, x, g, weight, pro=None, keep=()):
     """OIHW fp32 weight gradient (in-place accumulated across the nodes of one pass: _grad_target); ``pro``: the conv's
-    input was normalised on the operand path, x is the un-normalised tensor."""
+    input was normalised on the operand path, x is the un-normalised tensor; ``keep``: the tensors ``pro`` points into."""
     n, h, w, cins = x.shape
     d = _desc(prec, geom, n, h, w, cins, g.shape[-1])
-    scratch = _wgrad_scratch(lib, d, x.device)
-    dw, dw_ptr, accumulate = _grad_target(weight, weight.shape, x.device)
-    if pro is None:
-        L.check(lib.dei2i_conv2d_wgrad_oihw(byref(d), _p(x), _p(g), _p(scratch), scratch.numel(), c_void_p(dw_ptr), accumulate,
-                                            _stream()), "conv2d_wgrad")
-    else:
-        L.check(lib.dei2i_conv2d_wgrad_oihw_pro(byref(d), _p(x), _p(g), _p(scratch), scratch.numel(), c_void_p(dw_ptr), accumulate,
-                                                byref(pro), _stream()), "conv2d_wgrad_pro")
+    dev = x.device
+    side = None
+    if wgrad_side_stream and weight.is_leaf and torch._C._current_graph_task_id() >= 0:
+        side = _wgrad_streams.get(dev)
+        if side is None:
+            side = _wgrad_streams[dev] = torch.cuda.Stream(device=dev)
+    scratch = _wgrad_scratch(lib, d, dev, "wgrad_side" if side is not None else "wgrad")
+    dw, dw_ptr, accumulate = _grad_target(weight, weight.shape, dev)
+
+    def launch():
+        if pro is None:
+            L.check(lib.dei2i_conv2d_wgrad_oihw(byref(d), _p(x), _p(g), _p(scratch), scratch.numel(), c_void_p(dw_ptr), accumulate,
+                                                _stream()), "conv2d_wgrad")
+        else:
+            L.check(lib.dei2i_conv2d_wgrad_oihw_pro(byref(d), _p(x), _p(g), _p(scratch), scratch.numel(), c_void_p(dw_ptr), accumulate,
+                                                    byref(pro), _stream()), "conv2d_wgrad_pro")
+    if side is None:
+        launch()
+        return dw
+    side.wait_stream(torch.cuda.current_stream(dev))          # x, g (and an earlier node's contribution to dw) are ready
+    with torch.cuda.stream(side):
+        launch()
+    for t in (x, g, dw) + tuple(keep):                        # the allocator must not hand their memory out before the side stream is done
+        if t is not None:
+            t.record_stream(side)
+    if dev not in _wgrad_join_pending:
+        _wgrad_join_pending.add(dev)
+        torch.autograd.Variable._execution_engine.queue_callback(_wgrad_join(dev))
     return dw
 
 
@@ -507,10 +555,10 @@ class _Conv2d(torch.autograd.Function):
         else:
             g = dy
         dx = dw = db = None
+        if _wants_grad(ctx, 1):                              # (first: on its side stream it then runs beside the dgrad)
+            dw = _conv_wgrad(lib, prec, geom, x, g, weight)
         if _wants_grad(ctx, 0):
             dx = _conv_dgrad(lib, prec, geom, tuple(x.shape), couts, g, weight, ctx.cache, ctx.sources, ctx.per_call, x.dtype, x.device)
-        if _wants_grad(ctx, 1):
-            dw = _conv_wgrad(lib, prec, geom, x, g, weight)
         if ctx.has_bias and _wants_grad(ctx, 2):
             dbf = torch.empty(couts, dtype=torch.float32, device=x.device)
             rows = g.numel() // couts
@@ -770,7 +818,7 @@ class _BnActConv(torch.autograd.Function):
         dw = None
         if _wants_grad(ctx, 3):
             pro = L.ProDesc(a.data_ptr(), b.data_ptr(), 0, ctx.slope, None)
-            dw = _conv_wgrad(lib, prec, geom, y1, dy, weight, pro)
+            dw = _conv_wgrad(lib, prec, geom, y1, dy, weight, pro, keep=(a, b))
         dy1 = dbw = dbb = None
         if _wants_grad(ctx, 0) or _wants_grad(ctx, 1) or _wants_grad(ctx, 2):
             dh = _conv_dgrad(lib, prec, geom, tuple(y1.shape), dy.shape[-1], dy, weight, ctx.cache, ctx.sources, False, y1.dtype, y1.device)
@@ -996,10 +1044,10 @@ class _SpadeConv(torch.autograd.Function):
         dw = None
         if _wants_grad(ctx, 2):
             if ctx.ring_mode:                            # the conv's input was z_src (+ ring): no transform in the wgrad
-                dw = _conv_wgrad(lib, prec, geom, z_src, dy, weight, L.ProDesc(None, None, 0, 0.0, ring.data_ptr()))
+                dw = _conv_wgrad(lib, prec, geom, z_src, dy, weight, L.ProDesc(None, None, 0, 0.0, ring.data_ptr()), keep=(ring,))
             else:
                 pro = L.ProDesc(coefs[2].data_ptr(), coefs[3].data_ptr(), c, 0.0, ring.data_ptr())
-                dw = _conv_wgrad(lib, prec, geom, x, dy, weight, pro)
+                dw = _conv_wgrad(lib, prec, geom, x, dy, weight, pro, keep=(coefs, ring))
         dx = dgb = None
         if _wants_grad(ctx, 0) or _wants_grad(ctx, 1):
             # dL/dz at the LOGICAL (upsampled) resolution: the conv seen as a plain conv on z (the SPADE backward sums the

@@ -95,6 +95,10 @@ class GradReducer:
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(dev))      # the gradient's producer kernels
             side.wait_event(ready)
+            from . import ops
+            wg = ops.wgrad_stream(dev)                        # ... and the weight gradients computed on ops' side stream
+            if wg is not None:
+                side.wait_stream(wg)
             ctx = torch.cuda.stream(side)
         else:
             ctx = _NullCtx()
