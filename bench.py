@@ -253,13 +253,17 @@ def main():
     sync()
     if red is not None:
         red.overlap_report()                          # drop the warm-up steps' events
-    # Inside the timed region only the DOMINANT kernel family (the halo-resident 3x3 conv) is bracketed with HIP events, and
-    # only every 5th of its launches (126 per step: 5 is coprime, so over the timed steps every launch of the step's sequence
-    # is sampled equally often) -- two event records per launch break the back-to-back dispatch of the stream: bracketing all
-    # ~600 conv launches of a step cost 2.4 ms of a 44.2 ms step, all 126 halo launches 0.9 ms (measured round 2, same box).
+    # Inside the timed region only the DOMINANT kernel (the halo-resident 3x3 conv's forward launches: 65 per step, the
+    # step's largest single kernel) is bracketed with HIP events, and only every 4th of its launches (4 is coprime to 65, so over
+    # the timed steps every launch of the step's sequence is sampled equally often) -- two event records per launch break the
+    # back-to-back dispatch of the stream: bracketing all ~600 conv launches of a step cost 2.4 ms of a 44.2 ms step, all 126
+    # halo launches 0.9 ms (measured round 2, same box).  The same kernel's FOLD launches (the reflect dgrads, 56 per step) are
+    # a family of their own: they run during the backward passes, BESIDE the weight-gradient kernels of ops' side stream, so
+    # an event bracket around one of them spans two kernels sharing the GPU and says nothing about either.
     # The other conv families only count launches and FLOPs there (no events) and are timed in a few EXTRA steps afterwards.
-    HALO_SAMPLE = 5
-    fams = (("gather_gemm", _lib.PROF_GATHER_GEMM), ("wgrad", _lib.PROF_WGRAD), ("halo", _lib.PROF_HALO_CONV))
+    HALO_SAMPLE = 4
+    fams = (("gather_gemm", _lib.PROF_GATHER_GEMM), ("wgrad", _lib.PROF_WGRAD), ("halo", _lib.PROF_HALO_CONV),
+            ("halo_fold", _lib.PROF_HALO_FOLD))
 
     def collect():
         """-> {family: (launches, FLOPs of all launches, event-bracketed launches, their ms, their FLOPs)}"""
@@ -328,11 +332,15 @@ def main():
         "losses_last_step": {k: round(v[-1], 5) for kind in tr.losses.values() for k, v in kind.items() if v},
     }
     if fam:
-        hn, hfl, htn, hms, htfl = fam["halo"]            # the dominant kernel family: the halo-resident stride-1 3x3 conv (fwd + dgrad)
+        hn, hfl, htn, hms, htfl = fam["halo"]            # the dominant kernel: the halo-resident stride-1 3x3 conv, forward launches
+        fn_, ffl = fam["halo_fold"][:2]                  # its FOLD launches (reflect dgrads; timed region: counts only)
         on, ofl = fam["gather_gemm"][:2]                 # the other conv forward / dgrad kernels (timed region: counts only)
+        on, ofl = on + fn_, ofl + ffl
         wn, wfl = fam["wgrad"][:2]
         xhn, _, _, xhms, xhfl = fam_extra["halo"]        # all families with events on every launch, extra steps after the timed region
+        xfn, _, _, xfms, xffl = fam_extra["halo_fold"]
         xon, _, _, xoms, xofl = fam_extra["gather_gemm"]
+        xon, xoms, xofl = xon + xfn, xoms + xfms, xofl + xffl
         xwn, _, _, xwms, xwfl = fam_extra["wgrad"]
         peak = PEAK_TFLOPS[args.dtype]
         ach = htfl / (hms * 1e-3) / 1e12 if hms > 0 else 0.0
@@ -343,7 +351,7 @@ def main():
                 if traffic is None and os.path.exists(pmc):
                     with open(pmc) as f:
                         t = json.load(f)
-                    hk = "halo16_conv" if "halo16_conv" in t else "halo_conv"
+                    hk = next((k for k in ("halo16_conv_fwd", "halo16_conv", "halo_conv") if k in t), None)
                     if hk in t:
                         traffic = t[hk]["hbm_bytes_per_launch"]
                         traffic_src = ("profiles/%s_pmc_traffic.json (profiles/collect.sh + summarize.py): (2*FETCH_SIZE + WRITE_SIZE)"
@@ -352,17 +360,23 @@ def main():
                 if mfma_pmc is None and os.path.exists(pmc2):
                     with open(pmc2) as f:
                         t2 = json.load(f)
-                    mfma_pmc = t2.get("halo16_conv", t2.get("halo_conv", {})).get("mfma_busy_frac")
+                    mfma_pmc = t2.get("halo16_conv_fwd", t2.get("halo16_conv", t2.get("halo_conv", {}))).get("mfma_busy_frac")
         xn, xms, xfl = xhn + xon, xhms + xoms, xhfl + xofl
-        line["roofline"] = {"bound": "mfma", "kernel": "halo16_conv_kernel (halo-resident stride-1 3x3 conv, 16x32-pixel tiles: forward + "
-                            "zero-boundary dgrad; the step's dominant kernel, ~30 % of its device time)",
+        line["roofline"] = {"bound": "mfma", "kernel": "halo16_conv_kernel<128, 8, 0, false, 0, true> (halo-resident stride-1 3x3 conv, 16x32-pixel "
+                            "tiles, software-pipelined loop: the forward launches; the step's largest single kernel, ~15 % of its device "
+                            "time -- its FOLD instance, the reflect dgrads, is the second largest and runs beside the side-stream wgrads)",
                             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                             "traffic_source": traffic_src,
                             "mfma_busy_frac_pmc": mfma_pmc,      # same kernel, counters of a separate profiled run (profiles/)
                             "launches_per_step": hn / args.steps, "avg_launch_ms": hms / max(htn, 1),
                             "flops_per_launch": htfl / max(htn, 1), "event_bracketed_launches": htn,
-                            "timing": "HIP events around every %dth halo16_conv_kernel / halo_conv_kernel launch inside the timed region, "
+                            "timing": "HIP events around every %dth forward launch of halo16_conv_kernel inside the timed region, "
                                       "on the launch stream (%d of %d launches)" % (HALO_SAMPLE, htn, hn),
+                            "fold_launches": {"launches_per_step": xfn / max(extra_steps, 1),
+                                              "avg_launch_ms": xfms / max(xfn, 1),
+                                              "achieved": xffl / (xfms * 1e-3) / 1e12 if xfms > 0 else 0.0,
+                                              "note": "reflect dgrads, event-bracketed in %d extra steps; they share the GPU with the "
+                                                      "wgrad kernels of the side stream, so this is not a kernel-alone figure" % extra_steps},
                             "all_conv_fwd_dgrad_kernels": {"achieved": xfl / (xms * 1e-3) / 1e12 if xms > 0 else 0.0,
                                                            "launches_per_step": xn / max(extra_steps, 1),
                                                            "avg_launch_ms": xms / max(xn, 1),
@@ -372,8 +386,11 @@ def main():
                         "step_mfma_util": conv_flops_step / (ms_per_step * 1e-3) / (peak * 1e12),
                         "conv_launches_per_step": (hn + on + wn) / args.steps,
                         "wgrad_tflops": xwfl / (xwms * 1e-3) / 1e12 if xwms > 0 else 0.0,
-                        "conv_kernel_time_frac_of_step": (xms + xwms) / max(extra_steps, 1) / ms_per_step,
-                        "timing": "FLOPs counted in the timed region; wgrad / all-conv times from %d extra steps after it" % extra_steps}
+                        "conv_kernel_time_over_step_time": (xms + xwms) / max(extra_steps, 1) / ms_per_step,
+                        "timing": "FLOPs counted in the timed region; wgrad / all-conv times from %d extra steps after it.  With the "
+                                  "weight gradients on the side stream (config.weight_gradients_on_side_stream) wgrad kernels and backward "
+                                  "conv kernels run concurrently: their event brackets overlap, so wgrad_tflops and the time ratio are "
+                                  "not kernel-alone figures (the ratio can exceed 1); --no-wgrad-stream gives the serial ones" % extra_steps}
     if ddp is not None:
         # rank 0's view: time the gradient all-reduces occupied the side stream per backward pass, and the part that ran
         # after backward's last kernel (the optimizer waits for it) -- stream events, measured inside the timed region

@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdei2i_hip.so")
 BF16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 PAD_ZERO, PAD_REFLECT = 0, 1
-PROF_GATHER_GEMM, PROF_WGRAD, PROF_HALO_CONV = 0, 1, 2
+PROF_GATHER_GEMM, PROF_WGRAD, PROF_HALO_CONV, PROF_HALO_FOLD = 0, 1, 2, 3
 
 
 class ConvDesc(Structure):

@@ -1207,11 +1207,14 @@ static hipError_t launch_halo16(const GatherDesc& g, const void* src, const void
     attr_done[which] = true;
   }
   count_launch(K_HALO16_CONV);
-  prof_begin(PROF_HALO_CONV, 2.0 * (double)g.M * (double)(g.th * g.tw) * (double)g.Clog * (double)wrows, st);
+  // (profiling families: the pipelined forward instance is a kernel of its own -- bench.py's roofline line --, the FOLD launches
+  //  are another, the 64-channel tile counts with the other conv kernels)
+  const ProfFamily fam = fold ? PROF_HALO_FOLD : (pipe ? PROF_HALO_CONV : PROF_GATHER_GEMM);
+  prof_begin(fam, 2.0 * (double)g.M * (double)(g.th * g.tw) * (double)g.Clog * (double)wrows, st);
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, st, g, (const bf16_t*)src, (const bf16_t*)wgt, wrows, bias,
                      (bf16_t*)out, ldc, act, tiles_n, stats, g_v2_dbg, (const bf16_t*)ring,
                      ring != nullptr ? ring_pixels(g.Hl, g.Wl) : 0);
-  prof_end(PROF_HALO_CONV, st);
+  prof_end(fam, st);
   return hipGetLastError();
 }
 

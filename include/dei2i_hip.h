@@ -232,7 +232,9 @@ int dei2i_spectral_bwd(int Cout, int K, const float* G, const float* w_eff, cons
 /* ---- in-library kernel timing (bench.py roofline leg): HIP events around every launch of one kernel family ---- */
 #define DEI2I_PROF_GATHER_GEMM 0  /* the other conv forward / dgrad kernels: gather GEMM v1 / v2, thin convs */
 #define DEI2I_PROF_WGRAD 1
-#define DEI2I_PROF_HALO_CONV 2   /* halo_conv_kernel alone (its launches are not part of family 0) */
+#define DEI2I_PROF_HALO_CONV 2   /* the halo-resident 3x3 conv kernels, forward / zero-boundary launches (not part of family 0) */
+#define DEI2I_PROF_HALO_FOLD 3   /* their FOLD launches (input gradients of the reflect-padded convs: run during backward passes,
+                                    i.e. beside the weight-gradient kernels of ops' side stream) */
 /* on = 1: HIP events around every launch of the family + FLOP count; on = 2: launch and FLOP count only (no events: the
  * stream sees nothing extra, total_ms reads 0); on = k >= 3: events around every k-th launch only (a sample -- two event
  * records per launch break the stream's back-to-back dispatch); on = 0: off */
