@@ -258,3 +258,33 @@ def test_generator_and_both_loss_graphs_fused_equal_unfused_at_256_batch_4(ops):
         assert abs(a - b) <= 5e-4 * max(abs(b), 1e-3), m
     assert m["D_cos"] > 0.9995 and m["G_cos"] > 0.999 and m["G_worst_param_cos"] > 0.95, m
     assert m["running_stats_maxrel"] < 2e-3, m
+
+
+@pytest.mark.gpu
+def test_weight_gradients_on_the_side_stream_are_bit_identical_and_joined():
+    """ops.wgrad_side_stream: leaf-weight gradients are computed on a second stream and joined by an engine callback at the end
+    of the backward pass -- reading ``param.grad`` on the current stream right after ``backward()`` must see the finished
+    gradients, and they must be the bits of the single-stream run."""
+    import numpy as np
+    from de_i2i_gan_amd import ops
+    from de_i2i_gan_amd.trainers.defectgan_trainer import DefectGanTrainer
+    from helpers import make_opt
+    from oracle import defectgan_oracle as O
+    c = dict(image_size=128, batch=4, num_layers=4, ngf=32, ndf=32, hidden_nc=64)
+    bg, labels, df = O.synthetic_batch(c["batch"], c["image_size"])
+    grads = {}
+    for side in (True, False):
+        ops.wgrad_side_stream = side
+        try:
+            torch.manual_seed(11)
+            tr = DefectGanTrainer(make_opt(c, "cuda:0", "bf16"))
+            ls = tr.model("generator", bg, labels, df)
+            (ls[0] + 5 * ls[1] + 5 * ls[2] + 5 * ls[3] + ls[4]).backward()
+            # no torch.cuda.synchronize() here: the read below is ordered behind the side stream by the join alone
+            grads[side] = [p.grad.clone() for p in tr.model.netG.parameters() if p.grad is not None]
+            assert (ops.wgrad_stream("cuda:0") is not None) or not side
+        finally:
+            ops.wgrad_side_stream = True
+    assert len(grads[True]) == len(grads[False]) > 50
+    for a, b in zip(grads[True], grads[False]):
+        assert torch.equal(a, b)
