@@ -17,7 +17,7 @@ import sys
 from collections import defaultdict
 from pathlib import Path
 
-FAMILIES = (("thin_cin_conv", "thin_cin_conv_kernel"), ("thin_cout_conv", "thin_cout_conv_kernel"), ("halo16_conv", "halo16_conv_kernel"), ("halo16w4_conv", "halo16w4_conv_kernel"), ("halo_conv", "halo_conv_kernel"), ("gather_gemm_v2", "gather_gemm_v2_kernel"), ("gather_gemm_v1", "gather_gemm_kernel"),
+FAMILIES = (("thin_cin_conv", "thin_cin_conv_kernel"), ("thin_cout_conv", "thin_cout_conv_kernel"), ("halo16_conv", "halo16_conv_kernel"), ("halo_conv", "halo_conv_kernel"), ("gather_gemm_v2", "gather_gemm_v2_kernel"), ("gather_gemm_v1", "gather_gemm_kernel"),
             ("wgrad_halo", "wgrad_halo_kernel"), ("wgrad_thin", "wgrad_thin_kernel"), ("wgrad_v2", "wgrad_v2_kernel"), ("wgrad_reduce_unpack", "wgrad_reduce_unpack_kernel"),
             ("wgrad_v1", "wgrad_kernel"))
 

@@ -5,7 +5,7 @@ from oracle import defectgan_oracle as O
 lib = _lib.load()
 DEV = "cuda:0"
 def rel(a, b): return ((a.double().cpu() - b.double().cpu()).norm() / b.double().cpu().norm()).item()
-for mode in ([int(v) for v in sys.argv[1:]] or [2, 1]):
+for mode in ([int(v) for v in sys.argv[1:]] or [3, 1]):
     lib.dei2i_set_option(b"halo16", mode)
     for (cin, cout, H, W, N, refl, up, act) in [(64, 128, 64, 64, 32, True, False, "none"), (32, 64, 64, 64, 32, True, False, "leaky_relu"),
                                                 (96, 136, 64, 64, 16, False, False, "relu"), (64, 64, 32, 32, 32, True, True, "none"),

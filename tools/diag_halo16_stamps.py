@@ -54,10 +54,10 @@ raw = dbg.view(-1, 10).cpu()
 pro = (raw[:, 3] >> 32).double()
 raw[:, 3] &= 0xffffffff
 d = raw.double()
-if mode != 2:
+if True:
     live = d[:, 2] > 0
     print("prologue %.0f cycles | epilogue %.0f cycles (medians over waves)" % (pro[live].median().item(), (d[live, 3] - d[live, 0] - pro[live]).median().item()))
-nw = 4 if mode == 2 else 8
+nw = 8
 d = d.view(-1, 8, 10)[:, :nw]
 d = d[d[:, 0, 2] > 0]
 nk = d[0, 0, 2].item()
@@ -65,10 +65,6 @@ print("workgroups", d.shape[0], "k-steps", nk)
 print("loop cycles per wave: median %.0f -> %.0f per k-step; clock %.3f GHz; whole kernel %.0f cycles (prologue + epilogue %.0f)" % (
     d[..., 0].median().item(), d[..., 0].median().item() / nk, (d[..., 0] / d[..., 1]).median().item() * 0.1,
     d[..., 3].median().item(), d[..., 3].median().item() - d[..., 0].median().item()))
-if mode == 2:
-    sel = d[:, :, 4:].reshape(-1, 6)
-    print("4-wave kernel, cycles per k-step: half 0 %.0f | address prep %.0f | half 1 %.0f | halo issue %.0f | waits %.0f | barrier %.0f" % tuple((sel.median(0).values / nk).tolist()))
-    sys.exit(0)
 for grp, name in ((0, "group 0 (waves 0-3)"), (1, "group 1 (waves 4-7)")):
     sel = d[:, grp * 4:grp * 4 + 4, 4:].reshape(-1, 6)
     print(name, "cycles per k-step: M reads issued %.0f | M vmcnt wait %.0f | M lgkmcnt wait %.0f | M barrier %.0f | C mfma+dma %.0f | C barrier %.0f"
