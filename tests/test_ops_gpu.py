@@ -89,6 +89,11 @@ CONV_CASES += [
     (32, 64, 3, 1, 1, True, False, 64, 64, 32, False, "leaky_relu"),   # ONE slice (no halo re-issue), BN = 64, fused LReLU
     (96, 136, 3, 1, 1, False, False, 64, 64, 16, True, "relu"),        # three slices, zero padding, bias, ragged N tile
     (64, 64, 3, 1, 1, True, True, 32, 32, 32, False, "none"),          # fused nearest upsample
+    # the pipelined loop's ring / wait protocol on short and odd k-loops, and tiles that do NOT touch the image border:
+    (32, 128, 3, 1, 1, True, False, 64, 64, 32, False, "none"),        # ONE slice: 9 k-steps, the weight ring never wraps fully
+    (128, 128, 3, 1, 1, True, False, 48, 96, 32, False, "none"),       # 3 x 3 tiles per image (one interior tile); the dgrad is a
+                                                                       # FOLD launch of the 128-channel tile with rings on some tiles only
+    (160, 128, 3, 1, 1, False, False, 32, 64, 32, True, "leaky_relu"), # five slices (odd), the smallest FOLD-eligible image, zero pad
 ]
 FORCE_WGRAD_HALO = {(128, 64, 3, 1, 1, True, False, 16, 32, 8, False, "none"), (256, 48, 3, 1, 1, False, False, 8, 32, 4, False, "none"),
                     (64, 4, 3, 1, 1, True, False, 16, 32, 4, False, "none")}
