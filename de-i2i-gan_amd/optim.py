@@ -50,7 +50,6 @@ class FusedAdam(torch.optim.Optimizer):
         dev = plist[0].device
         lib = ops._lib_for(plist[0])
         n = len(plist)
-        table = torch.empty((n, 5), dtype=torch.int64, pin_memory=True)
         rows = []
         max_n = 0
         for p in plist:
@@ -61,8 +60,18 @@ class FusedAdam(torch.optim.Optimizer):
             rows.append((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()))
             max_n = max(max_n, p.numel())
             p._dei2i_keep = g          # keep a possibly-copied grad alive until the launch is enqueued
-        table.copy_(torch.tensor(rows, dtype=torch.int64))
-        table_dev = table.to(dev, non_blocking=True)
+        # the device pointer table is rebuilt and uploaded only when a pointer moved (in steady state the caching allocator hands
+        # every gradient the address it had the step before)
+        cache = self.__dict__.setdefault("_table_cache", {})
+        key = (dev, n, rows[0][0])
+        hit = cache.get(key)
+        if hit is not None and hit[0] == rows:
+            table_dev = hit[1]
+        else:
+            table = torch.empty((n, 5), dtype=torch.int64, pin_memory=True)
+            table.copy_(torch.tensor(rows, dtype=torch.int64))
+            table_dev = table.to(dev, non_blocking=True)
+            cache[key] = (rows, table_dev)
         L.check(lib.dei2i_adam_step(ctypes.c_void_p(table_dev.data_ptr()), n, max_n, lr, b1, b2, eps, 1.0 - b1 ** t,
                                     math.sqrt(1.0 - b2 ** t), self.grad_scale, weight_decay, ops._stream()), "adam_step")
         for p in plist:
