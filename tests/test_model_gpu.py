@@ -14,6 +14,9 @@ Tolerances
   (diagnosed with tools/diag_gstep.py: with identical D inputs the HIP gradient equals the fp64 oracle to 3e-6)."""
 import functools
 
+import json
+from pathlib import Path
+
 import numpy as np
 import pytest
 import torch
@@ -235,6 +238,52 @@ def test_bf16_tracks_f32_with_reference_init():
     for i in (1, 2):
         cos = float(torch.dot(a[i], b[i]) / (a[i].norm() * b[i].norm()))
         assert cos > 0.995, (i, cos)
+
+
+def test_bf16_default_widths_against_the_oracle_with_reference_init():
+    """The benchmarked mode at the reference's DEFAULT widths (ngf = ndf = 64, hidden_nc = 128) and the reference's own init
+    (N(0, 0.02)), checked against the ORACLE -- the fp32 CPU restatement the goldens pin to the reference -- not against the
+    build's own f32 mode: one D loss/backward and one G loss/backward at 64 x 64, batch 4 (what the oracle finishes in
+    seconds).  Bounds: the 7 losses 5e-4 relative (measured 4e-5), cosine of the full D and G gradients >= 0.995 (measured
+    0.9986 / 0.9990), their norms within 1 % (measured 4e-4 / 1e-3); the measured values go to gpurun_out/."""
+    from de_i2i_gan_amd.trainers.defectgan_trainer import DefectGanTrainer
+    c = dict(image_size=64, batch=4, num_layers=4, ngf=64, ndf=64, hidden_nc=128)
+    cfg = O.Cfg(image_size=64, ngf=64, ndf=64, num_layers=4, hidden_nc=128)
+    bg, labels, df = O.synthetic_batch(c["batch"], c["image_size"])
+    torch.manual_seed(321)
+    tr = DefectGanTrainer(make_opt(c, DEV, "bf16"))
+    G, D = tr.model.netG, tr.model.netD
+    SG = {k: v.detach().cpu().clone() for k, v in G.state_dict().items()}
+    SD = {k: v.detach().cpu().clone() for k, v in D.state_dict().items()}
+    assert list(SG) == list(O.generator_state_shapes(cfg)) and list(SD) == list(O.discriminator_state_shapes(cfg))
+    g1, c1 = tr.model("discriminator", bg, labels, df)
+    (g1 + 2 * c1).backward()
+    d_mine = {k: p.grad.double().cpu() for k, p in D.named_parameters()}
+    ls = tr.model("generator", bg, labels, df)
+    (ls[0] + 5 * ls[1] + 5 * ls[2] + 5 * ls[3] + ls[4]).backward()
+    g_mine = {k: p.grad.double().cpu() for k, p in G.named_parameters() if p.grad is not None}
+    torch.set_num_threads(16)
+    # the oracle's D step leaves G untouched (eval mode); its G loss then runs on the same states as the product's did
+    o_gan, o_clf, gD = O.train_discriminator_once(SG, SD, O.AdamState(), bg, labels, df, cfg)
+    for k in O.param_keys(SD):
+        SD[k].requires_grad_(False)
+    o_ls, gG = O.train_generator_once(SG, SD, O.AdamState(), bg, labels, df, cfg)
+    mine = np.array([float(g1), float(c1)] + [float(v) for v in ls])
+    ref = np.array([float(o_gan), float(o_clf)] + [float(v) for v in o_ls])
+    assert maxrel(mine, ref) < 5e-4, (mine.tolist(), ref.tolist())
+    report = {"loss_maxrel": maxrel(mine, ref)}
+    for tag, got, want in (("D", d_mine, gD), ("G", g_mine, gG)):
+        keys = [k for k in got if want.get(k) is not None]
+        assert len(keys) == len(got)
+        a = torch.cat([got[k].flatten() for k in keys])
+        b = torch.cat([want[k].double().flatten() for k in keys])
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
+        assert cos > 0.995, (tag, cos)
+        assert abs(float(a.norm() / b.norm()) - 1) < 1e-2, (tag, float(a.norm()), float(b.norm()))
+        report[tag + "_grad_cos"], report[tag + "_grad_norm_ratio"] = cos, float(a.norm() / b.norm())
+    out = Path(__file__).resolve().parents[1] / "gpurun_out"
+    out.mkdir(exist_ok=True)
+    (out / "bf16_vs_oracle_default_widths.json").write_text(json.dumps(report, indent=1))
 
 
 def test_step_wrapper_and_deferred_losses():
