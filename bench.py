@@ -49,6 +49,8 @@ def parse():
                     help="A/B: SPADE -> upsample -> conv writes the upsampled normalised tensor (ops.fuse_ring = False)")
     ap.add_argument("--no-wgrad-stream", action="store_true",
                     help="A/B: leaf-weight gradients on the main stream instead of the side stream (ops.wgrad_side_stream = False)")
+    ap.add_argument("--no-fuse-bwd", action="store_true",
+                    help="A/B: SPADE / BatchNorm backward reductions by a streaming pass instead of the dgrad epilogue (ops.fuse_bwd = False)")
     ap.add_argument("--fuse-pro", action="store_true",
                     help="A/B: BatchNorm / SPADE apply on the consumer conv's operand path (ops.fuse_pro = True; measured slower)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child process of the default run
@@ -224,6 +226,7 @@ def main():
     _ops.fuse_pro = bool(args.fuse_pro)
     _ops.fuse_ring = not args.no_fuse_ring
     _ops.wgrad_side_stream = not args.no_wgrad_stream
+    _ops.fuse_bwd = not args.no_fuse_bwd
     for kv in args.set_option:
         name, val = kv.split("=")
         _lib.check(_lib.load().dei2i_set_option(name.encode(), int(val)), "set_option " + kv)
@@ -328,7 +331,8 @@ def main():
                    "use_spectral": bool(args.use_spectral), "add_noise": bool(args.add_noise),
                    "conv_epilogue_statistics": not args.no_fuse_norm, "operand_path_norm": bool(args.fuse_pro),
                    "spade_upsample_at_source_resolution": not args.no_fuse_ring,
-                   "weight_gradients_on_side_stream": not args.no_wgrad_stream},
+                   "weight_gradients_on_side_stream": not args.no_wgrad_stream,
+                   "norm_backward_reductions_in_dgrad_epilogue": not args.no_fuse_bwd},
         "losses_last_step": {k: round(v[-1], 5) for kind in tr.losses.values() for k, v in kind.items() if v},
     }
     if fam:

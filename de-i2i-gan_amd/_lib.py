@@ -24,6 +24,12 @@ class ProDesc(Structure):
     _fields_ = [("A", c_void_p), ("B", c_void_p), ("n_stride", c_int), ("slope", c_float), ("ring", c_void_p)]
 
 
+class EpiNormDesc(Structure):
+    """struct dei2i_epi_norm: the backward reductions of the norm layer in front of a conv, from that conv's dgrad epilogue"""
+    _fields_ = [("kind", c_int), ("up", c_int), ("act", c_int), ("reserved", c_int), ("x", c_void_p), ("mean", c_void_p),
+                ("rstd", c_void_p), ("gb", c_void_p), ("a", c_void_p), ("b", c_void_p), ("partial", c_void_p)]
+
+
 class AdamRec(Structure):
     """struct dei2i_adam_rec"""
     _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_int64)]
@@ -32,6 +38,7 @@ class AdamRec(Structure):
 _P = c_void_p
 _CD = POINTER(ConvDesc)
 _PD = POINTER(ProDesc)
+_ED = POINTER(EpiNormDesc)
 
 # name -> (restype, argtypes); every symbol include/dei2i_hip.h declares
 SIGNATURES = {
@@ -102,6 +109,10 @@ SIGNATURES = {
     "dei2i_conv2d_wgrad_oihw_pro": (c_int, [_CD, _P, _P, _P, c_size_t, _P, c_int, _PD, _P]),
     "dei2i_ring_pixels": (c_size_t, [c_int, c_int]),
     "dei2i_conv2d_ring_supported": (c_int, [_CD]),
+    "dei2i_conv2d_dgrad_norm_supported": (c_int, [_CD]),
+    "dei2i_conv2d_dgrad_norm_chunks": (c_int, [_CD]),
+    "dei2i_conv2d_dgrad_input_norm": (c_int, [_CD, _P, _P, _P, _ED, _P]),
+    "dei2i_spade_bwd_border": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "dei2i_conv2d_fwd_ring": (c_int, [_CD, _P, _P, _P, _P, c_int, _P, _P, _P]),
     "dei2i_affine_act_img_fwd": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, c_float, _P, _P]),
     "dei2i_spade_prep": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_float, _P, _P, _P, _P, _P, _P, _P]),

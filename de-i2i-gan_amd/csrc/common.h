@@ -165,6 +165,10 @@ template <int VEC> DEI2I_D void ldcoef(const float* __restrict__ p, float (&v)[V
   }
 }
 
+// class of a pixel coordinate in the 5 x 5 gamma / beta table of a SPADE block whose label map is constant per image: the two
+// border rows / columns on each side have their own values (zero-padded 3x3 convs over a constant map), the interior is class 2
+DEI2I_D int border_class(int i, int extent) { return i < 2 ? i : (i >= extent - 2 ? 4 - (extent - 1 - i) : 2); }
+
 DEI2I_D float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -9,6 +9,7 @@ namespace dei2i {
 int g_use_wgrad_v2 = 1;
 int g_use_wgrad_halo = 1;
 int g_use_wgrad_thin = 1;
+extern int g_halo_bn, g_halo_stages, g_halo16, g_halo16_stages, g_halo16_fold;
 
 static ConvShape to_shape(const dei2i_conv* c) {
   ConvShape s;
@@ -466,6 +467,38 @@ int dei2i_conv2d_dgrad_input(const dei2i_conv* c, const void* dy, const void* wd
   const int rc = dei2i_conv2d_dgrad(c, dy, wd_packed, ext_scratch, ws, ws_bytes, s);
   if (rc != 0) return rc;
   return dei2i_fold_pad(c->dtype, c->N, c->H, c->W, c->CinS, c->pad, c->pad_mode, c->up, ext_scratch, nullptr, dx, s);
+}
+
+/* ---- input gradient + the backward reductions of the norm layer in front of the conv, one launch (conv_halo16.hip EPIN) ---- */
+static bool dgrad_norm_shape_ok(const dei2i_conv* c) {
+  if (!g_halo16 || !g_halo16_fold || g_halo16_stages != 8 || g_halo_bn != 0 || g_halo_stages != 0) return false;   // A/B options
+  if (!valid_conv(c) || c->dtype != DT_BF16 || c->up) return false;
+  if (c->kh != 3 || c->kw != 3 || c->stride != 1 || c->pad != 1 || c->pad_mode != PAD_REFLECT) return false;
+  if (c->H % 16 != 0 || c->W % 32 != 0 || c->H < 32 || c->W < 64 || c->CinS < 64 || c->CinS % 8 != 0 || c->CoutS % 32 != 0) return false;
+  if ((long long)c->N * c->H * c->W * c->CoutS >= (1ll << 31)) return false;
+  const int tiles_m = c->N * (c->H / 16) * (c->W / 32);
+  const int tn = c->CinS >= 128 ? (c->CinS + 127) / 128 : 1;
+  return tiles_m * tn >= (num_cu() * 7) / 8;
+}
+
+int dei2i_conv2d_dgrad_norm_supported(const dei2i_conv* c) { return dgrad_norm_shape_ok(c) ? 1 : 0; }
+
+int dei2i_conv2d_dgrad_norm_chunks(const dei2i_conv* c) { return (c->H / 8) * (c->W / 32); }
+
+int dei2i_conv2d_dgrad_input_norm(const dei2i_conv* c, const void* dy, const void* wd_packed, void* dx, const dei2i_epi_norm* en,
+                                  dei2i_stream s) {
+  if (!dy || !wd_packed || !dx || !en || !dgrad_norm_shape_ok(c)) return DEI2I_ERR_BAD_ARG;
+  if (!en->x || !en->mean || !en->rstd || !en->partial || en->up < 0 || en->up > 1) return DEI2I_ERR_BAD_ARG;
+  if (en->kind == 1 ? !en->gb : (en->kind != 2 || !en->a || !en->b || en->up)) return DEI2I_ERR_BAD_ARG;
+  ConvShape sh = to_shape(c);
+  sh.pad_mode = PAD_ZERO;
+  const GatherDesc interior = make_dgrad_desc(sh, c->CoutS, 0, 0);
+  EpiNorm e;
+  e.x = (const uint16_t*)en->x; e.mean = en->mean; e.rstd = en->rstd; e.gb = (const uint16_t*)en->gb; e.a = en->a; e.b = en->b;
+  e.partial = en->partial; e.kind = en->kind; e.up = en->up; e.act = en->act;
+  hipError_t ef = halo16_conv(interior, dy, wd_packed, c->Cin, nullptr, dx, c->CinS, ACT_NONE, num_cu(), (hipStream_t)s, nullptr, nullptr,
+                              true, &e);
+  return ef == hipErrorNotSupported ? DEI2I_ERR_BAD_ARG : (int)ef;
 }
 
 int dei2i_conv2d_wgrad(const dei2i_conv* c, const void* x, const void* dy, float* dw_packed, dei2i_stream s) {

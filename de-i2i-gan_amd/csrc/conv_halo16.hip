@@ -83,13 +83,16 @@ DEI2I_D int sw16(int row) { return ((row >> 2) & 1) << 1; }
 // 4 = no MFMAs (options v2_ablate = 7 / 8 / 9)
 // ABL (options v2_ablate = 10 + ABL, no stamps): the same as a bit mask -- 1 no LDS-DMA in the loop, 2 no fragment reads, 4 no MFMAs
 // PIPE: the software-pipelined main loop (see there) instead of the two-phase one
-template <int BN, int STAGES, int DIAG = 0, bool FOLD = false, int ABL = 0, bool PIPE = false>
+// EPIN: the epilogue also takes the backward reductions of the normalisation layer in front of this conv (geom.h: EpiNorm) from
+// the finished dz tile -- FOLD launches only (every conv of the generator is reflect-padded)
+template <int BN, int STAGES, int DIAG = 0, bool FOLD = false, int ABL = 0, bool PIPE = false, bool EPIN = false>
 __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, const bf16_t* __restrict__ src,
                                                           const bf16_t* __restrict__ wgt, const int wrows,
                                                           const float* __restrict__ bias, bf16_t* __restrict__ out,
                                                           const int ldc, const int act, const int tiles_n,
                                                           float* __restrict__ stats, unsigned long long* __restrict__ dbg,
-                                                          const bf16_t* __restrict__ zring, const int ring_pix) {
+                                                          const bf16_t* __restrict__ zring, const int ring_pix,
+                                                          const EpiNorm en) {
   // zring (optional): the input tensor is the SOURCE-resolution z of a SPADE -> upsample -> conv block whose 2-pixel frame
   // (at the logical, upsampled resolution) has per-pixel gamma / beta classes: those halo pixels come from the compact
   // ring tensor [N][ring_pix][Cs] (geom.h) instead of from src[y >> up][x >> up]
@@ -639,8 +642,13 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
 
   // ---- epilogue, in two halves of 8 tile rows: stage the half as bf16 [pixel][BN (+8 pad)] (8-byte writes: a lane
   //      holds 4 consecutive channels of its pixel), write back with 16-byte stores ----
+  // (EPIN: BOTH halves are staged up front -- the loop's buffers are dead, 512 rows fit -- so that no accumulator is live while
+  //  the write-back passes carry the 32 sums of the norm's backward; the reduction scratch then reuses the first half's rows)
   constexpr int CROW = BN * 2 + 16;
+  constexpr int HALF_BYTES = 256 * CROW;
   unsigned char* ctile = smem;
+  float* const red = reinterpret_cast<float*>(EPIN ? smem : smem + HALF_BYTES);
+  float* const cred = reinterpret_cast<float*>(smem + (EPIN ? 2 : 1) * HALF_BYTES);
   const float slope = act_slope(act);
   constexpr int CPR = BN / 8;             // 16-byte chunks per tile row
   constexpr int RPP = 512 / CPR;          // rows per pass
@@ -649,27 +657,49 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
   // statistics: one record per 8 x 32 half tile, i.e. the record grid of the 8 x 32 tile kernel (conv_halo.hip) and of
   // dei2i_conv2d_stats_chunks: record (2 * tile_row + half, tile_col) of the image
   const int rec0 = img * (2 * tiles_y * tiles_x) + (2 * (trem / tiles_x)) * tiles_x + (trem % tiles_x);
+  // EPIN: the per-channel coefficients of this thread's 8 channels -- kind 1: mean | rstd of the image; kind 2: a | b | mean | rstd
+  float nc[EPIN ? 4 : 1][8];
+  if constexpr (EPIN) {
+    if (ncol < ldc) {
+      if (en.kind == 1) {
+        ldcoef<8>(en.mean + (size_t)img * ldc + ncol, nc[0]);
+        ldcoef<8>(en.rstd + (size_t)img * ldc + ncol, nc[1]);
+      } else {
+        ldcoef<8>(en.a + ncol, nc[0]); ldcoef<8>(en.b + ncol, nc[1]);
+        ldcoef<8>(en.mean + ncol, nc[2]); ldcoef<8>(en.rstd + ncol, nc[3]);
+      }
+    }
+  }
+  auto stage_acc = [&](unsigned char* const stage) {
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+      const int col0 = wn * WTN + j * 16 + 4 * kg;
+      float bq[4];
+      uint32_t m01, m23;
+      epi_col_consts(bias, n0 + col0, wrows, bq, m01, m23);
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        const int row = ((wm & 1) * 4 + (i >> 1)) * 32 + (i & 1) * 16 + l16;
+        *reinterpret_cast<u32x2*>(stage + row * CROW + col0 * 2) =
+            epi_finish4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3], bq, slope, m01, m23);
+      }
+    }
+  };
+  if constexpr (EPIN) {
+    __syncthreads();
+    stage_acc(smem + (wm >> 1) * HALF_BYTES);
+  }
 #pragma unroll 1
   for (int half = 0; half < 2; ++half) {
     float st8[16];                        // sum (0..7) / sum of squares (8..15) of this thread's 8 channels
 #pragma unroll
     for (int k = 0; k < 16; ++k) st8[k] = 0.f;
+    float ep[EPIN ? 32 : 1];              // EPIN: this thread's 8 channels x the (up to) 4 sums of the norm's backward
+#pragma unroll
+    for (int k = 0; k < (EPIN ? 32 : 1); ++k) ep[k] = 0.f;
     __syncthreads();
-    if ((wm >> 1) == half) {
-#pragma unroll
-      for (int j = 0; j < CB; ++j) {
-        const int col0 = wn * WTN + j * 16 + 4 * kg;
-        float bq[4];
-        uint32_t m01, m23;
-        epi_col_consts(bias, n0 + col0, wrows, bq, m01, m23);
-#pragma unroll
-        for (int i = 0; i < PB; ++i) {
-          const int row = ((wm & 1) * 4 + (i >> 1)) * 32 + (i & 1) * 16 + l16;
-          *reinterpret_cast<u32x2*>(ctile + row * CROW + col0 * 2) =
-              epi_finish4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3], bq, slope, m01, m23);
-        }
-      }
-    }
+    if constexpr (EPIN) ctile = smem + half * HALF_BYTES;
+    if (!EPIN && (wm >> 1) == half) stage_acc(ctile);
     __syncthreads();
     if constexpr (FOLD) {
       // the ring's reflection: row ring -> tile row 1 (top) / 14 (bottom), then -- after a barrier: pixel (1,1) takes both --
@@ -716,7 +746,6 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
               for (int e = 0; e < 8; ++e) sum = fmaf(w8[e], d8[e], sum);
             }
           }
-          float* cred = reinterpret_cast<float*>(smem + 256 * CROW);
           if (part < 4) cred[part * BN + c] = sum;
           __syncthreads();
           if (tid < BN) {
@@ -729,22 +758,76 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
       }
     }
     if (ncol < ldc) {
-#pragma unroll
+#pragma unroll(EPIN ? 2 : 256 / RPP)
       for (int p = 0; p < 256 / RPP; ++p) {
         const int row = p * RPP + rsub;
         const size_t opix = (size_t)out_pixel(g, img, y0 + half * 8 + (row >> 5), x0 + (row & 31));
         const u32x4 v = *reinterpret_cast<const u32x4*>(ctile + row * CROW + chunk * 16);
         *reinterpret_cast<u32x4*>(out + opix * ldc + ncol) = v;
-        if (stats != nullptr) {
+        if (!EPIN && stats != nullptr) {
           float fv[8];
           Elem<bf16_t>::unpack(v, fv);
 #pragma unroll
           for (int e = 0; e < 8; ++e) { st8[e] += fv[e]; st8[8 + e] = fmaf(fv[e], fv[e], st8[8 + e]); }
         }
+        if constexpr (EPIN) {
+          // v = dL/dz of 8 channels of pixel (py, px), as the streaming pass would read it back (bf16): the same per-element
+          // arithmetic as spade_bwd_partial_kernel / bn_bwd_partial_kernel (reduce.hip)
+          const int py = y0 + half * 8 + (row >> 5), px = x0 + (row & 31);
+          const size_t xpix = ((size_t)(img * (g.Ho >> en.up) + (py >> en.up))) * (g.Wo >> en.up) + (px >> en.up);
+          float d8[8], x8[8];
+          Elem<bf16_t>::unpack(v, d8);
+          Elem<bf16_t>::unpack(*reinterpret_cast<const u32x4*>(en.x + xpix * ldc + ncol), x8);
+          if (en.kind == 1) {
+            const int cy = border_class(py, g.Ho), cx = border_class(px, g.Wo);
+            const bf16_t* gp = en.gb + ((size_t)(img * 5 + cy) * 5 + cx) * 2 * ldc + ncol;
+            float gm[8], bt[8];
+            Elem<bf16_t>::unpack(*reinterpret_cast<const u32x4*>(gp), gm);
+            Elem<bf16_t>::unpack(*reinterpret_cast<const u32x4*>(gp + ldc), bt);
+            const bool interior = cy == 2 && cx == 2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float xh = (x8[e] - nc[0][e]) * nc[1][e];
+              const float gg = fmaf(xh, 1.f + gm[e], bt[e]) > 0.f ? d8[e] : 0.f;
+              const float dxh = gg * (1.f + gm[e]);
+              ep[e] += dxh;
+              ep[8 + e] = fmaf(dxh, xh, ep[8 + e]);
+              if (interior) { ep[16 + e] += gg * xh; ep[24 + e] += gg; }
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float gg = d8[e] * act_grad_from_out(fmaf(nc[0][e], x8[e], nc[1][e]), en.act);
+              ep[e] += gg;
+              ep[8 + e] = fmaf(gg, (x8[e] - nc[2][e]) * nc[3][e], ep[8 + e]);
+            }
+          }
+        }
       }
     }
-    if (stats != nullptr) {                              // kernel-uniform: per-thread partials -> LDS -> ordered sums
-      float* red = reinterpret_cast<float*>(smem + 256 * CROW);
+    if constexpr (EPIN) {                                // per-thread partials -> LDS -> ordered sums, 16 values per round
+      float* mine = red + ((size_t)rsub * CPR + chunk) * 16;
+      const int nq = en.kind == 1 ? 4 : 2;
+      for (int round = 0; round < nq / 2; ++round) {
+        __syncthreads();                                 // (round 0: the write-back's reads of the rows `red` reuses)
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) {
+          f32x4 t;
+          t.x = round ? ep[16 + k] : ep[k]; t.y = round ? ep[17 + k] : ep[k + 1];
+          t.z = round ? ep[18 + k] : ep[k + 2]; t.w = round ? ep[19 + k] : ep[k + 3];
+          *reinterpret_cast<f32x4*>(mine + k) = t;
+        }
+        __syncthreads();
+        for (int o = tid; o < CPR * 16; o += 512) {
+          const int ch = o >> 4, k = o & 15;
+          float sum = 0.f;
+          for (int r = 0; r < RPP; ++r) sum += red[((size_t)r * CPR + ch) * 16 + k];
+          const int c = n0 + ch * 8 + (k & 7);
+          if (c < ldc) en.partial[((size_t)(rec0 + half * tiles_x) * nq + 2 * round + (k >> 3)) * ldc + c] = sum;
+        }
+      }
+    }
+    if (!EPIN && stats != nullptr) {                     // kernel-uniform: per-thread partials -> LDS -> ordered sums
       float* mine = red + ((size_t)rsub * CPR + chunk) * 16;
 #pragma unroll
       for (int k = 0; k < 16; k += 4) {
@@ -781,7 +864,8 @@ int g_halo16_stages = 8;
 
 template <int BN, int STAGES>
 static hipError_t launch_halo16(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out,
-                                int ldc, int act, hipStream_t st, float* stats, const void* ring = nullptr, bool fold = false) {
+                                int ldc, int act, hipStream_t st, float* stats, const void* ring = nullptr, bool fold = false,
+                                const EpiNorm* en = nullptr) {
   const int tiles_m = g.N * (g.Ho / H16_TH) * (g.Wo / H16_TW);
   const int tiles_n = (ldc + BN - 1) / BN;
   constexpr size_t loop_lds = 2 * (size_t)H16_HBYTES + (size_t)STAGES * BN * 64 + H16_GROUPS * 16 * sizeof(int);
@@ -843,9 +927,10 @@ static hipError_t launch_halo16(const GatherDesc& g, const void* src, const void
     }
   }
   if (fold && !pipe) kern = halo16_conv_kernel<BN, STAGES, 0, STAGES == 8>;   // (instantiated for the shipped ring depth only)
-  if (fold && STAGES != 8) return hipErrorNotSupported;
+  if (fold && !pipe && en != nullptr) kern = halo16_conv_kernel<BN, STAGES, 0, STAGES == 8, 0, false, STAGES == 8>;
+  if ((fold && STAGES != 8) || (en != nullptr && !fold)) return hipErrorNotSupported;
   static bool attr_done[16] = {};
-  const int which = fold ? 2 : (abl ? 7 + (g_v2_ablate - 10) : (diag && S8 ? g_v2_ablate - 3 : 0));
+  const int which = fold ? (en != nullptr ? 15 : 2) : (abl ? 7 + (g_v2_ablate - 10) : (diag && S8 ? g_v2_ablate - 3 : 0));
   if (!pipe && !attr_done[which]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -858,7 +943,7 @@ static hipError_t launch_halo16(const GatherDesc& g, const void* src, const void
   prof_begin(fam, 2.0 * (double)g.M * (double)(g.th * g.tw) * (double)g.Clog * (double)wrows, st);
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, st, g, (const bf16_t*)src, (const bf16_t*)wgt, wrows, bias,
                      (bf16_t*)out, ldc, act, tiles_n, stats, g_v2_dbg, (const bf16_t*)ring,
-                     ring != nullptr ? ring_pixels(g.Hl, g.Wl) : 0);
+                     ring != nullptr ? ring_pixels(g.Hl, g.Wl) : 0, en != nullptr ? *en : EpiNorm{});
   prof_end(fam, st);
   return hipGetLastError();
 }
@@ -868,7 +953,8 @@ static hipError_t launch_halo16(const GatherDesc& g, const void* src, const void
 // fold: the launch is the interior input gradient of a reflect-padded 3x3 conv and also folds the frame's ring and corners
 // into the border rows / columns -- see the kernel
 hipError_t halo16_conv(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out, int ldc,
-                       int act, int num_cu, hipStream_t st, float* stats, const void* ring, bool fold) {
+                       int act, int num_cu, hipStream_t st, float* stats, const void* ring, bool fold, const EpiNorm* en) {
+  if (en != nullptr && (!fold || (en->kind != 1 && en->kind != 2))) return hipErrorNotSupported;
   if (fold && (!g_halo16_fold || g.ys >= 0 || g.xs >= 0 || g.pad_mode != PAD_ZERO || g.up || g.Ho < 2 * H16_TH || g.Wo < 2 * H16_TW ||
                bias != nullptr || act != ACT_NONE || stats != nullptr || ring != nullptr))
     return hipErrorNotSupported;
@@ -887,10 +973,10 @@ hipError_t halo16_conv(const GatherDesc& g, const void* src, const void* wgt, in
   if (ldc >= 128) {
     if (g_halo16_stages == 4) return launch_halo16<128, 4>(g, src, wgt, wrows, bias, out, ldc, act, st, stats);
     if (g_halo16_stages == 6) return launch_halo16<128, 6>(g, src, wgt, wrows, bias, out, ldc, act, st, stats);
-    return launch_halo16<128, 8>(g, src, wgt, wrows, bias, out, ldc, act, st, stats, ring, fold);
+    return launch_halo16<128, 8>(g, src, wgt, wrows, bias, out, ldc, act, st, stats, ring, fold, en);
   }
   if (g_halo16_stages == 4) return launch_halo16<64, 4>(g, src, wgt, wrows, bias, out, ldc, act, st, stats);
-  return launch_halo16<64, 8>(g, src, wgt, wrows, bias, out, ldc, act, st, stats, ring, fold);
+  return launch_halo16<64, 8>(g, src, wgt, wrows, bias, out, ldc, act, st, stats, ring, fold, en);
 }
 
 }  // namespace dei2i

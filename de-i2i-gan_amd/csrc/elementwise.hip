@@ -110,7 +110,6 @@ __global__ void affine_act_img_kernel(const T* __restrict__ x, const float* __re
   }
 }
 
-DEI2I_D int border_class(int i, int extent) { return i < 2 ? i : (i >= extent - 2 ? 4 - (extent - 1 - i) : 2); }
 
 // ---- SPADE modulate + ReLU ----
 template <typename T>

@@ -225,6 +225,27 @@ struct ConvPro {
   int ring_pix;
 };
 
+// Backward reductions of the normalisation layer that PRODUCED a conv's input, taken in the epilogue of that conv's input-
+// gradient launch (conv_halo16.hip, FOLD build) while the dz tile is still on chip -- instead of a streaming pass that reads
+// dz and x again (reduce.hip: spade_bwd_partial_kernel / bn_bwd_partial_kernel, whose record layouts these are).
+//   kind 1: z = relu(IN(x)*(1+gamma)+beta), gamma / beta from the (N,5,5,2C) class table (normalization.py:24-37):
+//           partial[((n*chunks + chunk)*4 + q)*C + c], q = sum dxhat | sum dxhat*xhat | interior sum dgamma | interior sum dbeta
+//   kind 2: z = act(a*y + b) (BatchNorm + activation, architecture.py:116-118): partial[(chunk*2 + q)*C + c], q = sum g | sum g*xhat
+// chunk = the 8 x 32 half tile (record grid of dei2i_conv2d_stats_chunks); x / y has the conv input's channel stride; `up`: it
+// lives at half the resolution (SPADE behind a nearest x2 upsample).
+struct EpiNorm {
+  const uint16_t* x;
+  const float* mean;
+  const float* rstd;
+  const uint16_t* gb;
+  const float* a;
+  const float* b;
+  float* partial;
+  int kind;
+  int up;
+  int act;
+};
+
 // ---------------------------------------------------------------------------------------------
 // Index maps shared by the device kernels and the CPU geometry check
 // ---------------------------------------------------------------------------------------------

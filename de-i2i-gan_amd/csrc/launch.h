@@ -47,7 +47,8 @@ hipError_t halo_conv(const GatherDesc& g, const void* src, const void* wgt, int 
 
 // 16 x 32 pixel tiles, 32-channel slices (conv_halo16.hip): the large-grid 3x3 stride-1 layers
 hipError_t halo16_conv(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out, int ldc,
-                       int act, int num_cu, hipStream_t st, float* stats = nullptr, const void* ring = nullptr, bool fold = false);
+                       int act, int num_cu, hipStream_t st, float* stats = nullptr, const void* ring = nullptr, bool fold = false,
+                       const EpiNorm* en = nullptr);
 hipError_t gather_gemm(int dtype, const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias,
                        void* out, float* ws, size_t ws_bytes, int ldc, int act, hipStream_t st);
 hipError_t gather_gemm_multi(int dtype, const GatherDesc* descs, const long long* woffs, int n, const void* src,

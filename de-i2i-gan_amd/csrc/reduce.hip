@@ -285,7 +285,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
-DEI2I_D int border_class(int i, int extent) { return i < 2 ? i : (i >= extent - 2 ? 4 - (extent - 1 - i) : 2); }
 
 // ---- SPADE backward ----
 // z = relu(v), v = xhat*(1+gamma) + beta, xhat = (x - mean)*rstd.  With g = dz*[v > 0]:
@@ -962,6 +961,20 @@ int dei2i_spade_bwd_partial(int dtype, int N, int H, int W, int C, int up, const
       hipLaunchKernelGGL(spade_bwd_border_kernel<float>, dim3(25, N), dim3(256), combine_lds(dtype, 2), st, (const float*)dz,
                          (const float*)x, mean, rstd, (const float*)gb, (float*)dgb, H, W, C, up);
   }
+  return (int)hipGetLastError();
+}
+
+int dei2i_spade_bwd_border(int dtype, int N, int H, int W, int C, int up, const void* dz, const void* x, const float* mean,
+                           const float* rstd, const void* gb, void* dgb_cls, dei2i_stream s) {
+  if (N <= 0 || H < 4 || W < 4 || !cv_ok(dtype, C) || up < 0 || up > 1 || !dz || !x || !mean || !rstd || !gb || !dgb_cls)
+    return DEI2I_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)s;
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(spade_bwd_border_kernel<bf16_t>, dim3(25, N), dim3(256), combine_lds(dtype, 2), st, (const bf16_t*)dz,
+                       (const bf16_t*)x, mean, rstd, (const bf16_t*)gb, (bf16_t*)dgb_cls, H, W, C, up);
+  else
+    hipLaunchKernelGGL(spade_bwd_border_kernel<float>, dim3(25, N), dim3(256), combine_lds(dtype, 2), st, (const float*)dz,
+                       (const float*)x, mean, rstd, (const float*)gb, (float*)dgb_cls, H, W, C, up);
   return (int)hipGetLastError();
 }
 

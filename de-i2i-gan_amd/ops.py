@@ -68,9 +68,13 @@ class fp8_forward:
 #               VALU slots compete with the MFMA issue) against ~39 us of statistics + modulate kernels saved: +1.4 ms/step.
 #   fuse_ring : SPADE -> nearest x2 upsample -> conv keeps the normalised tensor at the SOURCE resolution (+ the logical
 #               image's 2-pixel frame in a compact ring tensor): the 4x larger upsampled tensor is never written or read -- ON
+#   fuse_bwd  : the backward REDUCTIONS of a SPADE / BatchNorm layer (sum dxhat, sum dxhat*xhat, ... per channel) from the epilogue
+#               of the input-gradient launch of the conv behind it, while the dz tile is on chip -- the streaming pass that read
+#               dz and x again (spade_bwd_partial / bn_bwd_partial) is not launched -- ON
 fuse_norm = True
 fuse_pro = False
 fuse_ring = True
+fuse_bwd = True
 
 _fp8_stash = []          # e4m3 copy produced by the last normalisation kernel, handed to its output tensor by the wrapper
 
@@ -399,11 +403,61 @@ def _stats_of(t, n, hw, c):
     return partial, chunks
 
 
-def _conv_dgrad(lib, prec, geom, x_shape, couts, g, weight, cache, sources, per_call, dtype, device):
-    """Gradient w.r.t. the conv's physical input (N, H, W, CinS) from g = dL/dy (activation already folded in)."""
+class _NormBwdHint:
+    """What the input-gradient launch of a conv needs to take the backward reductions of the norm layer in FRONT of the conv in
+    its epilogue (csrc/conv_halo16.hip EPIN; include/dei2i_hip.h: dei2i_epi_norm), and where it leaves them: the norm's forward
+    makes one, hangs it on its output tensor (``_dei2i_bwd_hint``) and keeps it; the conv that reads that tensor picks it up;
+    in backward the conv's dgrad fills ``partial`` and the norm's backward -- handed that very dz tensor -- skips its own
+    streaming pass.  kind 1: SPADE class mode + ReLU (x, gb, mean, rstd, up); kind 2: BatchNorm + act (x = y, a, b, mean, rstd)."""
+    __slots__ = ("kind", "x", "gb", "mean", "rstd", "a", "b", "act", "up", "partial", "chunks", "dz_ptr")
+
+    def __init__(self, kind, x, mean, rstd, gb=None, a=None, b=None, act=0, up=False):
+        self.kind, self.x, self.mean, self.rstd, self.gb, self.a, self.b, self.act, self.up = kind, x, mean, rstd, gb, a, b, act, up
+        self.partial = self.chunks = self.dz_ptr = None
+
+    def take(self, dz):
+        """-> (partial, records per image) when ``dz`` is the tensor the conv's dgrad wrote them for, else None (another
+        consumer's gradient was added to it, or the dgrad took a kernel without that epilogue)."""
+        partial, chunks, ptr = self.partial, self.chunks, self.dz_ptr
+        self.partial = self.chunks = self.dz_ptr = None
+        if partial is None or not dz.is_contiguous() or dz.data_ptr() != ptr:
+            return None
+        bwd_fused_counts["taken"] += 1
+        return partial, chunks
+
+
+bwd_fused_counts = {"epilogue": 0, "taken": 0}   # dgrad launches that took the reductions / norm backwards that used them (tests)
+_hint_stash = []         # the hint of the last norm forward, handed to its output tensor by the wrapper
+
+
+def _attach_hint(out):
+    if _hint_stash:
+        out._dei2i_bwd_hint = _hint_stash.pop()
+    return out
+
+
+def _conv_dgrad(lib, prec, geom, x_shape, couts, g, weight, cache, sources, per_call, dtype, device, hint=None):
+    """Gradient w.r.t. the conv's physical input (N, H, W, CinS) from g = dL/dy (activation already folded in).  ``hint``: the
+    norm layer that produced the input (_NormBwdHint) -- its backward reductions are taken in this launch when the kernel can."""
     n, h, w, cins = x_shape
     d = _desc(prec, geom, n, h, w, cins, couts)
     _, wd = cache.get(weight, sources, prec, geom, cins, couts, need_dgrad=True, need_fwd=False, per_call=per_call)
+    if hint is not None:
+        hint.partial = hint.chunks = hint.dz_ptr = None
+        up = 1 if hint.up else 0
+        if (fuse_bwd and prec is BF16 and tuple(hint.x.shape) == (n, h >> up, w >> up, cins) and hint.x.is_contiguous()
+                and lib.dei2i_conv2d_dgrad_norm_supported(byref(d))):
+            chunks = lib.dei2i_conv2d_dgrad_norm_chunks(byref(d))
+            partial = torch.empty((n, chunks, 4 if hint.kind == 1 else 2, cins), dtype=torch.float32, device=device)
+            dx = torch.empty(x_shape, dtype=dtype, device=device)
+            en = L.EpiNormDesc(hint.kind, up, hint.act, 0, hint.x.data_ptr(), hint.mean.data_ptr(), hint.rstd.data_ptr(),
+                               hint.gb.data_ptr() if hint.gb is not None else None,
+                               hint.a.data_ptr() if hint.a is not None else None,
+                               hint.b.data_ptr() if hint.b is not None else None, partial.data_ptr())
+            L.check(lib.dei2i_conv2d_dgrad_input_norm(byref(d), _p(g), _p(wd), _p(dx), byref(en), _stream()), "conv2d_dgrad_input_norm")
+            hint.partial, hint.chunks, hint.dz_ptr = partial, chunks, dx.data_ptr()
+            bwd_fused_counts["epilogue"] += 1
+            return dx
     ws = _workspace(device, lib.dei2i_conv2d_workspace_bytes(byref(d)))
     dx = torch.empty(x_shape, dtype=dtype, device=device)
     ext = None
@@ -491,6 +545,8 @@ class _Conv2d(torch.autograd.Function):
     def forward(ctx, x, weight, bias, cache: PackedWeights, sources, geom: ConvGeom, act: int, want_stats: bool = False):
         _require_gpu(x, "conv2d")
         prec = precision_of(x)
+        # the norm layer that wrote x left what this conv's dgrad needs to take its backward reductions (see _NormBwdHint)
+        ctx.hint = getattr(x, "_dei2i_bwd_hint", None) if (x.is_contiguous() and not geom.up) else None
         x = x.contiguous()
         n, h, w, cins = x.shape
         couts = prec.pad(geom.cout)
@@ -558,7 +614,8 @@ class _Conv2d(torch.autograd.Function):
         if _wants_grad(ctx, 1):                              # (first: on its side stream it then runs beside the dgrad)
             dw = _conv_wgrad(lib, prec, geom, x, g, weight)
         if _wants_grad(ctx, 0):
-            dx = _conv_dgrad(lib, prec, geom, tuple(x.shape), couts, g, weight, ctx.cache, ctx.sources, ctx.per_call, x.dtype, x.device)
+            dx = _conv_dgrad(lib, prec, geom, tuple(x.shape), couts, g, weight, ctx.cache, ctx.sources, ctx.per_call, x.dtype, x.device,
+                             hint=ctx.hint)
         if ctx.has_bias and _wants_grad(ctx, 2):
             dbf = torch.empty(couts, dtype=torch.float32, device=x.device)
             rows = g.numel() // couts
@@ -686,16 +743,21 @@ def _bn_coefs(lib, y, prec, weight, bias, running_mean, running_var, training, m
     return a, b, mean, rstd, nf
 
 
-def _bn_backward(lib, prec, dout, y, a, b, mean, rstd, act, training, weight, bias, nf):
-    """-> (dy, dweight, dbias) of z = act(a*y + b) given dL/dz (csrc/reduce.hip: bn_bwd_partial / bn_bwd_apply)."""
+def _bn_backward(lib, prec, dout, y, a, b, mean, rstd, act, training, weight, bias, nf, hint=None):
+    """-> (dy, dweight, dbias) of z = act(a*y + b) given dL/dz (csrc/reduce.hip: bn_bwd_partial / bn_bwd_apply).  ``hint``: the
+    dgrad of the conv behind the layer may have left the reduction records already (_NormBwdHint)."""
     st = _stream()
+    have = hint.take(dout) if hint is not None else None
     dout = dout.contiguous()
     n, h, w, c = y.shape
     pixels = n * h * w
-    chunks = lib.dei2i_bn_bwd_chunks(pixels)
-    partial = torch.empty((chunks, 2, c), dtype=torch.float32, device=y.device)
-    L.check(lib.dei2i_bn_bwd_partial(prec.code, pixels, c, _p(dout), _p(y), _p(a), _p(b), _p(mean), _p(rstd), act,
-                                     _p(partial), st), "bn_bwd_partial")
+    if have is not None:
+        partial, chunks = have[0], n * have[1]
+    else:
+        chunks = lib.dei2i_bn_bwd_chunks(pixels)
+        partial = torch.empty((chunks, 2, c), dtype=torch.float32, device=y.device)
+        L.check(lib.dei2i_bn_bwd_partial(prec.code, pixels, c, _p(dout), _p(y), _p(a), _p(b), _p(mean), _p(rstd), act,
+                                         _p(partial), st), "bn_bwd_partial")
     padded = nf < c               # padded channel stride: c-sized scratch vectors, sliced to num_features below
     if padded:
         tmp_wb = torch.empty((2, c), dtype=torch.float32, device=y.device)
@@ -756,13 +818,18 @@ class _BatchNormAct(torch.autograd.Function):
         ctx.prec, ctx.act, ctx.training, ctx.has_res = prec, act, training, res is not None
         ctx.params, ctx.nf = (weight, bias), nf
         ctx.save_for_backward(y, a, b, mean, rstd)
+        ctx.hint = None
+        if fuse_bwd and prec is BF16 and ctx.needs_input_grad[0]:
+            ctx.hint = _NormBwdHint(2, y, mean, rstd, a=a, b=b, act=act)
+            _hint_stash.append(ctx.hint)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         y, a, b, mean, rstd = ctx.saved_tensors
         weight, bias = ctx.params
-        dy, dweight, dbias = _bn_backward(_lib_for(y), ctx.prec, dout, y, a, b, mean, rstd, ctx.act, ctx.training, weight, bias, ctx.nf)
+        dy, dweight, dbias = _bn_backward(_lib_for(y), ctx.prec, dout, y, a, b, mean, rstd, ctx.act, ctx.training, weight, bias, ctx.nf,
+                                          hint=ctx.hint)
         return dy, dweight, dbias, (dout if ctx.has_res else None), None, None, None, None, None, None, None, None
 
 
@@ -772,8 +839,10 @@ def batchnorm_act(y, weight, bias, running_mean, running_var, training, act="non
     ``stats``: a norm layer reads the output next -- leave its statistics records with it (see _stats_of)."""
     del _fp8_stash[:]
     del _stats_stash[:]
-    return _attach_stats(_attach_fp8(_BatchNormAct.apply(y, weight, bias, res, running_mean, running_var, bool(training),
-                                                         float(momentum), float(eps), ACT[act], num_batches_tracked, bool(stats))))
+    del _hint_stash[:]
+    return _attach_hint(_attach_stats(_attach_fp8(_BatchNormAct.apply(y, weight, bias, res, running_mean, running_var, bool(training),
+                                                                      float(momentum), float(eps), ACT[act], num_batches_tracked,
+                                                                      bool(stats)))))
 
 
 class _BnActConv(torch.autograd.Function):
@@ -821,9 +890,11 @@ class _BnActConv(torch.autograd.Function):
             dw = _conv_wgrad(lib, prec, geom, y1, dy, weight, pro, keep=(a, b))
         dy1 = dbw = dbb = None
         if _wants_grad(ctx, 0) or _wants_grad(ctx, 1) or _wants_grad(ctx, 2):
-            dh = _conv_dgrad(lib, prec, geom, tuple(y1.shape), dy.shape[-1], dy, weight, ctx.cache, ctx.sources, False, y1.dtype, y1.device)
+            hint = _NormBwdHint(2, y1, mean, rstd, a=a, b=b, act=ctx.act)
+            dh = _conv_dgrad(lib, prec, geom, tuple(y1.shape), dy.shape[-1], dy, weight, ctx.cache, ctx.sources, False, y1.dtype, y1.device,
+                             hint=hint)
             bn_w, bn_b = ctx.params
-            dy1, dbw, dbb = _bn_backward(lib, prec, dh, y1, a, b, mean, rstd, ctx.act, ctx.training, bn_w, bn_b, ctx.nf)
+            dy1, dbw, dbb = _bn_backward(lib, prec, dh, y1, a, b, mean, rstd, ctx.act, ctx.training, bn_w, bn_b, ctx.nf, hint=hint)
         return (dy1, dbw, dbb, dw) + (None,) * 11
 
 
@@ -888,18 +959,26 @@ class _AffineAdd(torch.autograd.Function):
 # --------------------------------------------------------------------------------------------------------------
 # SPADE (InstanceNorm * (1+gamma) + beta) + ReLU, optional fused nearest x2 upsample of x
 # --------------------------------------------------------------------------------------------------------------
-def _spade_backward(lib, prec, dout, dskip, x, gb, mean, rstd, up, gb_mode, out_shape):
+def _spade_backward(lib, prec, dout, dskip, x, gb, mean, rstd, up, gb_mode, out_shape, hint=None):
     """-> (dx, dgb) of z = relu(IN(x)*(1+gamma)+beta) given dL/dz at the (upsampled) output resolution; dskip (optional) is
-    added to dx inside the apply kernel (the res block's identity branch)."""
+    added to dx inside the apply kernel (the res block's identity branch).  ``hint``: the dgrad of the conv behind the layer may
+    have left the reduction records already (_NormBwdHint); the 24 border classes of the table's gradient are then all that is
+    left of the first pass."""
     st = _stream()
     dev = x.device
+    have = hint.take(dout) if (hint is not None and gb_mode == 1) else None
     dout = dout.contiguous()
     n, h, w, c = out_shape
-    chunks = lib.dei2i_moments_chunks(h * w)
-    partial = torch.empty((n, chunks, 4, c), dtype=torch.float32, device=dev)
     dgb = torch.empty_like(gb)         # dense (N,H,W,2C), or the (N,5,5,2C) class table -- both written in full
-    L.check(lib.dei2i_spade_bwd_partial(prec.code, n, h, w, c, 1 if up else 0, _p(dout), _p(x), _p(mean), _p(rstd),
-                                        _p(gb), gb_mode, _p(dgb), _p(partial), st), "spade_bwd_partial")
+    if have is not None:
+        partial, chunks = have
+        L.check(lib.dei2i_spade_bwd_border(prec.code, n, h, w, c, 1 if up else 0, _p(dout), _p(x), _p(mean), _p(rstd), _p(gb),
+                                           _p(dgb), st), "spade_bwd_border")
+    else:
+        chunks = lib.dei2i_moments_chunks(h * w)
+        partial = torch.empty((n, chunks, 4, c), dtype=torch.float32, device=dev)
+        L.check(lib.dei2i_spade_bwd_partial(prec.code, n, h, w, c, 1 if up else 0, _p(dout), _p(x), _p(mean), _p(rstd),
+                                            _p(gb), gb_mode, _p(dgb), _p(partial), st), "spade_bwd_partial")
     coef = torch.empty((n, 2, c), dtype=torch.float32, device=dev)
     dx = torch.empty_like(x)
     L.check(lib.dei2i_spade_bwd_apply(prec.code, n, h, w, c, 1 if up else 0, _p(dout), _p(x), _p(mean), _p(rstd), _p(gb), gb_mode,
@@ -945,6 +1024,10 @@ class _SpadeRelu(torch.autograd.Function):
         ctx.prec, ctx.up, ctx.gb_mode = prec, up, gb_mode
         ctx.out_shape = (n, h, w, c)
         ctx.save_for_backward(x, gb, mean, rstd)        # backward recomputes the ReLU mask; the output is not kept
+        ctx.hint = None
+        if fuse_bwd and gb_mode == 1 and prec is BF16 and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            ctx.hint = _NormBwdHint(1, x, mean, rstd, gb=gb, up=up)
+            _hint_stash.append(ctx.hint)
         return (out, x_in) if skip else out
 
     @staticmethod
@@ -956,17 +1039,19 @@ class _SpadeRelu(torch.autograd.Function):
             dskip = dskip.contiguous()
             if dskip.dtype != x.dtype or dskip.shape != x.shape:
                 raise RuntimeError("spade_relu: identity-branch gradient does not match the activation")
-        dx, dgb = _spade_backward(_lib_for(x), ctx.prec, dout, dskip, x, gb, mean, rstd, ctx.up, ctx.gb_mode, ctx.out_shape)
+        dx, dgb = _spade_backward(_lib_for(x), ctx.prec, dout, dskip, x, gb, mean, rstd, ctx.up, ctx.gb_mode, ctx.out_shape,
+                                  hint=ctx.hint)
         return dx, dgb, None, None, None, None
 
 
 def spade_relu(x, gb, up: bool, gb_mode: int, eps: float = 1e-5, skip: bool = False):
     """relu(IN(x) * (1 + gamma) + beta); with ``skip`` -> (that, x): x handed through for the res block's identity add."""
     del _fp8_stash[:]
+    del _hint_stash[:]
     if skip:
         out, xs = _SpadeRelu.apply(x, gb, bool(up), int(gb_mode), float(eps), True)
-        return _attach_fp8(out), xs
-    return _attach_fp8(_SpadeRelu.apply(x, gb, bool(up), int(gb_mode), float(eps)))
+        return _attach_hint(_attach_fp8(out)), xs
+    return _attach_hint(_attach_fp8(_SpadeRelu.apply(x, gb, bool(up), int(gb_mode), float(eps))))
 
 
 class _SpadeConv(torch.autograd.Function):
@@ -1053,8 +1138,10 @@ class _SpadeConv(torch.autograd.Function):
             # dL/dz at the LOGICAL (upsampled) resolution: the conv seen as a plain conv on z (the SPADE backward sums the
             # 2x2 cells itself, and needs the per-logical-pixel mask and class)
             g_log = ConvGeom(geom.cin, geom.cout, geom.k, geom.stride, geom.pad, geom.reflect, False)
-            dz = _conv_dgrad(lib, prec, g_log, (n, h, w, c), dy.shape[-1], dy, weight, ctx.cache, ctx.sources, False, x.dtype, x.device)
-            dx, dgb = _spade_backward(lib, prec, dz, dskip, x, gb, coefs[0], coefs[1], up, 1, ctx.out_shape)
+            hint = _NormBwdHint(1, x, coefs[0], coefs[1], gb=gb, up=up)
+            dz = _conv_dgrad(lib, prec, g_log, (n, h, w, c), dy.shape[-1], dy, weight, ctx.cache, ctx.sources, False, x.dtype, x.device,
+                             hint=hint)
+            dx, dgb = _spade_backward(lib, prec, dz, dskip, x, gb, coefs[0], coefs[1], up, 1, ctx.out_shape, hint=hint)
         elif dskip is not None:
             dx = dskip
         return (dx, dgb, dw) + (None,) * 8

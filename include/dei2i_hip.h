@@ -280,6 +280,37 @@ int dei2i_conv2d_wgrad_oihw_pro(const dei2i_conv* c, const void* x, const void* 
 int dei2i_conv2d_ring_supported(const dei2i_conv* c);
 int dei2i_conv2d_fwd_ring(const dei2i_conv* c, const void* z_src, const void* ring, const void* w_packed, const float* bias, int act,
                           void* y, float* stats, dei2i_stream s);
+/* Backward reductions of the normalisation layer in FRONT of a conv, taken from the epilogue of that conv's input-gradient
+ * launch (the dz tile is still on chip) instead of by dei2i_spade_bwd_partial / dei2i_bn_bwd_partial re-reading dz and x:
+ *   kind 1  z = relu(IN(x)*(1+gamma)+beta) with the (N,5,5,2C) class table `gb` (normalization.py:24-37); mean / rstd (N,C);
+ *           partial (N, chunks, 4, C) -- the record layout of dei2i_spade_bwd_partial, for dei2i_spade_bwd_apply; the 24 border
+ *           classes of the table's gradient still come from dei2i_spade_bwd_border
+ *   kind 2  z = act(a*y + b), BatchNorm + activation (architecture.py:116-118), `x` = y; a / b / mean / rstd (C);
+ *           partial (N*chunks, 2, C) -- the record layout of dei2i_bn_bwd_partial, for dei2i_bn_bwd_apply
+ * chunks = dei2i_conv2d_dgrad_norm_chunks(c) records per image.  `x` has the conv input's channel stride (c->CinS) and, with
+ * `up`, half the resolution of the conv's input (SPADE behind a nearest x2 upsample; c describes the conv at the upsampled
+ * size with c->up = 0).  bf16, stride-1 reflect-padded 3x3 convs on grids the 16 x 32 tile kernel takes: ask _supported first --
+ * dei2i_conv2d_dgrad_input_norm has no fallback inside. */
+typedef struct dei2i_epi_norm {
+  int kind;
+  int up;
+  int act;
+  int reserved;
+  const void* x;
+  const float* mean;
+  const float* rstd;
+  const void* gb;
+  const float* a;
+  const float* b;
+  float* partial;
+} dei2i_epi_norm;
+int dei2i_conv2d_dgrad_norm_supported(const dei2i_conv* c);                   /* 1 / 0 */
+int dei2i_conv2d_dgrad_norm_chunks(const dei2i_conv* c);
+int dei2i_conv2d_dgrad_input_norm(const dei2i_conv* c, const void* dy, const void* wd_packed, void* dx, const dei2i_epi_norm* en,
+                                  dei2i_stream s);
+/* the border-class half of dei2i_spade_bwd_partial alone (class mode): dgb_cls[n, cy, cx, :] for the 24 classes (cy, cx) != (2, 2) */
+int dei2i_spade_bwd_border(int dtype, int N, int H, int W, int C, int up, const void* dz, const void* x, const float* mean,
+                           const float* rstd, const void* gb, void* dgb_cls, dei2i_stream s);
 /* out[n, p, c] = max(A[n, c] * x[n, p, c] + B[n, c], 0) + slope * min(..., 0): an affine + activation with per-IMAGE
  * coefficients (SPADE's interior class at the source resolution; HW pixels per image) */
 int dei2i_affine_act_img_fwd(int dtype, int N, int HW, int C, const void* x, const float* A, const float* B, float slope, void* out,

@@ -288,3 +288,76 @@ def test_weight_gradients_on_the_side_stream_are_bit_identical_and_joined():
     assert len(grads[True]) == len(grads[False]) > 50
     for a, b in zip(grads[True], grads[False]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,C,cout,hs,ws,N,up,skip", [("spade", 256, 256, 64, 64, 16, False, True), ("spade", 128, 64, 64, 64, 8, True, False),
+                                                         ("spade", 64, 64, 128, 128, 16, False, False), ("spade", 160, 128, 64, 64, 16, False, False),
+                                                         ("bn", 256, 256, 64, 64, 16, False, False), ("bn", 64, 128, 128, 128, 16, False, False),
+                                                         ("bn_eval", 256, 128, 64, 64, 16, False, False)])
+def test_norm_backward_reductions_from_the_dgrad_epilogue(kind, C, cout, hs, ws, N, up, skip):
+    """SURVEY.md Appendix B "their backward reductions from the dgrad epilogue": the per-channel sums of the SPADE / BatchNorm
+    backward (normalization.py:24-37, architecture.py:116-118) taken by the input-gradient launch of the conv behind the
+    layer (ops.fuse_bwd, conv_halo16.hip EPIN) against the streaming pass over dz and x (reduce.hip) on the same inputs:
+    the same per-element arithmetic on the same bf16 dz, only the order of the fp32 additions differs.  The oracle parity
+    of the default (epilogue) path is test_spade_conv_fused / test_bn_act_conv_fused / the model goldens."""
+    from de_i2i_gan_amd import ops
+    from de_i2i_gan_amd.networks.architecture import SPADE, Conv2d
+    torch.manual_seed(11)
+    x = (torch.randn(N, C, hs, ws) * 1.3 + 0.2).bfloat16()
+    h, w = (2 * hs, 2 * ws) if up else (hs, ws)
+    gy = nhwc(torch.randn(N, cout, h, w).bfloat16()).to(DEV)
+    gs = nhwc(torch.randn(N, C, hs, ws).bfloat16()).to(DEV)
+    conv = Conv2d(C, cout, 3, padding="same", padding_mode="reflect", bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(cout, C, 3, 3) * math.sqrt(2.0 / (C * 9)))
+    conv = conv.to(DEV)
+    keep = (ops.fuse_bwd, ops.fuse_pro, ops.fuse_ring, ops.fuse_norm)
+    res = {}
+    try:
+        ops.fuse_pro, ops.fuse_ring, ops.fuse_norm = False, True, True
+        if kind == "spade":
+            seg = torch.zeros(N, 6, 1, 1)
+            for i in range(N):
+                seg[i, 1 + i % 5] = 1
+            mod = SPADE(6, C, hidden_nc=32, kernel_size=(3, 3), padding="same")
+            with torch.no_grad():
+                for k_, p in mod.named_parameters():
+                    p.copy_(O.formula_tensor("spade." + k_, tuple(p.shape)) * (3.0 if p.dim() == 4 else 1.0))
+            mod = mod.to(DEV)
+        else:
+            bn_w = (torch.rand(C) + 0.5).to(DEV).requires_grad_(True)
+            bn_b = (torch.randn(C) * 0.1).to(DEV).requires_grad_(True)
+        for on in (True, False):
+            ops.fuse_bwd = on
+            conv.weight.grad = None
+            before = dict(ops.bwd_fused_counts)
+            xg = nhwc(x).to(DEV).requires_grad_(True)
+            if kind == "spade":
+                for p in mod.parameters():
+                    p.grad = None
+                mod._gb_cache.clear()
+                if skip:
+                    out, xs = mod.fused_conv(xg, seg.to(DEV), conv, up=up, skip=True)
+                    torch.autograd.backward([out, xs], [gy, gs])
+                else:
+                    mod.fused_conv(xg, seg.to(DEV), conv, up=up).backward(gy)
+                params = {k_: p.grad.clone() for k_, p in mod.named_parameters()}
+            else:
+                bn_w.grad = bn_b.grad = None
+                rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+                z = ops.batchnorm_act(xg, bn_w, bn_b, rm, rv, kind == "bn", "leaky_relu")
+                conv(z).backward(gy)
+                params = {"weight": bn_w.grad.clone(), "bias": bn_b.grad.clone()}
+            torch.cuda.synchronize()
+            took = {k_: ops.bwd_fused_counts[k_] - before[k_] for k_ in before}
+            assert took == ({"epilogue": 1, "taken": 1} if on else {"epilogue": 0, "taken": 0}), (on, took)
+            res[on] = (xg.grad.clone(), conv.weight.grad.clone(), params)
+    finally:
+        ops.fuse_bwd, ops.fuse_pro, ops.fuse_ring, ops.fuse_norm = keep
+    e, s = res[True], res[False]
+    assert torch.isfinite(e[0]).all()
+    assert rel_l2(e[0], s[0]) < 2e-4 and maxrel(e[0], s[0]) < 1e-2, (rel_l2(e[0], s[0]), maxrel(e[0], s[0]))   # bf16 dx: an ulp here and there
+    assert torch.equal(e[1], s[1])                                  # the weight gradient does not see the change at all
+    for k_ in e[2]:
+        assert rel_l2(e[2][k_], s[2][k_]) < 2e-4, (k_, rel_l2(e[2][k_], s[2][k_]))
