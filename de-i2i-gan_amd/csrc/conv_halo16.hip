@@ -659,11 +659,15 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
   const int rec0 = img * (2 * tiles_y * tiles_x) + (2 * (trem / tiles_x)) * tiles_x + (trem % tiles_x);
   // EPIN: the per-channel coefficients of this thread's 8 channels -- kind 1: mean | rstd of the image; kind 2: a | b | mean | rstd
   float nc[EPIN ? 4 : 1][8];
+  u32x4 gmi = {0u, 0u, 0u, 0u}, bti = {0u, 0u, 0u, 0u};      // kind 1: gamma | beta of the interior class (2, 2), packed
   if constexpr (EPIN) {
     if (ncol < ldc) {
       if (en.kind == 1) {
         ldcoef<8>(en.mean + (size_t)img * ldc + ncol, nc[0]);
         ldcoef<8>(en.rstd + (size_t)img * ldc + ncol, nc[1]);
+        const bf16_t* gp = en.gb + ((size_t)(img * 5 + 2) * 5 + 2) * 2 * ldc + ncol;
+        gmi = *reinterpret_cast<const u32x4*>(gp);
+        bti = *reinterpret_cast<const u32x4*>(gp + ldc);
       } else {
         ldcoef<8>(en.a + ncol, nc[0]); ldcoef<8>(en.b + ncol, nc[1]);
         ldcoef<8>(en.mean + ncol, nc[2]); ldcoef<8>(en.rstd + ncol, nc[3]);
@@ -697,6 +701,21 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
     float ep[EPIN ? 32 : 1];              // EPIN: this thread's 8 channels x the (up to) 4 sums of the norm's backward
 #pragma unroll
     for (int k = 0; k < (EPIN ? 32 : 1); ++k) ep[k] = 0.f;
+    // EPIN: this half's x rows of the thread (one 16-byte load per write-back pass) are requested HERE, ahead of the barriers and
+    // the ring / corner work on the staged tile, so their HBM latency is off the write-back's path
+    constexpr int NPASS = 256 / RPP;
+    u32x4 xq[EPIN ? NPASS : 1];
+    if constexpr (EPIN) {
+      if (ncol < ldc) {
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+          const int row = p * RPP + rsub;
+          const int py = y0 + half * 8 + (row >> 5), px = x0 + (row & 31);
+          const size_t xpix = ((size_t)(img * (g.Ho >> en.up) + (py >> en.up))) * (g.Wo >> en.up) + (px >> en.up);
+          xq[p] = *reinterpret_cast<const u32x4*>(en.x + xpix * ldc + ncol);
+        }
+      }
+    }
     __syncthreads();
     if constexpr (EPIN) ctile = smem + half * HALF_BYTES;
     if (!EPIN && (wm >> 1) == half) stage_acc(ctile);
@@ -758,7 +777,7 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
       }
     }
     if (ncol < ldc) {
-#pragma unroll(EPIN ? 2 : 256 / RPP)
+#pragma unroll
       for (int p = 0; p < 256 / RPP; ++p) {
         const int row = p * RPP + rsub;
         const size_t opix = (size_t)out_pixel(g, img, y0 + half * 8 + (row >> 5), x0 + (row & 31));
@@ -774,17 +793,21 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
           // v = dL/dz of 8 channels of pixel (py, px), as the streaming pass would read it back (bf16): the same per-element
           // arithmetic as spade_bwd_partial_kernel / bn_bwd_partial_kernel (reduce.hip)
           const int py = y0 + half * 8 + (row >> 5), px = x0 + (row & 31);
-          const size_t xpix = ((size_t)(img * (g.Ho >> en.up) + (py >> en.up))) * (g.Wo >> en.up) + (px >> en.up);
           float d8[8], x8[8];
           Elem<bf16_t>::unpack(v, d8);
-          Elem<bf16_t>::unpack(*reinterpret_cast<const u32x4*>(en.x + xpix * ldc + ncol), x8);
+          Elem<bf16_t>::unpack(xq[p], x8);
           if (en.kind == 1) {
             const int cy = border_class(py, g.Ho), cx = border_class(px, g.Wo);
-            const bf16_t* gp = en.gb + ((size_t)(img * 5 + cy) * 5 + cx) * 2 * ldc + ncol;
-            float gm[8], bt[8];
-            Elem<bf16_t>::unpack(*reinterpret_cast<const u32x4*>(gp), gm);
-            Elem<bf16_t>::unpack(*reinterpret_cast<const u32x4*>(gp + ldc), bt);
             const bool interior = cy == 2 && cx == 2;
+            u32x4 gq = gmi, bq2 = bti;                   // the interior class (kept in registers); the frame's pixels fetch theirs
+            if (!interior) {
+              const bf16_t* gp = en.gb + ((size_t)(img * 5 + cy) * 5 + cx) * 2 * ldc + ncol;
+              gq = *reinterpret_cast<const u32x4*>(gp);
+              bq2 = *reinterpret_cast<const u32x4*>(gp + ldc);
+            }
+            float gm[8], bt[8];
+            Elem<bf16_t>::unpack(gq, gm);
+            Elem<bf16_t>::unpack(bq2, bt);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               const float xh = (x8[e] - nc[0][e]) * nc[1][e];
