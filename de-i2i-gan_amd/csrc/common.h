@@ -190,6 +190,21 @@ DEI2I_D void glds16_asm(const void* gptr, unsigned char* lds_wave_base) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gptr), "s"(dst) : "memory");
 }
+// the same with a wave-uniform 64-bit base (SGPR pair) + a per-lane unsigned 32-bit BYTE offset: no 64-bit vector add per instruction
+// (lds_dst: the LDS byte address of the wave's 1 KB piece, wave-uniform -- lds_addr_of(smem) + offset)
+DEI2I_D unsigned lds_addr_of(const void* lds_ptr) {
+  typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
+  return (unsigned)(uintptr_t)(lds_byte_t*)lds_ptr;
+}
+DEI2I_D void glds16_asm_s(const void* sbase, unsigned voff_bytes, unsigned lds_dst) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)sbase);          // (the builtin returns int:
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((uintptr_t)sbase >> 32));  //  no sign extension into the high half)
+  const unsigned long long sb = ((unsigned long long)hi << 32) | (unsigned long long)lo;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff_bytes), "s"(sb), "s"(dst) : "memory");
+}
 #endif
 
 }  // namespace dei2i
