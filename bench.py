@@ -366,7 +366,7 @@ def main():
                         t2 = json.load(f)
                     mfma_pmc = t2.get("halo16_conv_fwd", t2.get("halo16_conv", t2.get("halo_conv", {}))).get("mfma_busy_frac")
         xn, xms, xfl = xhn + xon, xhms + xoms, xhfl + xofl
-        line["roofline"] = {"bound": "mfma", "kernel": "halo16_conv_kernel<128, 8, 0, false, 0, true> (halo-resident stride-1 3x3 conv, 16x32-pixel "
+        line["roofline"] = {"bound": "mfma", "kernel": "halo16_conv_kernel<128, 8, 0, false, 0, true, false> (halo-resident stride-1 3x3 conv, 16x32-pixel "
                             "tiles, software-pipelined loop: the forward launches; the step's largest single kernel, ~15 % of its device "
                             "time -- its FOLD instance, the reflect dgrads, is the second largest and runs beside the side-stream wgrads)",
                             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,

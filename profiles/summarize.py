@@ -25,7 +25,7 @@ FAMILIES = (("thin_cin_conv", "thin_cin_conv_kernel"), ("thin_cout_conv", "thin_
 def family(name):
     # the two large instances of the 16 x 32-tile halo conv are kernels of their own: the pipelined forward instance (the
     # step's largest kernel, bench.py's roofline line) and the FOLD instance (reflect dgrads)
-    if "halo16_conv_kernel<128, 8, 0, false, 0, true>" in name:
+    if "halo16_conv_kernel<128, 8, 0, false, 0, true" in name:
         return "halo16_conv_fwd"
     if "halo16_conv_kernel<128, 8, 0, true" in name:
         return "halo16_conv_fold"
