@@ -409,18 +409,28 @@ class _NormBwdHint:
     makes one, hangs it on its output tensor (``_dei2i_bwd_hint``) and keeps it; the conv that reads that tensor picks it up;
     in backward the conv's dgrad fills ``partial`` and the norm's backward -- handed that very dz tensor -- skips its own
     streaming pass.  kind 1: SPADE class mode + ReLU (x, gb, mean, rstd, up); kind 2: BatchNorm + act (x = y, a, b, mean, rstd)."""
-    __slots__ = ("kind", "x", "gb", "mean", "rstd", "a", "b", "act", "up", "partial", "chunks", "dz_ptr")
+    __slots__ = ("kind", "x", "gb", "mean", "rstd", "a", "b", "act", "up", "partial", "chunks", "dz", "dz_version")
 
     def __init__(self, kind, x, mean, rstd, gb=None, a=None, b=None, act=0, up=False):
         self.kind, self.x, self.mean, self.rstd, self.gb, self.a, self.b, self.act, self.up = kind, x, mean, rstd, gb, a, b, act, up
-        self.partial = self.chunks = self.dz_ptr = None
+        self.partial = self.chunks = self.dz = self.dz_version = None
+
+    def give(self, partial, chunks, dz):
+        # the dz tensor itself is held until the norm's backward has looked at it: while this reference exists autograd's input
+        # buffer cannot add a second consumer's gradient INTO dz (it accumulates in place only into a buffer nobody else holds),
+        # so "same storage, same version" below means "exactly what the dgrad kernel reduced"
+        self.partial, self.chunks, self.dz, self.dz_version = partial, chunks, dz, dz._version
+
+    def drop(self):
+        self.partial = self.chunks = self.dz = self.dz_version = None
 
     def take(self, dz):
         """-> (partial, records per image) when ``dz`` is the tensor the conv's dgrad wrote them for, else None (another
         consumer's gradient was added to it, or the dgrad took a kernel without that epilogue)."""
-        partial, chunks, ptr = self.partial, self.chunks, self.dz_ptr
-        self.partial = self.chunks = self.dz_ptr = None
-        if partial is None or not dz.is_contiguous() or dz.data_ptr() != ptr:
+        partial, chunks, mine, version = self.partial, self.chunks, self.dz, self.dz_version
+        self.drop()
+        if (partial is None or not dz.is_contiguous() or dz.data_ptr() != mine.data_ptr() or dz.shape != mine.shape
+                or dz._version != version):
             return None
         bwd_fused_counts["taken"] += 1
         return partial, chunks
@@ -443,7 +453,7 @@ def _conv_dgrad(lib, prec, geom, x_shape, couts, g, weight, cache, sources, per_
     d = _desc(prec, geom, n, h, w, cins, couts)
     _, wd = cache.get(weight, sources, prec, geom, cins, couts, need_dgrad=True, need_fwd=False, per_call=per_call)
     if hint is not None:
-        hint.partial = hint.chunks = hint.dz_ptr = None
+        hint.drop()
         up = 1 if hint.up else 0
         if (fuse_bwd and prec is BF16 and tuple(hint.x.shape) == (n, h >> up, w >> up, cins) and hint.x.is_contiguous()
                 and lib.dei2i_conv2d_dgrad_norm_supported(byref(d))):
@@ -455,7 +465,7 @@ def _conv_dgrad(lib, prec, geom, x_shape, couts, g, weight, cache, sources, per_
                                hint.a.data_ptr() if hint.a is not None else None,
                                hint.b.data_ptr() if hint.b is not None else None, partial.data_ptr())
             L.check(lib.dei2i_conv2d_dgrad_input_norm(byref(d), _p(g), _p(wd), _p(dx), byref(en), _stream()), "conv2d_dgrad_input_norm")
-            hint.partial, hint.chunks, hint.dz_ptr = partial, chunks, dx.data_ptr()
+            hint.give(partial, chunks, dx)
             bwd_fused_counts["epilogue"] += 1
             return dx
     ws = _workspace(device, lib.dei2i_conv2d_workspace_bytes(byref(d)))

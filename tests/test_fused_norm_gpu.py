@@ -361,3 +361,51 @@ def test_norm_backward_reductions_from_the_dgrad_epilogue(kind, C, cout, hs, ws,
     assert torch.equal(e[1], s[1])                                  # the weight gradient does not see the change at all
     for k_ in e[2]:
         assert rel_l2(e[2][k_], s[2][k_]) < 2e-4, (k_, rel_l2(e[2][k_], s[2][k_]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("conv_last", [True, False])
+def test_norm_backward_reductions_are_not_used_when_dz_has_a_second_consumer(conv_last):
+    """The ResBlock case (architecture.py:139-156: x feeds the block's first conv AND its identity add): the BatchNorm output has two
+    consumers, so dL/dz is the conv's input gradient PLUS the identity branch's gradient, summed by autograd's input buffer -- in
+    place into whichever arrives first when nobody else holds that tensor.  The dgrad epilogue only saw its own share: its records
+    must not be used (ops._NormBwdHint keeps the dgrad's tensor referenced until the norm's backward has looked at it, so the sum is
+    a new tensor, and compares storage + version).  Both arrival orders; against the streaming pass bit for bit."""
+    from de_i2i_gan_amd import ops
+    from de_i2i_gan_amd.networks.architecture import Conv2d
+    torch.manual_seed(5)
+    N, C, H = 16, 256, 64
+    x = nhwc((torch.randn(N, C, H, H) * 1.3 + 0.2).bfloat16()).to(DEV)
+    gy = nhwc(torch.randn(N, C, H, H).bfloat16()).to(DEV)
+    gs = nhwc(torch.randn(N, C, H, H).bfloat16()).to(DEV)
+    conv = Conv2d(C, C, 3, padding="same", padding_mode="reflect", bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(C, C, 3, 3) * math.sqrt(2.0 / (C * 9)))
+    conv = conv.to(DEV)
+    bn_w = (torch.rand(C) + 0.5).to(DEV).requires_grad_(True)
+    bn_b = (torch.randn(C) * 0.1).to(DEV).requires_grad_(True)
+    keep = (ops.fuse_bwd, ops.fuse_pro)
+    res = {}
+    try:
+        ops.fuse_pro = False
+        for on in (True, False):
+            ops.fuse_bwd = on
+            conv.weight.grad = bn_w.grad = bn_b.grad = None
+            before = dict(ops.bwd_fused_counts)
+            xg = x.clone().requires_grad_(True)
+            z = ops.batchnorm_act(xg, bn_w, bn_b, torch.zeros(C, device=DEV), torch.ones(C, device=DEV), True, "leaky_relu")
+            if conv_last:                                # the later node runs first in backward: the conv's gradient arrives first
+                side = ops.add(z, z)
+                y = conv(z)
+            else:
+                y = conv(z)
+                side = ops.add(z, z)
+            torch.autograd.backward([y, side], [gy, gs])
+            torch.cuda.synchronize()
+            took = {k_: ops.bwd_fused_counts[k_] - before[k_] for k_ in before}
+            assert took["taken"] == 0, (on, took)        # the records of a shared dz are never used
+            res[on] = (xg.grad.clone(), bn_w.grad.clone(), bn_b.grad.clone())
+    finally:
+        ops.fuse_bwd, ops.fuse_pro = keep
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
