@@ -24,8 +24,6 @@ class DefectGanModel(BaseModel):
         self.netG = DefectGanGenerator(opt).to(opt.device, non_blocking=True)
         self.netD = DefectGanDiscriminator(opt).to(opt.device, non_blocking=True)
         if opt.style_norm_block_type == "sean":          # style embeddings (defectgan_model.py:34-45)
-            if getattr(opt, "use_running_stats", False):
-                raise NotImplementedError("SEAN: --use_running_stats is not implemented")
             if opt.sean_alpha is not None:
                 self.netG.set_sean_alpha(opt.sean_alpha)
             if opt.sean_alpha != 0:
@@ -143,9 +141,20 @@ class DefectGanModel(BaseModel):
         done.record(torch.cuda.current_stream(dev))
         return out
 
+    def _sean_distill(self):
+        return self.opt.style_norm_block_type == "sean" and getattr(self.opt, "style_distill", False)
+
     def _compute_mae_generator_loss(self, imgs, labels):
-        """(rec, gan, clf): l1(G(masked), x), bce(D(G(masked)), 1), bce(cls(G(masked)), labels)"""
+        """(rec, gan, clf): l1(G(masked), x), bce(D(G(masked)), 1), bce(cls(G(masked)), labels); with SEAN's --style_distill
+        (defectgan_model.py:106-128) the two distillation terms are appended (logged only: their gradients were taken inside
+        the SEAN layers' forward) -- but not in the --split_training return, like the reference"""
+        if self._sean_distill():
+            self.netG.enable_sean_distill_loss(True)
         predicted, _ = self._repair_mask(imgs, labels)
+        distill = None
+        if self._sean_distill():
+            distill = self.netG.get_sean_distill_loss()
+            self.netG.enable_sean_distill_loss(False)
         rec_loss = self._cal_loss(predicted, imgs, "l1")
         if getattr(self.opt, "split_training", False):      # --split_training (defectgan_model.py:119-120): G sees only the L1 loss
             zero = torch.zeros([], device=rec_loss.device)
@@ -158,7 +167,8 @@ class DefectGanModel(BaseModel):
         finally:
             for p in d_params:
                 p.requires_grad_(True)
-        return rec_loss, self._cal_loss(fake_src, 1.0, "bce"), self._cal_loss(fake_cls, labels.view_as(fake_cls), self.clf_loss_type)
+        out = (rec_loss, self._cal_loss(fake_src, 1.0, "bce"), self._cal_loss(fake_cls, labels.view_as(fake_cls), self.clf_loss_type))
+        return out + (distill["latent"], distill["embed"]) if distill is not None else out
 
     def _compute_mae_discriminator_loss(self, imgs, labels):
         """(gan, clf): mean(bce(D(G(masked)), 0), bce(D(x), 1)), bce(cls(x), labels); G runs in eval mode, no grad"""
@@ -180,10 +190,21 @@ class DefectGanModel(BaseModel):
         self.netG.clear_spade_cache()
         if not os.environ.get("DEI2I_SPLIT_D") and nm_feat is None:
             self.netG.prime_spade((df_labels, nm_labels))        # both label sets' SPADE tables in one pass
+        sean = self.opt.style_norm_block_type == "sean"       # defectgan_model.py:177-182,192-197: what the four passes also feed
+        if self._sean_distill():
+            self.netG.enable_sean_distill_loss(True)
+        if sean and getattr(self.opt, "use_running_stats", False):
+            self.netG.track_running_stats = True
         fake_defects, df_prob = self.netG(bg_data, df_labels, df_feat)
         recover_normals, rec_df_prob = self.netG(fake_defects, nm_labels, nm_feat)
         fake_normals, nm_prob = self.netG(df_data, nm_labels, nm_feat)
         recover_defects, rec_nm_prob = self.netG(fake_normals, df_labels, df_feat)
+        distill = None
+        if self._sean_distill():
+            distill = self.netG.get_sean_distill_loss()
+            self.netG.enable_sean_distill_loss(False)
+        if sean and getattr(self.opt, "use_running_stats", False):
+            self.netG.track_running_stats = False
 
         # The reference lets autograd compute (and then discards) the discriminator's weight gradients here; the
         # G optimizer never reads them and optimizers['D'].zero_grad() drops them, so they are skipped.
@@ -208,8 +229,8 @@ class DefectGanModel(BaseModel):
         sd_cyc_loss = [self._cal_loss(df_prob, rec_df_prob, "l1"), self._cal_loss(nm_prob, rec_nm_prob, "l1")]
         sd_con_loss = [self._cal_loss(df_prob, None, "l1"), self._cal_loss(nm_prob, None, "l1"),
                        self._cal_loss(rec_df_prob, None, "l1"), self._cal_loss(rec_nm_prob, None, "l1")]
-        return (self._mean(gan_loss), self._mean(clf_loss), self._mean(rec_loss), self._mean(sd_cyc_loss),
-                self._mean(sd_con_loss))
+        out = (self._mean(gan_loss), self._mean(clf_loss), self._mean(rec_loss), self._mean(sd_cyc_loss), self._mean(sd_con_loss))
+        return out + (distill["latent"], distill["embed"]) if distill is not None else out      # (:238-244; not in the cycle_gan return)
 
     def _compute_discriminator_loss(self, bg_data, df_labels, df_data):
         """defectgan_model.py:251-292"""

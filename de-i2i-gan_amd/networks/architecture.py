@@ -435,15 +435,23 @@ class SEAN(nn.Module):
     latent; with embeddings ``feat`` (N, num_embeds, embed_nc) it is ``mean_e(ReLU(Linear(feat)) + latent)``, rows that come
     out all-zero replaced by the latent (:177-179).  Like AdaIN the modulation does not vary over space, so it runs on the
     SPADE kernels with a constant (N, 5, 5, 2C) table; the Linear layers ((N * num_embeds) x embed_nc x hidden_nc and smaller)
-    go through torch's library GEMM.  The ``mean_<labels>`` / ``std_<labels>`` buffers of every multi-label combination
-    (:104-109) exist for state_dict compatibility; ``--use_running_stats`` (inference from them) and ``--style_distill`` are
-    not implemented.  ``alpha`` is stored by ``set_alpha`` and, as in the reference, read by nothing."""
+    go through torch's library GEMM.
+
+    ``--use_running_stats`` (:104-125,162-176): while ``track_running_stats`` is on (the four generator passes of the G loss) every
+    sample's mixed code is appended to the list of its label combination; ``update_stats`` (once per epoch) writes the lists'
+    per-feature statistics into the ``mean_<labels>`` / ``std_<labels>`` buffers -- the reference stores the STANDARD DEVIATION in
+    ``mean_*`` and the MEAN in ``std_*`` (:124 assigns ``mean[:], std[:] = new_std, new_mean``), and so does this, so that
+    checkpoints interchange -- and ``inference_running_stats`` builds the code from a noise vector and those buffers instead of
+    embeddings.  ``--style_distill`` (:127-143,181-190): while enabled (the G loss) every forward with embeddings takes
+    KL(latent || mix) * 0.1 + KL(enc || mix) at temperature 4 against the detached mixed code and runs ITS OWN backward on the
+    spot (gradients land in mlp_latent / mlp_shared before the main backward adds to them); the two terms are kept for logging.
+    ``alpha`` is stored by ``set_alpha`` and, as in the reference, read by nothing."""
 
     def __init__(self, embed_nc, norm_nc, label_nc, hidden_nc=128, latent_dim=16, norm_layer=None, style_distill=False):
         super().__init__()
-        if style_distill:
-            raise NotImplementedError("SEAN: --style_distill (the distillation losses with their own backward) is not implemented")
-        self.style_distill = False
+        self.style_distill = bool(style_distill)
+        if self.style_distill:
+            self._distill_loss = None
         self.latent_dim, self.label_nc, self.hidden_nc, self.norm_nc = latent_dim, label_nc, hidden_nc, norm_nc
         self.noise_dim = latent_dim - label_nc
         self.alpha = 1.0
@@ -452,15 +460,41 @@ class SEAN(nn.Module):
         self.mlp_gamma = nn.Linear(hidden_nc, norm_nc)
         self.mlp_beta = nn.Linear(hidden_nc, norm_nc)
         self.mlp_latent = nn.Sequential(nn.Linear(label_nc, hidden_nc), nn.ReLU(inplace=True))
+        self.embeds = {}
         for bits in range(1 << label_nc):             # torch.cartesian_prod order: the first label is the slowest digit
             label = [(bits >> (label_nc - 1 - i)) & 1 for i in range(label_nc)]
             self.register_buffer("mean_" + label_to_str(label), torch.zeros(hidden_nc))
             self.register_buffer("std_" + label_to_str(label), torch.zeros(hidden_nc))
+            self.embeds[tuple(label)] = []
         self.inference_running_stats = False
         self.track_running_stats = False
+        self.num_embeds_tracked = 10000
 
     def set_alpha(self, alpha):
         self.alpha = alpha
+
+    def update_stats(self):
+        """normalization.py:111-125 (per epoch): statistics of the tracked codes of every label combination -> its two buffers
+        (swapped, see the class docstring); the lists keep their newest ``num_embeds_tracked`` entries."""
+        eps = 1e-5
+        for label, tracked in self.embeds.items():
+            if tracked:
+                first = getattr(self, "mean_" + label_to_str(label))
+                second = getattr(self, "std_" + label_to_str(label))
+                feat = torch.stack(tracked, dim=0)
+                new_std = (feat.var(dim=0) + eps).sqrt()
+                new_mean = feat.mean(dim=0)
+                first[:], second[:] = new_std, new_mean
+                self.embeds[label] = tracked[-self.num_embeds_tracked:]
+
+    @property
+    def distill_loss(self):
+        return self._distill_loss
+
+    @distill_loss.setter
+    def distill_loss(self, enable):
+        """True: start collecting {'latent': [...], 'embed': [...]}; False: distillation off (normalization.py:131-143)"""
+        self._distill_loss = {"latent": [], "embed": []} if enable else None
 
     def _class_table(self, cond, prec, c_stride):
         labels, feat = cond
@@ -469,15 +503,34 @@ class SEAN(nn.Module):
         latent_code = self.mlp_latent(labels)
         if feat is None:
             mix_feat = latent_code
+        elif self.inference_running_stats:            # feat: one noise vector (hidden_nc,) per sample
+            rows = []
+            for label, noise in zip(labels, feat):
+                key = label_to_str(tuple(int(v.item()) for v in label))
+                rows.append(noise.float() * getattr(self, "std_" + key) * 1.5 + getattr(self, "mean_" + key))
+            mix_feat = torch.stack(rows, dim=0)
         else:
-            if self.inference_running_stats or self.track_running_stats:
-                raise NotImplementedError("SEAN: --use_running_stats is not implemented")
             enc_feat = self.mlp_shared(feat.float())
             mix_feat = enc_feat + latent_code.view(n, 1, -1)
             if mix_feat.dim() == 3:
                 mix_feat = mix_feat.mean(dim=1)
+            if self.track_running_stats:
+                for label, row in zip(labels, mix_feat.clone().detach()):
+                    key = tuple(int(v.item()) for v in label)
+                    if row.dim() == 2:
+                        self.embeds[key].extend(row)
+                    else:
+                        self.embeds[key].append(row)
             mask = (mix_feat == 0).all(dim=1).view(-1, 1)
             mix_feat = mix_feat * ~mask + latent_code * mask
+            if self.style_distill and self._distill_loss is not None:
+                from ..utils.util import calc_kl_with_logits
+                target = mix_feat.detach()
+                latent_term = calc_kl_with_logits(latent_code, target, 4)
+                embed_term = calc_kl_with_logits(enc_feat, target, 4)
+                (latent_term * 0.1 + embed_term).backward(retain_graph=True)
+                self._distill_loss["latent"].append(latent_term)
+                self._distill_loss["embed"].append(embed_term)
         gb = torch.cat([nn.functional.pad(self.mlp_gamma(mix_feat), (0, c_stride - self.norm_nc)),
                         nn.functional.pad(self.mlp_beta(mix_feat), (0, c_stride - self.norm_nc))], dim=1)     # (N, 2 * c_stride)
         return gb.to(prec.dtype).view(n, 1, 1, 2 * c_stride).expand(n, 5, 5, 2 * c_stride).contiguous()

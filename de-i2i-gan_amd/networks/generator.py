@@ -113,12 +113,62 @@ class DefectGanGenerator(BaseNetwork):
         """generator.py:277-284"""
         super().update_per_epoch(epoch)
         alpha = (1 + math.cos(math.pi * epoch / self.opt.num_epochs)) / 2
-        if self.opt.style_norm_block_type == "sean" and self.opt.sean_alpha is None:
-            self.set_sean_alpha(alpha)
+        if self.opt.style_norm_block_type == "sean":
+            if self.opt.sean_alpha is None:
+                self.set_sean_alpha(alpha)
+            if getattr(self.opt, "use_running_stats", False):
+                self.update_stats()
+
+    def _seans(self):
+        from .architecture import SEAN
+        return [m for m in self.modules() if isinstance(m, SEAN)]
 
     def set_sean_alpha(self, alpha):
         """generator.py:286-289"""
-        from .architecture import SEAN
-        for m in self.modules():
-            if isinstance(m, SEAN):
-                m.set_alpha(alpha)
+        for m in self._seans():
+            m.set_alpha(alpha)
+
+    def enable_sean_distill_loss(self, enable_distill_loss):
+        """generator.py:291-294"""
+        for m in self._seans():
+            m.distill_loss = enable_distill_loss
+
+    def get_sean_distill_loss(self):
+        """generator.py:296-306: the terms every SEAN layer collected since distillation was enabled, averaged per kind
+        (an empty list stays an empty list)"""
+        out = {"latent": [], "embed": []}
+        for m in self._seans():
+            if m.distill_loss:
+                for kind in out:
+                    out[kind] += m.distill_loss[kind]
+        for kind in out:
+            if out[kind]:
+                out[kind] = torch.stack(out[kind]).mean()
+        return out
+
+    def update_stats(self):
+        """generator.py:308-311"""
+        for m in self._seans():
+            m.update_stats()
+
+    @property
+    def track_running_stats(self):
+        """generator.py:313-323 (the first SEAN layer's flag; the setter writes all of them)"""
+        for m in self._seans():
+            return m.track_running_stats
+
+    @track_running_stats.setter
+    def track_running_stats(self, value):
+        for m in self._seans():
+            m.track_running_stats = value
+
+    @property
+    def inference_running_stats(self):
+        """generator.py:325-335"""
+        for m in self._seans():
+            return m.inference_running_stats
+
+    @inference_running_stats.setter
+    def inference_running_stats(self, value):
+        for m in self._seans():
+            m.inference_running_stats = value

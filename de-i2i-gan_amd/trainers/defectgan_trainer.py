@@ -21,6 +21,9 @@ class DefectGanTrainer(BaseTrainer):
         self.loss_weights = {"clf_d": opt.loss_weight[0], "clf_g": opt.loss_weight[1], "rec": opt.loss_weight[2],
                              "sd_cyc": opt.loss_weight[3], "sd_con": opt.loss_weight[4]}
         self.loss_types = ["gan", "clf", "aux"]
+        self.distill = opt.style_norm_block_type == "sean" and getattr(opt, "style_distill", False)      # defectgan_trainer.py:29-30
+        if self.distill:
+            self.loss_types.append("distill")
         self._init_losses()
         if opt.phase == "val":
             raise NotImplementedError("phase='val' builds FID/LPIPS metric networks (downloaded weights): out of scope")
@@ -40,7 +43,8 @@ class DefectGanTrainer(BaseTrainer):
         with_e = "E" in self.optimizers                  # adain: the StyleExtractor is trained by the G loss (:140-141,161-163)
         if with_e:
             self.optimizers["E"].zero_grad()
-        gan_loss, clf_loss, rec_loss, sd_cyc_loss, sd_con_loss = self.model("generator", bg_data, df_labels, df_data)
+        losses = self.model("generator", bg_data, df_labels, df_data)
+        gan_loss, clf_loss, rec_loss, sd_cyc_loss, sd_con_loss = losses[:5]
         g_loss = gan_loss + clf_loss * self.loss_weights["clf_g"] + rec_loss * self.loss_weights["rec"] + \
             sd_cyc_loss * self.loss_weights["sd_cyc"] + sd_con_loss * self.loss_weights["sd_con"]
         g_loss.backward()
@@ -55,6 +59,8 @@ class DefectGanTrainer(BaseTrainer):
             self.reducer.broadcast_buffers(self.model.netG)      # BatchNorm running stats follow rank 0
         self._record([("gan", "G"), ("clf", "G"), ("aux", "rec"), ("aux", "cyc"), ("aux", "con")],
                      [gan_loss, clf_loss, rec_loss, sd_cyc_loss, sd_con_loss])
+        if self.distill:                                  # (:142-146) logged; the gradients were taken inside the SEAN layers
+            self._record([("distill", "latent"), ("distill", "embed")], list(losses[5:7]))
 
     def _train_discriminator_once(self, bg_data, df_labels, df_data):
         """defectgan_trainer.py:170-180"""

@@ -26,6 +26,9 @@ class MAETrainer(BaseTrainer):
         assert len(opt.loss_weight) == 3, f"length of loss weights must be 3, not {len(opt.loss_weight)}"
         self.loss_weights = {"rec": opt.loss_weight[0], "clf_D": opt.loss_weight[1], "clf_G": opt.loss_weight[2]}
         self.loss_types = ["rec", "gan", "clf"]
+        self.distill = opt.style_norm_block_type == "sean" and getattr(opt, "style_distill", False)      # mae_trainer.py:20-21
+        if self.distill:
+            self.loss_types.append("distill")
         self._init_losses()
         self.data_types = data_types
         if opt.phase == "val":
@@ -56,12 +59,15 @@ class MAETrainer(BaseTrainer):
     def _train_generator_once(self, data, labels):
         """mae_trainer.py:124-147"""
         self.optimizers["G"].zero_grad()
-        rec_loss, gan_loss, clf_loss = self.model("mae_generator", data, labels)
+        losses = self.model("mae_generator", data, labels)
+        rec_loss, gan_loss, clf_loss = losses[:3]
         g_loss = gan_loss + rec_loss * self.loss_weights["rec"] + clf_loss * self.loss_weights["clf_G"]
         self._scaled_update(g_loss, "G")
         if self.reducer is not None:
             self.reducer.broadcast_buffers(self.model.netG)
         self._record([("rec", "train"), ("gan", "G"), ("clf", "G")], [rec_loss, gan_loss, clf_loss])
+        if self.distill and len(losses) == 5:             # (:125-131) logged only
+            self._record([("distill", "latent"), ("distill", "embed")], list(losses[3:5]))
 
     def _train_discriminator_once(self, data, labels):
         """mae_trainer.py:149-158"""

@@ -52,6 +52,8 @@ class Cfg:
     cycle_gan: bool = False                             # --cycle_gan: G returns (foreground, prob), no cyc / con losses (generator.py:272-273)
     embed_nc: int = 768                                 # sean: width of the style embeddings (defectgan_options.py:65)
     num_embeds: int = 5                                 # sean: embeddings drawn per sample (defectgan_options.py:68)
+    style_distill: bool = False                         # sean --style_distill (normalization.py:181-190; defectgan_model.py:177-197,238-244)
+    use_running_stats: bool = False                     # sean --use_running_stats (normalization.py:111-125,162-176; defectgan_model.py:181-197)
 
 
 # --------------------------------------------------------------------------- #
@@ -195,26 +197,84 @@ def adain(S: Dict[str, Tensor], prefix: str, x: Tensor, style_feat: Tensor) -> T
     return normalized * (1 + gamma) + beta
 
 
+class SeanContext:
+    """The mutable state the reference keeps ON its SEAN modules and toggles from the model (defectgan_model.py:177-197):
+    ``distill`` -- None, or the collector of the distillation terms while --style_distill is enabled for a G loss (every
+    SEAN.forward with embeddings appends its two KL terms and the sum it back-propagates on the spot);
+    ``tracking`` -- --use_running_stats is tracking (the four passes of a G loss): every sample's mixed code is appended to
+    ``embeds[layer prefix][label tuple]`` -- the lists persist across steps, like the modules' (``reset`` empties them);
+    ``inference_running_stats`` -- build the code from a noise vector and the buffers."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.distill: Optional[Dict[str, list]] = None
+        self.tracking = False
+        self.embeds: Dict[str, Dict[tuple, list]] = {}
+        self.inference_running_stats = False
+
+
+SEAN_CTX = SeanContext()
+
+
+def calc_kl_with_logits(p: Tensor, q: Tensor, temperature: float = 4.0) -> Tensor:
+    """utils/util.py:109-119"""
+    return F.kl_div(F.log_softmax(q / temperature, dim=1), F.log_softmax(p / temperature, dim=1), reduction="batchmean",
+                    log_target=True) * temperature * temperature
+
+
 def sean(S: Dict[str, Tensor], prefix: str, x: Tensor, labels: Tensor, feat: Optional[Tensor]) -> Tensor:
-    """SEAN.forward -- normalization.py:139-202 (style_distill off, no running-stats inference): latent code from the labels;
-    without embeddings (feat None: sean_alpha 0) it is the style code, with embeddings (N, num_embeds, embed_nc) the code is
-    the mean over the embeddings of ReLU(Linear(feat)) + latent, all-zero rows replaced by the latent (:177-179)."""
+    """SEAN.forward -- normalization.py:139-202: latent code from the labels; without embeddings (feat None: sean_alpha 0) it
+    is the style code; with ``inference_running_stats`` the code is noise * std_<labels> * 1.5 + mean_<labels> (:162-168, feat =
+    one noise vector per sample); with embeddings (N, num_embeds, embed_nc) the code is the mean over the embeddings of
+    ReLU(Linear(feat)) + latent, tracked per label combination when asked (:169-176), all-zero rows replaced by the latent
+    (:177-179), distilled when asked (:181-190: the terms go to SEAN_CTX.distill; their gradient is added by the caller)."""
     n, c = x.shape[:2]
     normalized = instancenorm(x)
     labels = labels.reshape(n, -1)
     latent = relu(F.linear(labels, S[prefix + ".mlp_latent.0.weight"], S[prefix + ".mlp_latent.0.bias"]))
     if feat is None:
         mix = latent
+    elif SEAN_CTX.inference_running_stats:
+        rows = []
+        for label, noise in zip(labels, feat):
+            key = label_to_str(tuple(int(v.item()) for v in label))
+            rows.append(noise * S[prefix + ".std_" + key] * 1.5 + S[prefix + ".mean_" + key])
+        mix = torch.stack(rows, dim=0)
     else:
         enc = relu(F.linear(feat, S[prefix + ".mlp_shared.0.weight"], S[prefix + ".mlp_shared.0.bias"]))
         mix = enc + latent.view(n, 1, -1)
         if mix.dim() == 3:
             mix = mix.mean(dim=1)
+        if SEAN_CTX.tracking:
+            lists = SEAN_CTX.embeds.setdefault(prefix, {})
+            for label, row in zip(labels, mix.clone().detach()):
+                lists.setdefault(tuple(int(v.item()) for v in label), []).append(row)
         mask = (mix == 0).all(dim=1).view(-1, 1)
         mix = mix * ~mask + latent * mask
+        if SEAN_CTX.distill is not None:
+            target = mix.detach()
+            kl_latent, kl_embed = calc_kl_with_logits(latent, target, 4), calc_kl_with_logits(enc, target, 4)
+            SEAN_CTX.distill["latent"].append(kl_latent)
+            SEAN_CTX.distill["embed"].append(kl_embed)
+            SEAN_CTX.distill["backward"].append(kl_latent * 0.1 + kl_embed)      # what the layer calls .backward() on
     gamma = F.linear(mix, S[prefix + ".mlp_gamma.weight"], S[prefix + ".mlp_gamma.bias"]).view(n, c, 1, 1)
     beta = F.linear(mix, S[prefix + ".mlp_beta.weight"], S[prefix + ".mlp_beta.bias"]).view(n, c, 1, 1)
     return normalized * (1 + gamma) + beta
+
+
+def sean_update_stats(S: Dict[str, Tensor], embeds: Dict[str, Dict[tuple, list]], num_embeds_tracked: int = 10000) -> None:
+    """SEAN.update_stats of every layer (generator.py:308-311, normalization.py:111-125; once per epoch): per label combination
+    with tracked codes, sqrt(var + 1e-5) -> the ``mean_*`` buffer and the mean -> the ``std_*`` buffer (:124 assigns them
+    crosswise -- the buffers' names and contents are swapped in the reference, and checkpoints carry them that way)."""
+    for prefix, lists in embeds.items():
+        for label, rows in lists.items():
+            if rows:
+                feat = torch.stack(rows, dim=0)
+                S[prefix + ".mean_" + label_to_str(label)] = (feat.var(dim=0) + 1e-5).sqrt()
+                S[prefix + ".std_" + label_to_str(label)] = feat.mean(dim=0)
+                lists[label] = rows[-num_embeds_tracked:]
 
 
 def style_norm(S: Dict[str, Tensor], prefix: str, x: Tensor, labels: Tensor, style_feat: Optional[Tensor]) -> Tensor:
@@ -488,10 +548,18 @@ def generator_losses(SG, SD, bg: Tensor, df_labels: Tensor, df: Tensor, cfg: Cfg
     netD.eval(); netG.train() (:83-86) -> BatchNorm uses batch stats, running stats updated 4x."""
     nm_l, df_l = _labels(df_labels)
     nm_f, df_f = _style_feats(SE, bg, df_labels, df, cfg)
-    fake_defects, df_prob = generator_forward(SG, bg, df_l, cfg, training=True, style_feat=df_f)
-    recover_normals, rec_df_prob = generator_forward(SG, fake_defects, nm_l, cfg, training=True, style_feat=nm_f)
-    fake_normals, nm_prob = generator_forward(SG, df, nm_l, cfg, training=True, style_feat=nm_f)
-    recover_defects, rec_nm_prob = generator_forward(SG, fake_normals, df_l, cfg, training=True, style_feat=df_f)
+    distill = cfg.style_norm == "sean" and cfg.style_distill       # defectgan_model.py:177-182,192-197: on for the four passes only
+    if distill:
+        SEAN_CTX.distill = {"latent": [], "embed": [], "backward": []}
+    SEAN_CTX.tracking = cfg.style_norm == "sean" and cfg.use_running_stats
+    try:
+        fake_defects, df_prob = generator_forward(SG, bg, df_l, cfg, training=True, style_feat=df_f)
+        recover_normals, rec_df_prob = generator_forward(SG, fake_defects, nm_l, cfg, training=True, style_feat=nm_f)
+        fake_normals, nm_prob = generator_forward(SG, df, nm_l, cfg, training=True, style_feat=nm_f)
+        recover_defects, rec_nm_prob = generator_forward(SG, fake_normals, df_l, cfg, training=True, style_feat=df_f)
+    finally:
+        collected, SEAN_CTX.distill = SEAN_CTX.distill, None
+        SEAN_CTX.tracking = False
     fd_src, fd_cls = discriminator_forward(SD, diff_augment(fake_defects, cfg.diff_aug), cfg)     # defectgan_model.py:200-205
     fn_src, fn_cls = discriminator_forward(SD, diff_augment(fake_normals, cfg.diff_aug), cfg)
     ones = torch.ones_like(fd_src)
@@ -505,6 +573,9 @@ def generator_losses(SG, SD, bg: Tensor, df_labels: Tensor, df: Tensor, cfg: Cfg
     zero = torch.zeros_like(df_prob)
     con = torch.stack([l1(df_prob, zero, False), l1(nm_prob, zero, False), l1(rec_df_prob, zero, False),
                        l1(rec_nm_prob, zero, False)]).mean()
+    if distill:        # :238-244 -- the two logged means (generator.py:296-306), + the sum the layers back-propagated themselves
+        return (gan, clf, rec, cyc, con, torch.stack(collected["latent"]).mean(), torch.stack(collected["embed"]).mean(),
+                torch.stack(collected["backward"]).sum())
     return gan, clf, rec, cyc, con
 
 
@@ -578,9 +649,15 @@ def train_generator_once(SG, SD, stG: AdamState, bg, df_labels, df, cfg: Cfg, sc
     if trained_e:
         for k in param_keys(SE):
             SE[k].requires_grad_(True)
-    gan, clf, rec, cyc, con = generator_losses(SG, SD, bg, df_labels, df, cfg, SE)
+    out = generator_losses(SG, SD, bg, df_labels, df, cfg, SE)
+    gan, clf, rec, cyc, con = out[:5]
     w = cfg.loss_weight
     g_loss = gan + clf * w[1] + rec * w[2] + cyc * w[3] + con * w[4]
+    if len(out) == 8:
+        # --style_distill: every SEAN layer ran (0.1 KL_latent + KL_embed).backward() inside its forward (normalization.py:186),
+        # un-scaled, into the same .grad fields the main backward then adds to -> the gradient of g_loss * scale + their sum
+        grads = _grads(g_loss * scale + out[7], SG)
+        return tuple(t.detach() for t in (gan, clf, rec, cyc, con, out[5], out[6])), grads
     if trained_e:
         keys_g, keys_e = param_keys(SG), param_keys(SE)
         gs = torch.autograd.grad(g_loss * scale, [SG[k] for k in keys_g] + [SE[k] for k in keys_e], allow_unused=True)
