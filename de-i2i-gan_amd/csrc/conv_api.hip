@@ -489,7 +489,8 @@ int dei2i_conv2d_dgrad_input_norm(const dei2i_conv* c, const void* dy, const voi
                                   dei2i_stream s) {
   if (!dy || !wd_packed || !dx || !en || !dgrad_norm_shape_ok(c)) return DEI2I_ERR_BAD_ARG;
   if (!en->x || !en->mean || !en->rstd || !en->partial || en->up < 0 || en->up > 1) return DEI2I_ERR_BAD_ARG;
-  if (en->kind == 1 ? !en->gb : (en->kind != 2 || !en->a || !en->b || en->up)) return DEI2I_ERR_BAD_ARG;
+  const int kind = en->kind & 0xff;            // (bits 8+: timing-only switches of tools/diag_epin.py)
+  if (kind == 1 ? !en->gb : (kind != 2 || !en->a || !en->b || en->up)) return DEI2I_ERR_BAD_ARG;
   ConvShape sh = to_shape(c);
   sh.pad_mode = PAD_ZERO;
   const GatherDesc interior = make_dgrad_desc(sh, c->CoutS, 0, 0);

@@ -662,7 +662,7 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
   u32x4 gmi = {0u, 0u, 0u, 0u}, bti = {0u, 0u, 0u, 0u};      // kind 1: gamma | beta of the interior class (2, 2), packed
   if constexpr (EPIN) {
     if (ncol < ldc) {
-      if (en.kind == 1) {
+      if ((en.kind & 0xff) == 1) {
         ldcoef<8>(en.mean + (size_t)img * ldc + ncol, nc[0]);
         ldcoef<8>(en.rstd + (size_t)img * ldc + ncol, nc[1]);
         const bf16_t* gp = en.gb + ((size_t)(img * 5 + 2) * 5 + 2) * 2 * ldc + ncol;
@@ -796,7 +796,9 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
           float d8[8], x8[8];
           Elem<bf16_t>::unpack(v, d8);
           Elem<bf16_t>::unpack(xq[p], x8);
-          if (en.kind == 1) {
+          if (en.kind & 0x100) {                         // (timing only, tools/diag_epin.py: no arithmetic -- the loads stay live)
+            ep[0] += x8[0] + d8[0];
+          } else if ((en.kind & 0xff) == 1) {
             const int cy = border_class(py, g.Ho), cx = border_class(px, g.Wo);
             const bool interior = cy == 2 && cx == 2;
             u32x4 gq = gmi, bq2 = bti;                   // the interior class (kept in registers); the frame's pixels fetch theirs
@@ -830,8 +832,8 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
     }
     if constexpr (EPIN) {                                // per-thread partials -> LDS -> ordered sums, 16 values per round
       float* mine = red + ((size_t)rsub * CPR + chunk) * 16;
-      const int nq = en.kind == 1 ? 4 : 2;
-      for (int round = 0; round < nq / 2; ++round) {
+      const int nq = (en.kind & 0xff) == 1 ? 4 : 2;
+      for (int round = 0; round < ((en.kind & 0x200) ? 0 : nq / 2); ++round) {      // (0x200: timing only, no reduction)
         __syncthreads();                                 // (round 0: the write-back's reads of the rows `red` reuses)
 #pragma unroll
         for (int k = 0; k < 16; k += 4) {
@@ -977,7 +979,7 @@ static hipError_t launch_halo16(const GatherDesc& g, const void* src, const void
 // into the border rows / columns -- see the kernel
 hipError_t halo16_conv(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out, int ldc,
                        int act, int num_cu, hipStream_t st, float* stats, const void* ring, bool fold, const EpiNorm* en) {
-  if (en != nullptr && (!fold || (en->kind != 1 && en->kind != 2))) return hipErrorNotSupported;
+  if (en != nullptr && (!fold || ((en->kind & 0xff) != 1 && (en->kind & 0xff) != 2))) return hipErrorNotSupported;
   if (fold && (!g_halo16_fold || g.ys >= 0 || g.xs >= 0 || g.pad_mode != PAD_ZERO || g.up || g.Ho < 2 * H16_TH || g.Wo < 2 * H16_TW ||
                bias != nullptr || act != ACT_NONE || stats != nullptr || ring != nullptr))
     return hipErrorNotSupported;
