@@ -43,3 +43,28 @@ def test_two_rank_rccl_step_through_the_launcher():
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 8 and line["value"] > 0
     assert line["ddp"]["collectives_per_step"] > 2 and line["ddp"]["comm_ms_per_pass"] > 0
     assert all(v == v for v in line["losses_last_step"].values())               # finite (no NaN)
+
+
+@pytest.mark.gpu
+def test_the_one_gpu_bench_line_keeps_the_drivers_contract():
+    """`python bench.py --gpus 1 --steps K --warmup W` -> ONE JSON line on stdout with the keys the driver reads (metric / unit of
+    BASELINE.json, whole-job value, the roofline object of the dominant kernel); the CPU baseline leg is skipped here (it is 10-30 s
+    of oracle time; its own switch)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"], env=env,
+                       timeout=900, stdout=subprocess.PIPE)
+    assert r.returncode == 0
+    out = [ln for ln in r.stdout.decode().strip().splitlines() if ln.startswith("{")]
+    assert len(out) == 1
+    line = json.loads(out[0])
+    base = json.loads((REPO / "BASELINE.json").read_text())
+    assert base["metric"].startswith(line["metric"].replace("256x256", "256×256")) and line["unit"] == "pairs/s"     # BASELINE.json's headline metric
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["warmup"] == 2 and line["higher_is_better"] is True
+    assert line["scaling"] == "weak" and line["vs_baseline"] is None and line["dtype"] == "bf16" and line["data"] == "synthetic"
+    assert abs(line["value"] - line["config"]["global_batch"] / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    assert "workload" in line["config"] and "model" not in line["config"]
+    rf = line["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.2 < rf["frac"] < 1.0
+    assert rf["launches_per_step"] > 0 and rf["event_bracketed_launches"] > 0
+    assert all(v == v for v in line["losses_last_step"].values())
