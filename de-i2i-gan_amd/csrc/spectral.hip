@@ -5,7 +5,7 @@
 //   w_eff = W / sigma
 //   backward (u, v constants):  dW = G / sigma - (sum(G . W) / sigma^2) * u v^T
 // As plain torch ops this is ~14 small launches per conv forward and ~11 per backward (3 000 launches per step with the
-// README recipe options); here it is 5 / 3 launches forward and 2 backward, all reductions in a fixed order
+// README recipe options); here it is 3 / 2 launches forward and 2 backward, all reductions in a fixed order
 // (deterministic).  The in-place (u, v) buffers are updated by the kernels; the vectors sigma was computed with are also
 // written to u_used / v_used, which the backward pass reads (later forwards iterate the buffers again).
 #include <hip/hip_runtime.h>
@@ -62,69 +62,85 @@ __global__ __launch_bounds__(SN_COLS * SN_RG) void sn_wt_u_kernel(const float* _
   }
 }
 
-// out[i] = in[i] / max(sqrt(sum part), eps), written to both destinations; scal[slot] = that norm.  Every workgroup sums
-// the partials itself with the same fixed pattern (strided per thread, then the block tree), so all agree bit for bit.
-__global__ __launch_bounds__(256) void sn_normalize_kernel(const float* __restrict__ in, const float* __restrict__ part, int nparts,
-                                                           int n, float* __restrict__ dst_a, float* __restrict__ dst_b,
-                                                           float* __restrict__ scal, int slot, int write_sigma) {
-  __shared__ float red[4];
+// The two normalisations of the power iteration are scalings, and s = W v is linear in v: with t = W^T u un-normalised,
+//   v = t / max(|t|, eps),   s = W v = (W t) / max(|t|, eps),   u' = s / max(|s|, eps),   sigma = u' . s = |s|^2 / max(|s|, eps)
+// so no pass has to wait for a normalised vector to exist: the W t pass applies 1 / max(|t|, eps) to its row sums (every
+// workgroup sums the |t|^2 partials itself, same fixed pattern, bit-identical across workgroups) and writes its slice of v; the
+// scale pass sums the |s|^2 partials the same way, writes its slice of u', and divides W by sigma.  3 launches instead of 5.
+DEI2I_D float sn_sum_parts(const float* __restrict__ part, int nparts, float* red) {
   float p = 0.f;
   for (int i = threadIdx.x; i < nparts; i += 256) p += part[i];
-  const float tot = sn_block_sum(p, red);
-  const float norm = sqrtf(tot);
-  const float inv = 1.f / fmaxf(norm, SN_EPS);
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const float v = in[i] * inv;
-    dst_a[i] = v;
-    dst_b[i] = v;
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    scal[slot] = norm;
-    if (write_sigma) scal[2] = tot * inv;                  // sigma = u . s with u = s / max(|s|, eps)
-  }
+  return sn_block_sum(p, red);
 }
 
-// s[r] = sum_k W[r][k] v[k]  (one workgroup per row); part[r] = s[r]^2 (training) or u[r] * s[r] (eval: sigma partials)
-__global__ __launch_bounds__(256) void sn_w_v_kernel(const float* __restrict__ W, const float* __restrict__ v, const float* __restrict__ u,
-                                                     int K, float* __restrict__ s, float* __restrict__ part, int eval_mode) {
+// s[r] = inv * sum_k W[r][k] x[k]  (one workgroup per row), inv = 1 / max(sqrt(sum tpart), eps) when tpart != nullptr (training:
+// x = t un-normalised; the workgroup also writes its slice of v = x * inv to v and v_used, and workgroup 0 scal[0] = |t|), else 1
+// (eval: x = the stored v).  part[r] = s[r]^2 (training) or u[r] * s[r] (eval: sigma partials).
+__global__ __launch_bounds__(256) void sn_w_v_kernel(const float* __restrict__ W, const float* __restrict__ x, const float* __restrict__ u,
+                                                     int Cout, int K, const float* __restrict__ tpart, int ntparts,
+                                                     float* __restrict__ v, float* __restrict__ v_used, float* __restrict__ scal,
+                                                     float* __restrict__ s, float* __restrict__ part) {
   __shared__ float red[4];
   const int r = blockIdx.x;
+  float inv = 1.f;
+  if (tpart != nullptr) {
+    const float norm = sqrtf(sn_sum_parts(tpart, ntparts, red));
+    inv = 1.f / fmaxf(norm, SN_EPS);
+    const int per = (K + Cout - 1) / Cout;                               // this workgroup's slice of v
+    for (int k = r * per + threadIdx.x; k < min(K, (r + 1) * per); k += 256) {
+      const float vk = x[k] * inv;
+      v[k] = vk;
+      v_used[k] = vk;
+    }
+    if (r == 0 && threadIdx.x == 0) scal[0] = norm;
+    __syncthreads();
+  }
   const float* row = W + (size_t)r * K;
   float a0 = 0.f, a1 = 0.f;
   int k = threadIdx.x;
   for (; k + 256 < K; k += 512) {
-    a0 = fmaf(row[k], v[k], a0);
-    a1 = fmaf(row[k + 256], v[k + 256], a1);
+    a0 = fmaf(row[k], x[k], a0);
+    a1 = fmaf(row[k + 256], x[k + 256], a1);
   }
-  if (k < K) a0 = fmaf(row[k], v[k], a0);
-  const float sr = sn_block_sum(a0 + a1, red);
+  if (k < K) a0 = fmaf(row[k], x[k], a0);
+  const float sr = sn_block_sum(a0 + a1, red) * inv;
   if (threadIdx.x == 0) {
     s[r] = sr;
-    part[r] = eval_mode ? u[r] * sr : sr * sr;
+    part[r] = tpart != nullptr ? sr * sr : u[r] * sr;
   }
 }
 
-// eval mode: scal[2] = sigma = sum part; also copy the stored vectors into u_used / v_used
-__global__ __launch_bounds__(256) void sn_eval_sigma_kernel(const float* __restrict__ part, int Cout, const float* __restrict__ u,
-                                                            const float* __restrict__ v, int K, float* __restrict__ u_used,
-                                                            float* __restrict__ v_used, float* __restrict__ scal) {
+// out = W / sigma, sigma from the Cout partials of the pass before (every workgroup sums them itself):
+//   training: tot = sum s^2, sigma = tot / max(sqrt(tot), eps); the workgroup writes its slice of u = s / max(|s|, eps) to u and u_used
+//   eval    : sigma = sum u[r] s[r]; the workgroup copies its slices of the stored u, v to u_used, v_used
+// scal[1] = |s| (training), scal[2] = sigma.  n4 = n / 4 float4 groups, then the (< 4) tail elements.
+__global__ __launch_bounds__(256) void sn_scale_kernel(const float* __restrict__ W, const float* __restrict__ spart, const float* __restrict__ sv,
+                                                       int Cout, int K, int training, float* __restrict__ u, const float* __restrict__ v,
+                                                       float* __restrict__ u_used, float* __restrict__ v_used, float* __restrict__ scal,
+                                                       size_t n, float* __restrict__ out) {
   __shared__ float red[4];
-  if (blockIdx.x == 0) {
-    float p = 0.f;
-    for (int i = threadIdx.x; i < Cout; i += 256) p += part[i];
-    const float tot = sn_block_sum(p, red);
-    if (threadIdx.x == 0) scal[2] = tot;
+  const float tot = sn_sum_parts(spart, Cout, red);
+  float sigma = tot;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  if (training) {
+    const float norm = sqrtf(tot);
+    const float inv_s = 1.f / fmaxf(norm, SN_EPS);
+    sigma = tot * inv_s;                                                 // u . s with u = s / max(|s|, eps)
+    for (size_t i = tid; i < (size_t)Cout; i += stride) {
+      const float ur = sv[i] * inv_s;
+      u[i] = ur;
+      u_used[i] = ur;
+    }
+    if (tid == 0) scal[1] = norm;
+  } else {
+    for (size_t i = tid; i < (size_t)(Cout + K); i += stride) {
+      if (i < (size_t)Cout) u_used[i] = u[i];
+      else v_used[i - Cout] = v[i - Cout];
+    }
   }
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Cout + K; i += gridDim.x * blockDim.x) {
-    if (i < Cout) u_used[i] = u[i];
-    else v_used[i - Cout] = v[i - Cout];
-  }
-}
-
-// out = W / sigma.  n4 = n / 4 float4 groups, then the (< 4) tail elements.
-__global__ void sn_scale_kernel(const float* __restrict__ W, const float* __restrict__ scal, size_t n, float* __restrict__ out) {
-  const float inv = 1.f / scal[2];
-  const size_t n4 = n >> 2, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  if (tid == 0) scal[2] = sigma;
+  const float inv = 1.f / sigma;
+  const size_t n4 = n >> 2;
   for (size_t i = tid; i < n4; i += stride) {
     float4 w = reinterpret_cast<const float4*>(W)[i];
     w.x *= inv; w.y *= inv; w.z *= inv; w.w *= inv;
@@ -208,20 +224,17 @@ int dei2i_spectral_fwd(int Cout, int K, const float* W, float* u, float* v, int 
   float* sv = scratch + K;               // Cout
   float* part_t = sv + Cout;             // cb
   float* part_s = part_t + cb;           // Cout
+  const size_t n = (size_t)Cout * K;
   if (iterate) {
     hipLaunchKernelGGL(sn_wt_u_kernel, dim3(cb), dim3(SN_COLS * SN_RG), 0, st, W, (const float*)u, Cout, K, t, part_t);
-    hipLaunchKernelGGL(sn_normalize_kernel, dim3((K + 255) / 256 > 64 ? 64 : (K + 255) / 256), dim3(256), 0, st, (const float*)t,
-                       (const float*)part_t, cb, K, v, v_used, scal, 0, 0);
-    hipLaunchKernelGGL(sn_w_v_kernel, dim3(Cout), dim3(256), 0, st, W, (const float*)v_used, (const float*)u, K, sv, part_s, 0);
-    hipLaunchKernelGGL(sn_normalize_kernel, dim3((Cout + 255) / 256 > 64 ? 64 : (Cout + 255) / 256), dim3(256), 0, st,
-                       (const float*)sv, (const float*)part_s, Cout, Cout, u, u_used, scal, 1, 1);
+    hipLaunchKernelGGL(sn_w_v_kernel, dim3(Cout), dim3(256), 0, st, W, (const float*)t, (const float*)u, Cout, K, (const float*)part_t, cb,
+                       v, v_used, scal, sv, part_s);
   } else {
-    hipLaunchKernelGGL(sn_w_v_kernel, dim3(Cout), dim3(256), 0, st, W, (const float*)v, (const float*)u, K, sv, part_s, 1);
-    hipLaunchKernelGGL(sn_eval_sigma_kernel, dim3(((Cout + K + 255) / 256) > 64 ? 64 : (Cout + K + 255) / 256), dim3(256), 0, st,
-                       (const float*)part_s, Cout, (const float*)u, (const float*)v, K, u_used, v_used, scal);
+    hipLaunchKernelGGL(sn_w_v_kernel, dim3(Cout), dim3(256), 0, st, W, (const float*)v, (const float*)u, Cout, K, (const float*)nullptr, 0,
+                       (float*)nullptr, (float*)nullptr, scal, sv, part_s);
   }
-  const size_t n = (size_t)Cout * K;
-  hipLaunchKernelGGL(sn_scale_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, st, W, (const float*)scal, n, w_eff);
+  hipLaunchKernelGGL(sn_scale_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, st, W, (const float*)part_s, (const float*)sv, Cout, K,
+                     iterate ? 1 : 0, u, (const float*)v, u_used, v_used, scal, n, w_eff);
   return (int)hipGetLastError();
 }
 
