@@ -319,15 +319,16 @@ class SPADE(nn.Module):
         n, hs, ws, c = x.shape
         h, w = (2 * hs, 2 * ws) if up else (hs, ws)
         class_mode = segmap.shape[2] == 1 and segmap.shape[3] == 1 and h >= 4 and w >= 4
-        if class_mode and type(conv) is Conv2d and conv.bias is None:     # (spectral convs derive their weight per call: unfused)
-            wt, geom = conv.weight, conv.geom(up)
-            params_grad = wt.requires_grad or self.mlp_gamma.weight.requires_grad
+        if class_mode and isinstance(conv, Conv2d) and conv.bias is None:
+            geom = conv.geom(up)
+            params_grad = any(p.requires_grad for p in conv.parameters()) or self.mlp_gamma.weight.requires_grad
             need_grad = torch.is_grad_enabled() and (x.requires_grad or params_grad)
-            mode = ops.spade_conv_supported(x, wt, geom, need_grad)
+            mode = ops.spade_conv_supported(x, None, geom, need_grad)
             if mode is not None:
                 self._ran_class_mode = True
                 gb = self._class_table(segmap, prec, h, w)
-                return ops.spade_conv(x, gb, wt, conv._packed, geom, skip=skip, stats=stats, mode=mode)
+                wt, sources = conv.effective_weight()         # (a spectral conv iterates u, v here: once per forward, like conv(...))
+                return ops.spade_conv(x, gb, wt, conv._packed, geom, skip=skip, stats=stats, mode=mode, sources=sources)
         if skip:
             z, xs = self(x, segmap, up=up, skip=True)
             return conv(z, stats=stats), xs
@@ -409,12 +410,13 @@ class AdaIN(nn.Module):
         """conv(self(x, style_feat, up)) -- with skip: (that, x) -- see SPADE.fused_conv"""
         prec = ops.precision_of(x)
         gb = self._class_table(style_feat, prec, x.shape[-1])
-        if type(conv) is Conv2d and conv.bias is None:
-            wt, geom = conv.weight, conv.geom(up)
-            need_grad = torch.is_grad_enabled() and (x.requires_grad or wt.requires_grad or gb.requires_grad)
-            mode = ops.spade_conv_supported(x, wt, geom, need_grad)
+        if isinstance(conv, Conv2d) and conv.bias is None:
+            geom = conv.geom(up)
+            need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in conv.parameters()) or gb.requires_grad)
+            mode = ops.spade_conv_supported(x, None, geom, need_grad)
             if mode is not None:
-                return ops.spade_conv(x, gb, wt, conv._packed, geom, skip=skip, stats=stats, mode=mode)
+                wt, sources = conv.effective_weight()
+                return ops.spade_conv(x, gb, wt, conv._packed, geom, skip=skip, stats=stats, mode=mode, sources=sources)
         if skip:
             z, xs = ops.spade_relu(x, gb, up, 1, skip=True)
             return conv(z, stats=stats), xs

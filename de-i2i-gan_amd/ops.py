@@ -1100,7 +1100,10 @@ class _SpadeConv(torch.autograd.Function):
                                      _p(coefs[0]), _p(coefs[1]), _p(coefs[2]), _p(coefs[3]), _p(ring), st), "spade_prep")
         couts = prec.pad(geom.cout)
         d = _desc(prec, geom, n, hs, ws, c, couts)
-        wf = cache.get(weight, sources, prec, geom, c, couts, need_dgrad=any(s_.requires_grad for s_ in sources))[0]
+        per_call = bool(getattr(weight, "_dei2i_per_call", False))
+        if per_call:                                      # spectral norm in training mode: the packed copies travel with the call (see _Conv2d)
+            cache = PackedWeights()
+        wf = cache.get(weight, sources, prec, geom, c, couts, need_dgrad=any(s_.requires_grad for s_ in sources), per_call=per_call)[0]
         y = torch.empty((n, h, w, couts), dtype=prec.dtype, device=dev)
         out_partial = None
         if want_stats:
@@ -1118,7 +1121,7 @@ class _SpadeConv(torch.autograd.Function):
             pro = L.ProDesc(coefs[2].data_ptr(), coefs[3].data_ptr(), c, 0.0, ring.data_ptr())
             L.check(lib.dei2i_conv2d_fwd_fused(byref(d), _p(x), _p(wf), None, L.ACT_NONE, _p(y), byref(pro), _p(out_partial), st),
                     "conv2d_fwd_fused(spade)")
-        ctx.prec, ctx.up, ctx.geom, ctx.cache, ctx.sources, ctx.ring_mode = prec, up, geom, cache, sources, ring_mode
+        ctx.prec, ctx.up, ctx.geom, ctx.cache, ctx.sources, ctx.ring_mode, ctx.per_call = prec, up, geom, cache, sources, ring_mode, per_call
         ctx.out_shape = (n, h, w, c)
         ctx.save_for_backward(x, gb, coefs, ring, weight, z_src)
         return (y, x_in) if skip else y
@@ -1149,8 +1152,8 @@ class _SpadeConv(torch.autograd.Function):
             # 2x2 cells itself, and needs the per-logical-pixel mask and class)
             g_log = ConvGeom(geom.cin, geom.cout, geom.k, geom.stride, geom.pad, geom.reflect, False)
             hint = _NormBwdHint(1, x, coefs[0], coefs[1], gb=gb, up=up)
-            dz = _conv_dgrad(lib, prec, g_log, (n, h, w, c), dy.shape[-1], dy, weight, ctx.cache, ctx.sources, False, x.dtype, x.device,
-                             hint=hint)
+            dz = _conv_dgrad(lib, prec, g_log, (n, h, w, c), dy.shape[-1], dy, weight, ctx.cache, ctx.sources, ctx.per_call, x.dtype,
+                             x.device, hint=hint)
             dx, dgb = _spade_backward(lib, prec, dz, dskip, x, gb, coefs[0], coefs[1], up, 1, ctx.out_shape, hint=hint)
         elif dskip is not None:
             dx = dskip
@@ -1161,8 +1164,6 @@ def spade_conv_supported(x, weight, geom: ConvGeom, need_grad: bool):
     """How can conv(relu(SPADE(up(x)))) run fused?  -> "pro" (the norm on the conv's operand path: fuse_pro), "ring" (upsampling
     blocks: z at the source resolution + the frame's ring tensor: fuse_ring) or None.  ``geom`` carries the upsample flag."""
     if not (fuse_norm and x.is_cuda and x.dtype == torch.bfloat16 and not _fp8_forward):
-        return None
-    if getattr(weight, "_dei2i_per_call", False):
         return None
     lib = _lib_for(x)
     n, hs, ws, c = x.shape
