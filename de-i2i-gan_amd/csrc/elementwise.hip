@@ -254,6 +254,57 @@ __global__ void cast_from_f32_kernel(const float* __restrict__ src, T* __restric
     Elem<T>::store(dst + i, src[i]);
 }
 
+// nn.AvgPool2d(2, 2) on NHWC (the down-scaling ResBlocks of the conv StyleExtractor, architecture.py:157-168): fp32 sum of the 2x2
+// cell, one rounding; backward spreads dout / 4 over the cell
+template <typename T>
+__global__ void avgpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, int N, int Ho, int Wo, int C) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cv = C / VEC;
+  const size_t total = (size_t)N * Ho * Wo * cv;
+  const size_t row = (size_t)2 * Wo * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) * VEC;
+    size_t r = i / cv;
+    const int w = (int)(r % Wo); r /= Wo;
+    const int h = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    const T* p = x + ((size_t)n * 2 * Ho + 2 * h) * row + (size_t)2 * w * C + c;
+    float a[VEC], b[VEC], cc[VEC], d[VEC];
+    Elem<T>::unpack(*reinterpret_cast<const u32x4*>(p), a);
+    Elem<T>::unpack(*reinterpret_cast<const u32x4*>(p + C), b);
+    Elem<T>::unpack(*reinterpret_cast<const u32x4*>(p + row), cc);
+    Elem<T>::unpack(*reinterpret_cast<const u32x4*>(p + row + C), d);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) a[e] = ((a[e] + b[e]) + (cc[e] + d[e])) * 0.25f;
+    *reinterpret_cast<u32x4*>(out + i * VEC) = Elem<T>::pack(a);
+  }
+}
+
+template <typename T>
+__global__ void avgpool2_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dx, int N, int Ho, int Wo, int C) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cv = C / VEC;
+  const size_t total = (size_t)N * Ho * Wo * cv;
+  const size_t row = (size_t)2 * Wo * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) * VEC;
+    size_t r = i / cv;
+    const int w = (int)(r % Wo); r /= Wo;
+    const int h = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    float g[VEC];
+    Elem<T>::unpack(*reinterpret_cast<const u32x4*>(dout + i * VEC), g);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) g[e] *= 0.25f;
+    const u32x4 q = Elem<T>::pack(g);
+    T* p = dx + ((size_t)n * 2 * Ho + 2 * h) * row + (size_t)2 * w * C + c;
+    *reinterpret_cast<u32x4*>(p) = q;
+    *reinterpret_cast<u32x4*>(p + C) = q;
+    *reinterpret_cast<u32x4*>(p + row) = q;
+    *reinterpret_cast<u32x4*>(p + row + C) = q;
+  }
+}
+
 }  // namespace dei2i
 
 using namespace dei2i;
@@ -417,6 +468,33 @@ int dei2i_cast_from_f32(int dtype, size_t n, const float* src, void* dst, dei2i_
   else
     hipLaunchKernelGGL(cast_from_f32_kernel<float>, dim3(grid_for(n, 256, EW_CAP)), dim3(256), 0, (hipStream_t)s, src,
                        (float*)dst, n);
+  return (int)hipGetLastError();
+}
+
+/* nn.AvgPool2d(2, 2) on an NHWC tensor of (N, H, W, C), H and W even; out / dout: (N, H/2, W/2, C) */
+int dei2i_avgpool2_fwd(int dtype, int N, int H, int W, int C, const void* x, void* out, dei2i_stream s) {
+  const int vec = vec_of(dtype);
+  if (N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || C % vec || !x || !out) return DEI2I_ERR_BAD_ARG;
+  const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / vec);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(avgpool2_fwd_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (bf16_t*)out,
+                       N, H / 2, W / 2, C);
+  else
+    hipLaunchKernelGGL(avgpool2_fwd_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)s, (const float*)x, (float*)out, N,
+                       H / 2, W / 2, C);
+  return (int)hipGetLastError();
+}
+
+int dei2i_avgpool2_bwd(int dtype, int N, int H, int W, int C, const void* dout, void* dx, dei2i_stream s) {
+  const int vec = vec_of(dtype);
+  if (N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || C % vec || !dout || !dx) return DEI2I_ERR_BAD_ARG;
+  const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / vec);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(avgpool2_bwd_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)dout, (bf16_t*)dx,
+                       N, H / 2, W / 2, C);
+  else
+    hipLaunchKernelGGL(avgpool2_bwd_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)s, (const float*)dout, (float*)dx, N,
+                       H / 2, W / 2, C);
   return (int)hipGetLastError();
 }
 

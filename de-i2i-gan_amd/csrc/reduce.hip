@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void spade_bwd_partial_kernel(const T* __restr
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const T* __restrict__ gb, int gb_mode,
                                                                 T* __restrict__ dgb_dense, float* __restrict__ partial, int H,
-                                                                int W, int C, int up, int chunks) {
+                                                                int W, int C, int up, int chunks, float slope = 0.f) {
   constexpr int VEC = Elem<T>::VEC;
   extern __shared__ float smem[];
   const int cv = C / VEC, rpp = 256 / cv;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void spade_bwd_partial_kernel(const T* __restr
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         const float xh = (xv[e] - mv[e]) * rv[e];
-        const float g = fmaf(xh, 1.f + gm[e], bt[e]) > 0.f ? d[e] : 0.f;
+        const float g = fmaf(xh, 1.f + gm[e], bt[e]) > 0.f ? d[e] : slope * d[e];      // (slope: 0 = ReLU -- SPADE; dei2i_in_act_bwd: any)
         const float dxh = g * (1.f + gm[e]);
         dg[e] = g * xh;
         db[e] = g;
@@ -443,7 +443,7 @@ template <typename T>
 __global__ void spade_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ x, const float* __restrict__ mean,
                                        const float* __restrict__ rstd, const T* __restrict__ gb, int gb_mode,
                                        const float* __restrict__ coef, const T* __restrict__ addend, T* __restrict__ dx, int N,
-                                       int H, int W, int C, int up) {
+                                       int H, int W, int C, int up, float slope = 0.f) {
   constexpr int VEC = Elem<T>::VEC;
   const int cv = C / VEC;
   const int Hs = H >> up, Ws = W >> up;
@@ -472,7 +472,7 @@ __global__ void spade_bwd_apply_kernel(const T* __restrict__ dz, const T* __rest
         Elem<T>::unpack(*reinterpret_cast<const u32x4*>(gb + gpix * 2 * C + C + c), bt);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-          const float g = fmaf(xh[e], 1.f + gm[e], bt[e]) > 0.f ? d[e] : 0.f;
+          const float g = fmaf(xh[e], 1.f + gm[e], bt[e]) > 0.f ? d[e] : slope * d[e];
           acc[e] = fmaf(g, 1.f + gm[e], acc[e]);
         }
       }
@@ -996,6 +996,35 @@ int dei2i_spade_bwd_apply(int dtype, int N, int H, int W, int C, int up, const v
   else
     hipLaunchKernelGGL(spade_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dz, (const float*)x, mean,
                        rstd, (const float*)gb, gb_mode, (const float*)coef, (const float*)addend, (float*)dx, N, H, W, C, up);
+  return (int)hipGetLastError();
+}
+
+/* Backward of z = act(IN(x)), IN = InstanceNorm2d(affine=False), act of the ReLU family with negative slope `slope` (0.2:
+ * LeakyReLU, 1: no activation) -- the SPADE backward kernels with gamma = beta = 0: `zero_table` is an all-zero (N,5,5,2C) table
+ * in the compute dtype.  partial: (N, dei2i_moments_chunks(H*W), 4, C) floats, coef: (N, 2, C) floats (scratch). */
+int dei2i_in_act_bwd(int dtype, int N, int H, int W, int C, const void* dz, const void* x, const float* mean, const float* rstd,
+                     float slope, const void* zero_table, float* partial, float* coef, const void* addend, void* dx, dei2i_stream s) {
+  const int vec = dtype == DT_BF16 ? 8 : 4;
+  if (N <= 0 || H < 4 || W < 4 || !cv_ok(dtype, C) || !dz || !x || !mean || !rstd || !zero_table || !partial || !coef || !dx)
+    return DEI2I_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)s;
+  const int chunks = dei2i_moments_chunks(H * W);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(spade_bwd_partial_kernel<bf16_t>, dim3(chunks, N), dim3(256), combine_lds(dtype, 4), st, (const bf16_t*)dz,
+                       (const bf16_t*)x, mean, rstd, (const bf16_t*)zero_table, 1, (bf16_t*)nullptr, partial, H, W, C, 0, chunks, slope);
+  else
+    hipLaunchKernelGGL(spade_bwd_partial_kernel<float>, dim3(chunks, N), dim3(256), combine_lds(dtype, 4), st, (const float*)dz,
+                       (const float*)x, mean, rstd, (const float*)zero_table, 1, (float*)nullptr, partial, H, W, C, 0, chunks, slope);
+  hipLaunchKernelGGL(spade_bwd_finalize_kernel, dim3(C, N), dim3(combine_threads(chunks)), 0, st, (const float*)partial, N, chunks, C,
+                     (double)H * (double)W, coef, (void*)nullptr, dtype);
+  const size_t total = (size_t)N * H * W * (C / vec);
+  const unsigned grid = grid_for(total, 256, 256u * 16u);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(spade_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)x, mean, rstd,
+                       (const bf16_t*)zero_table, 1, (const float*)coef, (const bf16_t*)addend, (bf16_t*)dx, N, H, W, C, 0, slope);
+  else
+    hipLaunchKernelGGL(spade_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dz, (const float*)x, mean, rstd,
+                       (const float*)zero_table, 1, (const float*)coef, (const float*)addend, (float*)dx, N, H, W, C, 0, slope);
   return (int)hipGetLastError();
 }
 

@@ -187,6 +187,10 @@ def _is_batchnorm(norm_layer):
     return norm_layer is BatchNorm2d or norm_layer is nn.BatchNorm2d
 
 
+def _is_instancenorm(norm_layer):
+    return norm_layer is nn.InstanceNorm2d or norm_layer == "instance"
+
+
 class NoiseInjection(nn.Module):
     """x + weight * noise with one N(0,1) value per pixel, shared by the channels (architecture.py:374-389, the
     'constant' weight type the blocks use).  Works on the NHWC activations: the noise is drawn as (N,1,H,W) like the
@@ -214,16 +218,20 @@ def _reject(use_spectral=False, add_noise=False):
 
 
 class ConvBlock(nn.Module):
-    """conv -> [BatchNorm2d] -> [act]  (architecture.py:79-118)"""
+    """conv -> [BatchNorm2d | InstanceNorm2d(affine=False)] -> [act]  (architecture.py:79-118; the InstanceNorm form is the conv
+    StyleExtractor's, extractor.py:50-80: no parameters, per-(n, c) statistics, ops.instance_norm_act)"""
 
     def __init__(self, f_in, f_out, kernel_size=(3, 3), stride=(1, 1), padding=0, padding_mode="zeros", bias=False,
                  norm_layer=None, act_layer=None, use_spectral=False):
         super().__init__()
         blocks = [make_conv(use_spectral, f_in, f_out, kernel_size, stride, padding, padding_mode, bias)]
-        self._has_norm = norm_layer is not None
+        self._instance_norm = _is_instancenorm(norm_layer)
+        self._has_norm = norm_layer is not None and not self._instance_norm
+        if self._instance_norm:
+            blocks.append(Act("instance_norm(affine=False)"))
         if self._has_norm:
             if not _is_batchnorm(norm_layer):
-                raise NotImplementedError("ConvBlock: only BatchNorm2d is used by the reference hot path")
+                raise NotImplementedError("ConvBlock: BatchNorm2d and InstanceNorm2d are the norms the reference uses here")
             blocks.append(BatchNorm2d(f_out))
         if act_layer not in (None, "leaky_relu", "relu"):
             raise NotImplementedError(f"ConvBlock activation [{act_layer}] is not fused")
@@ -232,6 +240,9 @@ class ConvBlock(nn.Module):
         self.conv_block = nn.Sequential(*blocks)
 
     def forward(self, x, seg=None, res=None, out_stats=False):
+        if self._instance_norm:
+            assert res is None
+            return ops.instance_norm_act(self.conv_block[0](x, stats=True), self._act)
         if self._has_norm:
             y = self.conv_block[0](x, stats=True)
             return self.conv_block[1](y, self._act, res, stats=out_stats)
@@ -259,20 +270,27 @@ class DeConvBlock(nn.Module):
 
 
 class ResBlock(nn.Module):
-    """x + BN(conv(LReLU(BN(conv(x)))))  (architecture.py:121-176, down_scale=False)"""
+    """x + BN(conv(LReLU(BN(conv(x)))))  (architecture.py:121-176); ``down_scale=True`` (the conv StyleExtractor's blocks,
+    :157-168): ConvBlock -> AvgPool2d(2, 2) -> ConvBlock, plus the shortcut AvgPool2d(ConvBlock 1x1 (x)) -- same child indices
+    (res_block.0 / .2, conv_s.0) as the reference's Sequentials."""
 
     def __init__(self, f_in, f_out, kernel_size=(3, 3), stride=(1, 1), padding=0, padding_mode="zeros", bias=False,
                  norm_layer=BatchNorm2d, act_layer="relu", use_spectral=False, down_scale=False):
         super().__init__()
-        if down_scale:
-            raise NotImplementedError("ResBlock(down_scale=True) is not on the reference hot path")
-        self.down_scale = False
-        self.res_block = nn.Sequential(
-            ConvBlock(f_in, f_in, kernel_size, stride, padding, padding_mode, bias, norm_layer, act_layer, use_spectral),
-            ConvBlock(f_in, f_out, kernel_size, stride, padding, padding_mode, bias, norm_layer, None, use_spectral))
+        self.down_scale = bool(down_scale)
+        blocks = [ConvBlock(f_in, f_in, kernel_size, stride, padding, padding_mode, bias, norm_layer, act_layer, use_spectral),
+                  ConvBlock(f_in, f_out, kernel_size, stride, padding, padding_mode, bias, norm_layer, None, use_spectral)]
+        if self.down_scale:
+            blocks.insert(1, Act("avg_pool 2x2"))
+            self.conv_s = nn.Sequential(ConvBlock(f_in, f_out, (1, 1), (1, 1), 0, padding_mode, False, norm_layer, None, use_spectral),
+                                        Act("avg_pool 2x2"))
+        self.res_block = nn.Sequential(*blocks)
 
     def forward(self, x, seg=None, out_stats=False):
         """``out_stats``: a norm layer (the decoder's first SPADE) reads the block's output next."""
+        if self.down_scale:
+            h = self.res_block[2](ops.avgpool2(self.res_block[0](x)))
+            return ops.add(h, ops.avgpool2(self.conv_s[0](x)), stats=out_stats)
         first, second = self.res_block[0], self.res_block[1]
         if first._has_norm and second._has_norm:
             # conv -> [BN + LeakyReLU on the second conv's operand path] -> conv -> BN + identity add (one kernel)

@@ -1189,6 +1189,111 @@ def spade_conv(x, gb, weight, cache, geom: ConvGeom, eps: float = 1e-5, skip: bo
 
 
 # --------------------------------------------------------------------------------------------------------------
+# InstanceNorm2d(affine=False) + activation, AvgPool2d(2, 2): the blocks of the conv StyleExtractor (extractor.py:50-80)
+# --------------------------------------------------------------------------------------------------------------
+_zero_tables = {}
+
+
+def _zero_table(device, dtype, n, c):
+    key = (torch.device(device), dtype, n, c)
+    t = _zero_tables.get(key)
+    if t is None:
+        if len(_zero_tables) > 16:
+            _zero_tables.clear()
+        t = _zero_tables[key] = torch.zeros((n, 5, 5, 2 * c), dtype=dtype, device=device)
+    return t
+
+
+class _InstanceNormAct(torch.autograd.Function):
+    """z = act(InstanceNorm2d(x)), affine=False, eps 1e-5 (architecture.py:79-118 with norm_layer=nn.InstanceNorm2d): per-(n, c)
+    statistics (the producer's records when it left any), then one affine + activation pass with per-image coefficients
+    A = rstd, B = -mean * rstd.  ``slope``: 0.2 LeakyReLU, 0 ReLU, 1 none.  Backward: the SPADE backward kernels with
+    gamma = beta = 0 (dei2i_in_act_bwd); ``res`` (optional) is added to the output and its gradient passed through."""
+
+    @staticmethod
+    def forward(ctx, x, slope: float, res, eps: float):
+        _require_gpu(x, "instance_norm_act")
+        prec = precision_of(x)
+        x = x.contiguous()
+        n, h, w, c = x.shape
+        lib = _lib_for(x)
+        st = _stream()
+        dev = x.device
+        mean = torch.empty((n, c), dtype=torch.float32, device=dev)
+        rstd = torch.empty((n, c), dtype=torch.float32, device=dev)
+        have = _stats_of(x, n, h * w, c) if fuse_norm else None
+        if have is not None:
+            partial, chunks = have
+        else:
+            chunks = lib.dei2i_moments_chunks(h * w)
+            partial = torch.empty((n, chunks, 2, c), dtype=torch.float32, device=dev)
+            L.check(lib.dei2i_moments_partial(prec.code, n, h * w, c, _p(x), _p(partial), st), "moments_partial")
+        L.check(lib.dei2i_in_finalize_chunks(n, h * w, c, chunks, _p(partial), eps, _p(mean), _p(rstd), st), "in_finalize")
+        a, b = rstd, -mean * rstd
+        out = torch.empty_like(x)
+        cv = c // (8 if prec is BF16 else 4)
+        if 256 % cv == 0 or cv % 256 == 0:                # (the per-image kernel keeps one channel vector per thread)
+            L.check(lib.dei2i_affine_act_img_fwd(prec.code, n, h * w, c, _p(x), _p(a), _p(b), slope, _p(out), st), "affine_act_img")
+        else:                                             # odd channel counts: the per-channel kernel, image by image
+            act = {1.0: L.ACT_NONE, 0.0: L.ACT_RELU, 0.2: L.ACT_LRELU}[slope]
+            for i in range(n):
+                L.check(lib.dei2i_affine_act_fwd(prec.code, h * w, c, _p(x[i]), _p(a[i]), _p(b[i]), None, act, _p(out[i]), None, 1.0, st),
+                        "affine_act")
+        if res is not None:
+            out = out + res
+        ctx.prec, ctx.slope, ctx.has_res = prec, slope, res is not None
+        ctx.save_for_backward(x, mean, rstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, mean, rstd = ctx.saved_tensors
+        prec = ctx.prec
+        n, h, w, c = x.shape
+        lib = _lib_for(x)
+        dout = dout.contiguous()
+        chunks = lib.dei2i_moments_chunks(h * w)
+        partial = torch.empty((n, chunks, 4, c), dtype=torch.float32, device=x.device)
+        coef = torch.empty((n, 2, c), dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        L.check(lib.dei2i_in_act_bwd(prec.code, n, h, w, c, _p(dout), _p(x), _p(mean), _p(rstd), ctx.slope,
+                                     _p(_zero_table(x.device, x.dtype, n, c)), _p(partial), _p(coef), None, _p(dx), _stream()), "in_act_bwd")
+        return dx, None, (dout if ctx.has_res else None), None
+
+
+def instance_norm_act(x, act="none", res=None, eps=1e-5):
+    """act(InstanceNorm2d(x)) (+ res) on an NHWC activation with H, W >= 4; act: "none" | "relu" | "leaky_relu" """
+    slope = {"none": 1.0, "relu": 0.0, "leaky_relu": 0.2}[act or "none"]
+    return _InstanceNormAct.apply(x, slope, res, float(eps))
+
+
+class _AvgPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x, "avgpool2")
+        prec = precision_of(x)
+        x = x.contiguous()
+        n, h, w, c = x.shape
+        out = torch.empty((n, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
+        L.check(_lib_for(x).dei2i_avgpool2_fwd(prec.code, n, h, w, c, _p(x), _p(out), _stream()), "avgpool2_fwd")
+        ctx.prec, ctx.shape = prec, (n, h, w, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        n, h, w, c = ctx.shape
+        dout = dout.contiguous()
+        dx = torch.empty(ctx.shape, dtype=dout.dtype, device=dout.device)
+        L.check(_lib_for(dout).dei2i_avgpool2_bwd(ctx.prec.code, n, h, w, c, _p(dout), _p(dx), _stream()), "avgpool2_bwd")
+        return dx
+
+
+def avgpool2(x):
+    """nn.AvgPool2d(2, 2) on an NHWC activation (H, W even)"""
+    return _AvgPool2.apply(x)
+
+
+# --------------------------------------------------------------------------------------------------------------
 # generator heads: tanh / sigmoid / compose  (generator.py:268-270), NaN guard (generator.py:266-267)
 # --------------------------------------------------------------------------------------------------------------
 class _Compose(torch.autograd.Function):

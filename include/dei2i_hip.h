@@ -308,6 +308,15 @@ int dei2i_conv2d_dgrad_norm_supported(const dei2i_conv* c);                   /*
 int dei2i_conv2d_dgrad_norm_chunks(const dei2i_conv* c);
 int dei2i_conv2d_dgrad_input_norm(const dei2i_conv* c, const void* dy, const void* wd_packed, void* dx, const dei2i_epi_norm* en,
                                   dei2i_stream s);
+/* Backward of z = act(InstanceNorm2d(x)) (affine=False) with an activation of the ReLU family of negative slope `slope` (0.2:
+ * LeakyReLU, 1: none) -- the norm of the conv StyleExtractor's blocks (models/networks/extractor.py:50-80 with
+ * architecture.py:79-176): the SPADE backward kernels with gamma = beta = 0.  zero_table: an all-zero (N,5,5,2C) table in the
+ * compute dtype; partial (N, dei2i_moments_chunks(H*W), 4, C) and coef (N, 2, C) floats are scratch; addend (optional) is added to dx. */
+int dei2i_in_act_bwd(int dtype, int N, int H, int W, int C, const void* dz, const void* x, const float* mean, const float* rstd,
+                     float slope, const void* zero_table, float* partial, float* coef, const void* addend, void* dx, dei2i_stream s);
+/* nn.AvgPool2d(2, 2) on NHWC (N, H, W, C), H and W even (architecture.py:157-168); out / dout: (N, H/2, W/2, C) */
+int dei2i_avgpool2_fwd(int dtype, int N, int H, int W, int C, const void* x, void* out, dei2i_stream s);
+int dei2i_avgpool2_bwd(int dtype, int N, int H, int W, int C, const void* dout, void* dx, dei2i_stream s);
 /* the border-class half of dei2i_spade_bwd_partial alone (class mode): dgb_cls[n, cy, cx, :] for the 24 classes (cy, cx) != (2, 2) */
 int dei2i_spade_bwd_border(int dtype, int N, int H, int W, int C, int up, const void* dz, const void* x, const float* mean,
                            const float* rstd, const void* gb, void* dgb_cls, dei2i_stream s);

@@ -52,6 +52,7 @@ class Cfg:
     cycle_gan: bool = False                             # --cycle_gan: G returns (foreground, prob), no cyc / con losses (generator.py:272-273)
     embed_nc: int = 768                                 # sean: width of the style embeddings (defectgan_options.py:65)
     num_embeds: int = 5                                 # sean: embeddings drawn per sample (defectgan_options.py:68)
+    sean_alpha: float = 0.0                             # adain: 0 = the MLP StyleExtractor on [labels | noise], 1 = the conv encoder on the image (extractor.py:44-80)
     style_distill: bool = False                         # sean --style_distill (normalization.py:181-190; defectgan_model.py:177-197,238-244)
     use_running_stats: bool = False                     # sean --use_running_stats (normalization.py:111-125,162-176; defectgan_model.py:181-197)
 
@@ -192,6 +193,7 @@ def adain(S: Dict[str, Tensor], prefix: str, x: Tensor, style_feat: Tensor) -> T
     layers on the style feature (N, hidden_nc)."""
     normalized = instancenorm(x)
     n, c = x.shape[:2]
+    style_feat = style_feat.reshape(n, -1)              # (:58 views the conv extractor's (N, hidden_nc, 1, 1) the same way)
     gamma = F.linear(style_feat, S[prefix + ".mlp_gamma.weight"], S[prefix + ".mlp_gamma.bias"]).view(n, c, 1, 1)
     beta = F.linear(style_feat, S[prefix + ".mlp_beta.weight"], S[prefix + ".mlp_beta.bias"]).view(n, c, 1, 1)
     return normalized * (1 + gamma) + beta
@@ -322,9 +324,34 @@ def get_style_embeds(embeddings, labels: Tensor, cfg: "Cfg", rng) -> Optional[Te
     return torch.stack(out)
 
 
+def avgpool2(x: Tensor) -> Tensor:
+    """nn.AvgPool2d(2, 2)"""
+    n, c, h, w = x.shape
+    return x.reshape(n, c, h // 2, 2, w // 2, 2).mean(dim=(3, 5))
+
+
+def style_extractor_conv(SE: Dict[str, Tensor], x: Tensor, cfg: "Cfg") -> Tensor:
+    """StyleExtractor.forward with sean_alpha == 1 (extractor.py:50-80,92-93): ConvBlock 7x7 stride 2 reflect + LeakyReLU (no
+    norm); log2(image_size) - 3 ResBlocks with down_scale (architecture.py:139-176: ConvBlock 3x3 reflect + InstanceNorm2d +
+    LeakyReLU, AvgPool2d(2, 2), ConvBlock 3x3 + InstanceNorm2d; shortcut = AvgPool2d(ConvBlock 1x1 + InstanceNorm2d)); ConvBlock
+    4x4 valid, no norm, no activation -> (N, hidden_nc, 1, 1).  No biases anywhere."""
+    h = leaky_relu(conv2d(x, SE["shared.0.conv_block.0.weight"], stride=2, pad=3, mode="reflect"))
+    nb = int(math.log2(cfg.image_size)) - 3
+    for b in range(1, nb + 1):
+        p = f"shared.{b}"
+        r = leaky_relu(instancenorm(conv2d(h, SE[p + ".res_block.0.conv_block.0.weight"], stride=1, pad=1, mode="reflect")))
+        r = instancenorm(conv2d(avgpool2(r), SE[p + ".res_block.2.conv_block.0.weight"], stride=1, pad=1, mode="reflect"))
+        sc = avgpool2(instancenorm(conv2d(h, SE[p + ".conv_s.0.conv_block.0.weight"], stride=1, pad=0)))
+        h = r + sc
+    return conv2d(h, SE[f"shared.{nb + 1}.conv_block.0.weight"], stride=1, pad=0)
+
+
 def style_extractor(SE: Dict[str, Tensor], x: Tensor, labels: Tensor, cfg: "Cfg") -> Tensor:
     """StyleExtractor.forward with sean_alpha == 0 (extractor.py:44-49,88-92): five Linear layers (ReLU between them) on
-    [labels | noise], noise ~ N(0,1) of width latent_dim - label_nc (NOISE_SOURCE replaces the draw in the goldens)."""
+    [labels | noise], noise ~ N(0,1) of width latent_dim - label_nc (NOISE_SOURCE replaces the draw in the goldens);
+    sean_alpha == 1: the conv encoder on the image (style_extractor_conv)."""
+    if cfg.sean_alpha == 1:
+        return style_extractor_conv(SE, x, cfg)
     shape = (labels.shape[0], cfg.latent_dim - cfg.label_nc)
     noise = NOISE_SOURCE(shape) if NOISE_SOURCE is not None else torch.randn(shape)
     h = torch.cat([labels.reshape(labels.shape[0], -1), noise.to(labels.dtype)], dim=1)
@@ -762,8 +789,20 @@ def generator_state_shapes(cfg: Cfg) -> Dict[str, Tuple[int, ...]]:
 def extractor_state_shapes(cfg: Cfg) -> Dict[str, Tuple[int, ...]]:
     """StyleExtractor.state_dict() with sean_alpha == 0 (extractor.py:44-49): Linear(latent_dim, 256), 3 x Linear(256, 256),
     Linear(256, hidden_nc) at Sequential indices 0, 2, 4, 6, 8."""
-    dims = [cfg.latent_dim, 256, 256, 256, 256, cfg.hidden_nc]
     sh: Dict[str, Tuple[int, ...]] = {}
+    if cfg.sean_alpha == 1:                              # extractor.py:50-80: conv weights only (no biases, parameter-free norms)
+        crt = cfg.ndf
+        sh["shared.0.conv_block.0.weight"] = (crt, cfg.input_nc, 7, 7)
+        nb = int(math.log2(cfg.image_size)) - 3
+        for b in range(1, nb + 1):
+            new = min(crt * 2, 256)
+            sh[f"shared.{b}.conv_s.0.conv_block.0.weight"] = (new, crt, 1, 1)           # (registered before res_block: :161-168)
+            sh[f"shared.{b}.res_block.0.conv_block.0.weight"] = (crt, crt, 3, 3)
+            sh[f"shared.{b}.res_block.2.conv_block.0.weight"] = (new, crt, 3, 3)
+            crt = new
+        sh[f"shared.{nb + 1}.conv_block.0.weight"] = (cfg.hidden_nc, crt, 4, 4)
+        return sh
+    dims = [cfg.latent_dim, 256, 256, 256, 256, cfg.hidden_nc]
     for i in range(5):
         sh[f"shared.{2 * i}.weight"] = (dims[i + 1], dims[i])
         sh[f"shared.{2 * i}.bias"] = (dims[i + 1],)

@@ -29,9 +29,13 @@ from oracle import defectgan_oracle as O  # noqa: E402
 from trainers.defectgan_trainer import DefectGanTrainer  # noqa: E402  (the reference)
 
 torch.set_num_threads(8)
-NAME = "t5_img64_b2_adain"
-C = dict(image_size=64, batch=2, num_layers=4, ngf=8, ndf=8, hidden_nc=16, style_norm="adain", latent_dim=16,
-         tol_step2=8e-2, tol_gradnorm=0.3, tol_post=5e-2, tol_running=0.2)
+CONFIGS = {
+    "t5_img64_b2_adain": dict(image_size=64, batch=2, num_layers=4, ngf=8, ndf=8, hidden_nc=16, style_norm="adain", latent_dim=16,
+                              tol_step2=8e-2, tol_gradnorm=0.3, tol_post=5e-2, tol_running=0.2),
+    # --sean_alpha 1: the StyleExtractor is the conv encoder on the image (extractor.py:50-80) instead of the MLP on [labels | noise]
+    "t9_img64_b2_adain_conv": dict(image_size=64, batch=2, num_layers=4, ngf=8, ndf=8, hidden_nc=16, style_norm="adain", latent_dim=16,
+                                   sean_alpha=1, tol_step2=8e-2, tol_gradnorm=0.3, tol_post=5e-2, tol_running=0.2),
+}
 
 
 def close(a, b, what, rtol=2e-4, atol=2e-6):
@@ -57,17 +61,18 @@ def gnorms(net):
     return keys, np.array([float(p.grad.double().norm()) if p.grad is not None else -1.0 for _, p in net.named_parameters()])
 
 
-def main():
-    c = C
+def main(NAME):
+    c = CONFIGS[NAME]
+    alpha = c.get("sean_alpha", 0)
     cfg = O.Cfg(image_size=c["image_size"], ngf=c["ngf"], ndf=c["ndf"], num_layers=c["num_layers"], hidden_nc=c["hidden_nc"],
-                style_norm="adain", latent_dim=c["latent_dim"])
+                style_norm="adain", latent_dim=c["latent_dim"], sean_alpha=alpha)
     opt = SimpleNamespace(
         model="defectgan", num_res=6, cycle_gan=False, label_nc=6, skip_conn=False, ngf=c["ngf"], ndf=c["ndf"], input_nc=3,
         use_spectral=False, num_scales=2, style_norm_block_type="adain", hidden_nc=c["hidden_nc"], style_distill=False, embed_nc=768,
         add_noise=False, num_layers=c["num_layers"], image_size=c["image_size"], batch_size=c["batch"], device=torch.device("cpu"),
         is_train=True, clf_loss_type="bce", continue_training=False, load_model_name=None, init_type="normal", init_variance=0.02,
         phase="train", ckpt_dir=Path(tempfile.mkdtemp()), name="golden", iters_per_epoch=10, num_epochs=-1, num_iters=100, lr=[2e-4],
-        optimizer="adam", scheduler="step", lr_decay=5e-3, loss_weight=[2, 5, 5, 5, 1], num_critics=1, diff_aug="", sean_alpha=0,
+        optimizer="adam", scheduler="step", lr_decay=5e-3, loss_weight=[2, 5, 5, 5, 1], num_critics=1, diff_aug="", sean_alpha=alpha,
         use_running_stats=False, save_latest_freq=10 ** 9, latent_dim=c["latent_dim"])
     tr = DefectGanTrainer(opt)
     G, D, E = tr.model.netG, tr.model.netD, tr.model.netE
@@ -79,7 +84,8 @@ def main():
     O.NOISE_SOURCE = O.shape_noise
     try:
         for net, shapes in ((G, O.generator_state_shapes(cfg)), (D, O.discriminator_state_shapes(cfg)), (E, O.extractor_state_shapes(cfg))):
-            assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == shapes, "state_dict manifest mismatch"
+            got = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+            assert got == shapes and (alpha == 0 or list(got) == list(shapes)), "state_dict manifest mismatch"
         meta = {"config": c, "name": NAME, "G_keys": list(G.state_dict().keys()), "D_keys": list(D.state_dict().keys()),
                 "E_keys": list(E.state_dict().keys())}
         arrays, errs = {}, {}
@@ -152,4 +158,5 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    for name in (sys.argv[1:] or list(CONFIGS)):
+        main(name)

@@ -15,15 +15,16 @@ from oracle import defectgan_oracle as O
 
 GOLD = Path(__file__).resolve().parent / "golden"
 NAME = "t5_img64_b2_adain"
+NAMES = ["t5_img64_b2_adain", "t9_img64_b2_adain_conv"]      # t9: --sean_alpha 1, the conv StyleExtractor on the image (extractor.py:50-80)
 DEV = "cuda:0"
 
 
-def load():
-    meta = json.loads((GOLD / f"{NAME}.json").read_text())
-    arr = np.load(GOLD / f"{NAME}.npz")
+def load(name=NAME):
+    meta = json.loads((GOLD / f"{name}.json").read_text())
+    arr = np.load(GOLD / f"{name}.npz")
     c = meta["config"]
     cfg = O.Cfg(image_size=c["image_size"], ngf=c["ngf"], ndf=c["ndf"], num_layers=c["num_layers"], hidden_nc=c["hidden_nc"],
-                style_norm="adain", latent_dim=c["latent_dim"])
+                style_norm="adain", latent_dim=c["latent_dim"], sean_alpha=c.get("sean_alpha", 0))
     return meta, arr, c, cfg
 
 
@@ -32,8 +33,9 @@ def maxrel(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
 
 
-def test_oracle_adain_matches_the_reference_fixture():
-    meta, arr, c, cfg = load()
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_adain_matches_the_reference_fixture(name):
+    meta, arr, c, cfg = load(name)
     O.NOISE_SOURCE = O.shape_noise
     try:
         SG, SD, SE = (O.make_state(f(cfg)) for f in (O.generator_state_shapes, O.discriminator_state_shapes, O.extractor_state_shapes))
@@ -56,23 +58,24 @@ def test_oracle_adain_matches_the_reference_fixture():
         O.NOISE_SOURCE = None
 
 
-def _build(pname):
+def _build(pname, name=NAME):
     from de_i2i_gan_amd import ops
     from de_i2i_gan_amd.trainers.defectgan_trainer import DefectGanTrainer
-    meta, arr, c, cfg = load()
+    meta, arr, c, cfg = load(name)
     ops.noise_source = O.shape_noise
-    tr = DefectGanTrainer(make_opt(c, DEV, pname, style_norm_block_type="adain", sean_alpha=0, latent_dim=c["latent_dim"]))
+    tr = DefectGanTrainer(make_opt(c, DEV, pname, style_norm_block_type="adain", sean_alpha=c.get("sean_alpha", 0), latent_dim=c["latent_dim"]))
     for net in (tr.model.netG, tr.model.netD, tr.model.netE):
         formula_fill(net)
     return tr, meta, arr, c
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
 @pytest.mark.parametrize("pname", ["f32", "bf16"])
-def test_adain_forward_and_two_steps_match_the_reference_fixture(pname):
+def test_adain_forward_and_two_steps_match_the_reference_fixture(pname, name):
     from de_i2i_gan_amd import ops
     try:
-        tr, meta, arr, c = _build(pname)
+        tr, meta, arr, c = _build(pname, name)
         G, D, E = tr.model.netG, tr.model.netD, tr.model.netE
         assert list(G.state_dict().keys()) == meta["G_keys"] and list(D.state_dict().keys()) == meta["D_keys"]
         assert list(E.state_dict().keys()) == meta["E_keys"] and sorted(tr.optimizers) == ["D", "E", "G"]
@@ -86,7 +89,9 @@ def test_adain_forward_and_two_steps_match_the_reference_fixture(pname):
             else:       # bf16 on the formula-filled 8-channel nets (see test_model_gpu.py): rms 0.3, single elements 4.2 x that
                 a, b = got.double().cpu(), torch.as_tensor(arr[key]).double()
                 if key.startswith("G_"):
-                    assert ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item() < 0.3 and maxrel(a, b) < 1.26, key
+                    # (t9: the style feature comes through eight more bf16 conv / InstanceNorm layers: single elements up to 1.33)
+                    top = 1.26 if name == NAME else 1.5
+                    assert ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item() < 0.3 and maxrel(a, b) < top, key
                 else:   # a handful of near-zero logits computed on the bf16 G output: absolute
                     assert float((a - b).abs().max()) < 0.1, key
         losses = []

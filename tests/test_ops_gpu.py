@@ -525,3 +525,39 @@ def test_pack_weight_both_matches_the_separate_packers(ops, pname, shape):
     torch.cuda.synchronize()
     assert torch.equal(f1, f2)
     assert torch.equal(g1, g2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pname,N,C,H,act", [("f32", 2, 8, 8, "leaky_relu"), ("f32", 3, 20, 16, "none"), ("bf16", 4, 64, 32, "leaky_relu"),
+                                             ("bf16", 2, 256, 8, "none"), ("bf16", 2, 16, 4, "relu")])
+def test_instance_norm_act_and_avgpool_match_torch(pname, N, C, H, act):
+    """The conv StyleExtractor's blocks (extractor.py:50-80 with architecture.py:79-176): act(InstanceNorm2d(x)) (affine=False, eps
+    1e-5, biased variance) and AvgPool2d(2, 2), forward and backward, against torch's own ops in float64 on the rounded operands."""
+    import torch.nn.functional as F
+    from de_i2i_gan_amd import ops
+    prec = ops.get_precision(pname)
+    torch.manual_seed(3)
+    cs = prec.pad(C)
+    x = torch.zeros(N, H, H, cs)
+    x[..., :C] = torch.randn(N, H, H, C) * 1.7 + 0.3
+    x = x.to(prec.dtype)
+    g = torch.zeros(N, H // 2, H // 2, cs)
+    g[..., :C] = torch.randn(N, H // 2, H // 2, C)
+    g = g.to(prec.dtype)
+    xg = x.to(dev()).requires_grad_(True)
+    y = ops.avgpool2(ops.instance_norm_act(xg, act))
+    y.backward(g.to(dev()))
+    xr = x.double().permute(0, 3, 1, 2)[:, :C].requires_grad_(True)
+    z = F.instance_norm(xr, eps=1e-5)
+    z = F.leaky_relu(z, 0.2) if act == "leaky_relu" else (torch.relu(z) if act == "relu" else z)
+    yr = F.avg_pool2d(z, 2, 2)
+    yr.backward(g.double().permute(0, 3, 1, 2)[:, :C])
+    tol = 2e-5 if pname == "f32" else 1.5e-2
+    got_y = y.detach().double().cpu().permute(0, 3, 1, 2)[:, :C]
+    got_dx = xg.grad.double().cpu().permute(0, 3, 1, 2)[:, :C]
+    assert float((got_y - yr.detach()).abs().max() / yr.detach().abs().max()) < tol
+    # InstanceNorm's backward subtracts means: the bf16 rounding of the output is amplified by the cancellation -> relative L2 there
+    if pname == "f32":
+        assert float((got_dx - xr.grad).abs().max() / xr.grad.abs().max()) < 1e-4
+    else:
+        assert float((got_dx - xr.grad).norm() / xr.grad.norm()) < 3e-2
