@@ -48,9 +48,40 @@ __global__ __launch_bounds__(256) void adam_kernel(const dei2i_adam_rec* __restr
   }
 }
 
+// torch.optim.SGD / torch.optim.RMSprop with the defaults the reference constructs them with (trainers/base_trainer.py:71-74: only
+// lr is passed -- no momentum, no weight decay, RMSprop alpha 0.99, eps 1e-8, not centered), same pointer table (RMSprop's
+// square average lives in rec.m; rec.v is not touched):
+//   kind 0  p -= lr * g                       kind 1  sq = alpha sq + (1 - alpha) g^2;  p -= lr * g / (sqrt(sq) + eps)
+__global__ __launch_bounds__(256) void sgd_rmsprop_kernel(const dei2i_adam_rec* __restrict__ table, int kind, float lr, float alpha,
+                                                          float eps, float grad_scale) {
+  const dei2i_adam_rec rec = table[blockIdx.y];
+  const int64_t n = rec.n, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float gv = rec.g[i] * grad_scale;
+    if (kind == 0) {
+      rec.p[i] -= lr * gv;
+    } else {
+      const float sq = alpha * rec.m[i] + (1.f - alpha) * gv * gv;
+      rec.m[i] = sq;
+      rec.p[i] -= lr * (gv / (sqrtf(sq) + eps));
+    }
+  }
+}
+
 }  // namespace dei2i
 
 using namespace dei2i;
+
+extern "C" int dei2i_sgd_rmsprop_step(const dei2i_adam_rec* table_dev, int count, int64_t max_n, int kind, float lr, float alpha,
+                                      float eps, float grad_scale, dei2i_stream s) {
+  if (!table_dev || count <= 0 || max_n <= 0 || (kind != 0 && kind != 1)) return DEI2I_ERR_BAD_ARG;
+  int64_t bx = (max_n + 255) / 256;
+  if (bx < 1) bx = 1;
+  if (bx > 2048) bx = 2048;
+  hipLaunchKernelGGL(sgd_rmsprop_kernel, dim3((unsigned)bx, (unsigned)count), dim3(256), 0, (hipStream_t)s, table_dev, kind, lr, alpha, eps,
+                     grad_scale);
+  return (int)hipGetLastError();
+}
 
 extern "C" int dei2i_adam_step(const dei2i_adam_rec* table_dev, int count, int64_t max_n, float lr, float beta1, float beta2,
                                float eps, float bias_c1, float bias_c2_sqrt, float grad_scale, float decoupled_decay,

@@ -77,3 +77,68 @@ class FusedAdam(torch.optim.Optimizer):
         for p in plist:
             p._dei2i_epoch = getattr(p, "_dei2i_epoch", 0) + 1      # raw-pointer update: invalidate packed copies
             p._dei2i_keep = None
+
+
+class _FusedPlain(torch.optim.Optimizer):
+    """torch.optim.SGD / torch.optim.RMSprop as trainers/base_trainer.py:71-74 constructs them (``optim_cls(params, lr=...)``: no
+    momentum, no weight decay; RMSprop alpha 0.99, eps 1e-8, not centered) on csrc/adam.hip's second kernel: one launch per step,
+    parameters whose ``grad`` is None skipped (no state), ``grad_scale`` like FusedAdam (the data-parallel 1/world)."""
+    KIND = None
+
+    def __init__(self, params, lr, grad_scale=1.0, **defaults):
+        if lr < 0.0:
+            raise ValueError("invalid learning rate")
+        super().__init__(params, dict(lr=lr, **defaults))
+        self.grad_scale = float(grad_scale)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            plist = [p for p in group["params"] if p.grad is not None]
+            if not plist:
+                continue
+            dev = plist[0].device
+            lib = ops._lib_for(plist[0])
+            rows, max_n = [], 0
+            for p in plist:
+                ops._require_gpu(p, type(self).__name__)
+                if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_contiguous():
+                    raise TypeError(f"{type(self).__name__} expects contiguous fp32 parameters and fp32 gradients")
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                st = self.state[p]
+                if self.KIND == 1 and len(st) == 0:
+                    st["step"] = 0
+                    st["square_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                if self.KIND == 1:
+                    st["step"] += 1
+                aux = st["square_avg"].data_ptr() if self.KIND == 1 else 0
+                rows.append((p.data_ptr(), g.data_ptr(), aux, 0, p.numel()))
+                max_n = max(max_n, p.numel())
+                p._dei2i_keep = g
+            table = torch.tensor(rows, dtype=torch.int64).to(dev)
+            L.check(lib.dei2i_sgd_rmsprop_step(ctypes.c_void_p(table.data_ptr()), len(rows), max_n, self.KIND, float(group["lr"]),
+                                               float(group.get("alpha", 0.0)), float(group.get("eps", 0.0)), self.grad_scale,
+                                               ops._stream()), "sgd_rmsprop_step")
+            for p in plist:
+                p._dei2i_epoch = getattr(p, "_dei2i_epoch", 0) + 1      # raw-pointer update: invalidate packed copies
+                p._dei2i_keep = None
+            self._table_keep = table           # (alive until the next step's launch is enqueued)
+        return loss
+
+
+class FusedSGD(_FusedPlain):
+    KIND = 0
+
+    def __init__(self, params, lr, grad_scale=1.0):
+        super().__init__(params, lr, grad_scale)
+
+
+class FusedRMSprop(_FusedPlain):
+    KIND = 1
+
+    def __init__(self, params, lr, alpha=0.99, eps=1e-8, grad_scale=1.0):
+        super().__init__(params, lr, grad_scale, alpha=alpha, eps=eps)

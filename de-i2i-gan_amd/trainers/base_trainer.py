@@ -7,7 +7,7 @@ import torch
 from torch import optim
 
 from ..models import create_model
-from ..optim import FusedAdam
+from ..optim import FusedAdam, FusedRMSprop, FusedSGD
 
 
 # opt.optimizer -> keyword arguments of the fused optimizer (the reference builds torch.optim.Adam(betas=(0.5, 0.999)) /
@@ -75,8 +75,10 @@ class BaseTrainer:
     def _create_optimizer(self, opt):
         if not isinstance(self.lr, (int, float, dict)):
             raise AssertionError("type of lr should be scalar or dict")
-        if opt.optimizer in ("sgd", "rmsprop"):
-            raise NotImplementedError(f"optimizer [{opt.optimizer}]: only 'adam' / 'adamw' have a fused kernel")
+        if opt.optimizer in ("sgd", "rmsprop"):          # torch's defaults, lr only (base_trainer.py:71-74)
+            cls = FusedSGD if opt.optimizer == "sgd" else FusedRMSprop
+            self.optimizers = {name: cls(net.parameters(), lr=self._lr_of(name)) for name, net in self.model.networks.items()}
+            return
         if opt.optimizer not in _OPTIMIZER_ARGS:
             raise NameError(f"optimizer named {opt.optimizer} not defined")
         self.optimizers = {name: FusedAdam(net.parameters(), lr=self._lr_of(name), **_OPTIMIZER_ARGS[opt.optimizer])

@@ -216,6 +216,10 @@ typedef struct dei2i_adam_rec {
 int dei2i_adam_step(const dei2i_adam_rec* table_dev, int count, int64_t max_n, float lr, float beta1, float beta2,
                     float eps, float bias_c1, float bias_c2_sqrt, float grad_scale, float decoupled_decay, dei2i_stream s);
 /* decoupled_decay: AdamW's weight decay (p *= 1 - lr*decay before the Adam update); 0 = torch.optim.Adam */
+/* torch.optim.SGD (kind 0: p -= lr*g) / torch.optim.RMSprop (kind 1: sq = alpha*sq + (1-alpha)*g^2 in rec.m; p -= lr*g/(sqrt(sq)+eps))
+ * as trainers/base_trainer.py:71-74 constructs them (lr only: torch's defaults otherwise); same pointer table, rec.v unused */
+int dei2i_sgd_rmsprop_step(const dei2i_adam_rec* table_dev, int count, int64_t max_n, int kind, float lr, float alpha, float eps,
+                           float grad_scale, dei2i_stream s);
 
 /* ---- spectral normalisation of a conv weight (--use_spectral; torch.nn.utils.spectral_norm semantics, one power
  * iteration per training-mode forward) ----  W = weight_orig as a (Cout, K) fp32 matrix, u (Cout) / v (K) the module's

@@ -561,3 +561,30 @@ def test_instance_norm_act_and_avgpool_match_torch(pname, N, C, H, act):
         assert float((got_dx - xr.grad).abs().max() / xr.grad.abs().max()) < 1e-4
     else:
         assert float((got_dx - xr.grad).norm() / xr.grad.norm()) < 3e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["sgd", "rmsprop"])
+def test_fused_sgd_and_rmsprop_match_torch(kind):
+    """trainers/base_trainer.py:71-74: ``optim.SGD(params, lr=...)`` / ``optim.RMSprop(params, lr=...)`` (torch's defaults); three
+    steps over tensors of odd sizes, one of them without a gradient (skipped: no state), against torch's own optimizer in float64."""
+    from de_i2i_gan_amd.optim import FusedRMSprop, FusedSGD
+    torch.manual_seed(9)
+    shapes = [(7,), (33, 5), (64, 64, 3, 3), (1,)]
+    ps = [torch.randn(s) for s in shapes]
+    mine = [p.clone().to(dev()).requires_grad_(True) for p in ps]
+    ref = [p.clone().double().requires_grad_(True) for p in ps]
+    o_mine = (FusedSGD if kind == "sgd" else FusedRMSprop)(mine, lr=1e-2)
+    o_ref = (torch.optim.SGD if kind == "sgd" else torch.optim.RMSprop)(ref, lr=1e-2)
+    for step in range(3):
+        for i, (a, b) in enumerate(zip(mine, ref)):
+            if i == 3:
+                a.grad = b.grad = None                       # a parameter the loss does not reach
+                continue
+            g = torch.randn(shapes[i]) * (1.0 + step)
+            a.grad, b.grad = g.to(dev()), g.double()
+        o_mine.step()
+        o_ref.step()
+    for a, b in zip(mine, ref):
+        assert float((a.detach().double().cpu() - b.detach()).abs().max()) < 2e-6 * max(1.0, float(b.detach().abs().max()))
+    assert len(o_mine.state.get(mine[3], {})) == 0
