@@ -256,23 +256,51 @@ __global__ __launch_bounds__(512) void thin_cout_conv_kernel(const GatherDesc g,
   const int tiles_x = g.Wo / TC_TW, tiles_y = g.Ho / TC_TH;
   const int tiles_img = tiles_x * tiles_y;
 
+  // Per-lane constants of this wave's halo pieces (group wave + 8 i: pixel p = 8 grp + lane / 8), hoisted by hand: the halo row /
+  // column of the pixel and its swizzled channel offset.  The address chain per piece was ~60 instructions (a division by the
+  // halo width, two bounds checks, 64-bit products) against 36 MFMAs of compute per 3x3 tile: the issue phase, not the stream,
+  // set the kernel's time (wgrad_halo.hip has the measurement of the same pattern).  Reflect-padded launches (the heads) issue a
+  // piece as a wave-uniform image base + a 32-bit per-lane byte offset; zero-padded ones (the stem's interior dgrad) keep the
+  // per-lane pointer with its zero-page select.
+  constexpr int TO_MAXG = 9;                                           // 7x7: 67 groups -> 9 per wave
+  int hyx[TO_MAXG], coff[TO_MAXG];
+#pragma unroll
+  for (int i = 0; i < TO_MAXG; ++i) {
+    const int grp = wave + 8 * i;
+    const int p = grp * 8 + (lane >> 3);
+    const int hy = p / hwd, hx = p - hy * hwd;
+    hyx[i] = (grp < ngroups && p < npix) ? ((hy << 16) | hx) : -1;
+    coff[i] = ((lane & 7) ^ ((p >> 1) & 7)) << 3;
+    asm volatile("" : "+v"(hyx[i]), "+v"(coff[i]));
+  }
+  const bool fast = g.pad_mode == PAD_REFLECT;
+  const unsigned halo_lds = lds_addr_of(halo);
   auto issue_halo = [&](int buf, int t) {
     const int img = t / tiles_img;
     const int rem = t - img * tiles_img;
     const int ty = rem / tiles_x;
     const int hy0 = ty * TC_TH + g.by0 + (g.ys < 0 ? -(g.th - 1) : 0);
     const int hx0 = (rem - ty * tiles_x) * TC_TW + g.bx0 + (g.xs < 0 ? -(g.tw - 1) : 0);
-    for (int grp = wave; grp < ngroups; grp += 8) {                  // wave-uniform trip count
-      const int p = grp * 8 + (lane >> 3);
-      const bf16_t* ptr = zero;
-      if (p < npix) {
-        const int hy = p / hwd, hx = p - hy * hwd;
-        const int y = bound_coord(hy0 + hy, g.Hl, g.pad_mode);
-        const int x = bound_coord(hx0 + hx, g.Wl, g.pad_mode);
-        if ((y | x) >= 0)
-          ptr = src + ((size_t)((img * g.Hs + (y >> g.up)) * g.Ws + (x >> g.up))) * 64 + (((lane & 7) ^ ((p >> 1) & 7)) << 3);
+    const bf16_t* ibase = src + (size_t)img * ((size_t)g.Hs * g.Ws * 64);                    // wave-uniform
+#pragma unroll
+    for (int i = 0; i < TO_MAXG; ++i) {
+      const int grp = wave + 8 * i;
+      if (grp >= ngroups) break;                                     // wave-uniform
+      if (fast) {
+        const int q = hyx[i] < 0 ? 0 : hyx[i];                       // padding slots of the last group: any valid pixel (never read)
+        const int vy = hy0 + (q >> 16), vx = hx0 + (q & 0xffff);
+        const int ay = max(vy, -vy), ax = max(vx, -vx);
+        const int y = min(ay, 2 * g.Hl - 2 - ay), x = min(ax, 2 * g.Wl - 2 - ax);
+        glds16_asm_s(ibase, (unsigned)((((y >> g.up) * g.Ws + (x >> g.up)) << 6) + coff[i]) * 2u, halo_lds + buf * halo_bytes + grp * 1024);
+      } else {
+        const bf16_t* ptr = zero;
+        if (hyx[i] >= 0) {
+          const int y = bound_coord(hy0 + (hyx[i] >> 16), g.Hl, g.pad_mode);
+          const int x = bound_coord(hx0 + (hyx[i] & 0xffff), g.Wl, g.pad_mode);
+          if ((y | x) >= 0) ptr = ibase + (unsigned)((((y >> g.up) * g.Ws + (x >> g.up)) << 6) + coff[i]);
+        }
+        glds16tc(ptr, halo + buf * halo_bytes + grp * 1024);
       }
-      glds16tc(ptr, halo + buf * halo_bytes + grp * 1024);
     }
   };
 
