@@ -544,7 +544,7 @@ class SEAN(nn.Module):
             mask = (mix_feat == 0).all(dim=1).view(-1, 1)
             mix_feat = mix_feat * ~mask + latent_code * mask
             if self.style_distill and self._distill_loss is not None:
-                from ..utils.util import calc_kl_with_logits
+                from ..utils.distill import calc_kl_with_logits
                 target = mix_feat.detach()
                 latent_term = calc_kl_with_logits(latent_code, target, 4)
                 embed_term = calc_kl_with_logits(enc_feat, target, 4)
