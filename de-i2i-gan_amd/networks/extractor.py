@@ -16,34 +16,33 @@ from .architecture import ConvBlock, ResBlock
 from .base_network import BaseNetwork
 
 
+WIDEST = 256            # widest layer of either form (extractor.py:41)
+
+
 class StyleExtractor(BaseNetwork):
     def __init__(self, opt):
         super().__init__()
-        assert opt.image_size in (64, 128, 256, 512, 1024), "image size should be one of [64, 128, 256, 512, 1024]"
-        num_blocks = int(math.log2(opt.image_size)) - 3
-        max_dim = 256
-        self.hidden_nc = opt.hidden_nc
-        self.prec = ops.get_precision(getattr(opt, "compute_dtype", "bf16"))
-        self.sean_alpha = opt.sean_alpha
+        if opt.image_size not in (64, 128, 256, 512, 1024):
+            raise AssertionError("image size should be one of [64, 128, 256, 512, 1024]")
+        self.sean_alpha, self.hidden_nc = opt.sean_alpha, opt.hidden_nc
         self.noise_dim = opt.latent_dim - opt.label_nc
-        if opt.sean_alpha == 0:
-            layers = [nn.Linear(opt.latent_dim, max_dim), nn.ReLU(inplace=True)]
-            for _ in range(3):
-                layers += [nn.Linear(max_dim, max_dim), nn.ReLU(inplace=True)]
-            layers.append(nn.Linear(max_dim, opt.hidden_nc))
-            self.shared = nn.Sequential(*layers)
-        elif opt.sean_alpha == 1:
-            crt_dim = opt.ndf
-            blocks = [ConvBlock(opt.input_nc, crt_dim, kernel_size=(7, 7), stride=(2, 2), padding=3, padding_mode="reflect",
-                                norm_layer=None, act_layer="leaky_relu", use_spectral=False)]
-            for _ in range(num_blocks):
-                new_dim = min(crt_dim * 2, max_dim)
-                blocks.append(ResBlock(crt_dim, new_dim, kernel_size=(3, 3), stride=(1, 1), padding="same", padding_mode="reflect",
-                                       norm_layer=nn.InstanceNorm2d, act_layer="leaky_relu", use_spectral=False, down_scale=True))
-                crt_dim = new_dim
-            blocks.append(ConvBlock(crt_dim, opt.hidden_nc, kernel_size=(4, 4), stride=(1, 1), padding=0, norm_layer=None,
-                                    act_layer=None, use_spectral=False))
-            self.shared = nn.Sequential(*blocks)
+        self.prec = ops.get_precision(getattr(opt, "compute_dtype", "bf16"))
+        if self.sean_alpha == 0:                              # MLP on [labels | noise]: latent_dim -> 256 x 4 -> hidden_nc
+            widths = [opt.latent_dim] + [WIDEST] * 4
+            mlp = []
+            for fan_in, fan_out in zip(widths[:-1], widths[1:]):
+                mlp += [nn.Linear(fan_in, fan_out), nn.ReLU(inplace=True)]
+            self.shared = nn.Sequential(*mlp, nn.Linear(WIDEST, opt.hidden_nc))
+        elif self.sean_alpha == 1:                            # conv encoder on the image: halves the size down to 4 x 4, then 4x4 -> 1x1
+            halvings = int(math.log2(opt.image_size)) - 3      # after the stride-2 stem
+            chans = [opt.ndf]
+            for _ in range(halvings):
+                chans.append(min(2 * chans[-1], WIDEST))
+            enc = [ConvBlock(opt.input_nc, chans[0], (7, 7), (2, 2), 3, "reflect", norm_layer=None, act_layer="leaky_relu")]
+            enc += [ResBlock(c_in, c_out, (3, 3), (1, 1), "same", "reflect", norm_layer=nn.InstanceNorm2d, act_layer="leaky_relu",
+                             down_scale=True) for c_in, c_out in zip(chans[:-1], chans[1:])]
+            enc.append(ConvBlock(chans[-1], opt.hidden_nc, (4, 4), (1, 1), 0, norm_layer=None, act_layer=None))
+            self.shared = nn.Sequential(*enc)
         else:
             raise NotImplementedError("sean_alpha should be 0 or 1")
 
