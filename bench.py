@@ -7,8 +7,11 @@
 A "step" = DefectGanTrainer.step(): one discriminator update + one generator update (num_critics = 1) on one
 synthetic batch that is already resident in HBM.  value = pairs/s over ALL ranks (weak scaling: 16 pairs per GPU).
 One JSON line is printed by rank 0.  Extra objects:
-  roofline     -- the dominant kernel family (implicit-GEMM gather conv: forward + dgrad), algorithmic FLOPs / HIP-event
-                  time of its launches inside the timed region, against the dense bf16 MFMA peak
+  roofline     -- the step's dominant kernel: whichever instance of the halo-resident 3x3 conv (its FOLD launches = the reflect
+                  dgrads with the ring and the norm-backward reductions, or its forward launches) holds more device time,
+                  algorithmic FLOPs / HIP-event time of its launches, KERNEL-ALONE (extra steps after the timed region with the
+                  weight gradients on the main stream, so no bracket spans two concurrent kernels), against the dense bf16 MFMA
+                  peak; sub-objects: the other instance, the forward instance sampled INSIDE the timed region, the family
   cpu_baseline -- the CPU oracle restatement of the same step timed on this box's host cores (rank 0, N = 1 only)
 """
 import argparse
@@ -289,16 +292,22 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     ddp = red.overlap_report() if red is not None else None
+    red_stats = dict(red.stats) if red is not None else None      # before the extra steps below add to them
     fam, fam_extra, extra_steps = {}, {}, 0
     if not args.no_roofline:
         fam = collect()
+        # kernel-alone figures: a few EXTRA steps after the timed region with events on every conv launch and the weight
+        # gradients on the MAIN stream -- with the side stream a bracket around a backward conv spans that kernel and a wgrad
+        # kernel sharing the GPU and prices neither
         extra_steps = min(3, args.steps)
+        _ops.wgrad_side_stream = False
         for name, fid in fams:
             lib.dei2i_prof_enable(fid, 1)
         for _ in range(extra_steps):
             step()
         sync()
         fam_extra = collect()
+        _ops.wgrad_side_stream = not args.no_wgrad_stream
     if hasattr(tr, "flush_losses"):
         tr.flush_losses()
     if rank == 0:
@@ -332,7 +341,13 @@ def main():
                    "conv_epilogue_statistics": not args.no_fuse_norm, "operand_path_norm": bool(args.fuse_pro),
                    "spade_upsample_at_source_resolution": not args.no_fuse_ring,
                    "weight_gradients_on_side_stream": not args.no_wgrad_stream,
-                   "norm_backward_reductions_in_dgrad_epilogue": not args.no_fuse_bwd},
+                   "norm_backward_reductions_in_dgrad_epilogue": not args.no_fuse_bwd,
+                   # what the step does differently from a literal transcription of the reference's step (same function):
+                   "defer_loss_sync": bool(opt.defer_loss_sync),      # losses stay on the device; no .item() per update
+                   "discriminator_passes": "one batched D pass per step phase (4 image batches in the D step, 2 in the G step: "
+                                           "D has no batch statistics)" if not args.use_spectral else "one D pass per image batch (spectral norm iterates u, v per call)",
+                   "eval_generator_passes_in_d_step": "one batched eval-mode G pass (2 x batch; running BatchNorm statistics)",
+                   "d_weight_gradients_in_g_step": "skipped (the reference computes and discards them)"},
         "losses_last_step": {k: round(v[-1], 5) for kind in tr.losses.values() for k, v in kind.items() if v},
     }
     if fam:
@@ -348,9 +363,9 @@ def main():
         xwn, _, _, xwms, xwfl = fam_extra["wgrad"]
         peak = PEAK_TFLOPS[args.dtype]
         ach = htfl / (hms * 1e-3) / 1e12 if hms > 0 else 0.0
-        traffic, traffic_src, mfma_pmc = None, None, None
+        traffic, traffic_src, mfma_pmc, traffic_fold, mfma_pmc_fold = None, None, None, None, None
         if args.dtype == "bf16" and args.image_size == 256 and args.batch == 16:
-            for tag in ("r02", "r01_g"):                  # newest committed rocprofv3 --pmc summaries (profiles/)
+            for tag in ("r03", "r02", "r01_g"):           # newest committed rocprofv3 --pmc summaries (profiles/)
                 pmc = os.path.join(REPO, "profiles", tag + "_pmc_traffic.json")
                 if traffic is None and os.path.exists(pmc):
                     with open(pmc) as f:
@@ -358,48 +373,65 @@ def main():
                     hk = next((k for k in ("halo16_conv_fwd", "halo16_conv", "halo_conv") if k in t), None)
                     if hk in t:
                         traffic = t[hk]["hbm_bytes_per_launch"]
+                        traffic_fold = t.get("halo16_conv_fold", {}).get("hbm_bytes_per_launch")
                         traffic_src = ("profiles/%s_pmc_traffic.json (profiles/collect.sh + summarize.py): (2*FETCH_SIZE + WRITE_SIZE)"
-                                       "*1024 bytes per %s_kernel launch, separate --pmc passes" % (tag, hk))
+                                       "*1024 bytes per launch of the kernel instance, separate --pmc passes" % tag)
                 pmc2 = os.path.join(REPO, "profiles", tag + "_pmc_mfma.json")
                 if mfma_pmc is None and os.path.exists(pmc2):
                     with open(pmc2) as f:
                         t2 = json.load(f)
                     mfma_pmc = t2.get("halo16_conv_fwd", t2.get("halo16_conv", t2.get("halo_conv", {}))).get("mfma_busy_frac")
+                    mfma_pmc_fold = t2.get("halo16_conv_fold", {}).get("mfma_busy_frac")
         xn, xms, xfl = xhn + xon, xhms + xoms, xhfl + xofl
-        line["roofline"] = {"bound": "mfma", "kernel": "halo16_conv_kernel<128, 8, 0, false, 0, true, false> (halo-resident stride-1 3x3 conv, 16x32-pixel "
-                            "tiles, software-pipelined loop: the forward launches; the step's largest single kernel, ~15 % of its device "
-                            "time -- its FOLD instance, the reflect dgrads, is the second largest and runs beside the side-stream wgrads)",
-                            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
-                            "traffic_source": traffic_src,
-                            "mfma_busy_frac_pmc": mfma_pmc,      # same kernel, counters of a separate profiled run (profiles/)
-                            "launches_per_step": hn / args.steps, "avg_launch_ms": hms / max(htn, 1),
-                            "flops_per_launch": htfl / max(htn, 1), "event_bracketed_launches": htn,
-                            "timing": "HIP events around every %dth forward launch of halo16_conv_kernel inside the timed region, "
-                                      "on the launch stream (%d of %d launches)" % (HALO_SAMPLE, htn, hn),
-                            "fold_launches": {"launches_per_step": xfn / max(extra_steps, 1),
-                                              "avg_launch_ms": xfms / max(xfn, 1),
-                                              "achieved": xffl / (xfms * 1e-3) / 1e12 if xfms > 0 else 0.0,
-                                              "note": "reflect dgrads, event-bracketed in %d extra steps; they share the GPU with the "
-                                                      "wgrad kernels of the side stream, so this is not a kernel-alone figure" % extra_steps},
+
+        def inst(n, ms, fl, what):
+            a = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            return {"kernel": what, "achieved": a, "frac": a / peak, "launches_per_step": n / max(extra_steps, 1),
+                    "avg_launch_ms": ms / max(n, 1), "flops_per_launch": fl / max(n, 1), "ms_per_step": ms / max(extra_steps, 1)}
+        K_FOLD = ("halo16_conv_kernel<128, 8, 0, true, 0, false, true> (halo-resident stride-1 3x3 conv, 16x32-pixel tiles: the FOLD "
+                  "launches = input gradients of the reflect-padded convs, with the reflect ring and the SPADE / BatchNorm backward "
+                  "reductions in the epilogue)")
+        K_FWD = ("halo16_conv_kernel<128, 8, 0, false, 0, true, false> (the same kernel's forward / zero-boundary launches, "
+                 "software-pipelined loop)")
+        fold_i, fwd_i = inst(xfn, xfms, xffl, K_FOLD), inst(xhn, xhms, xhfl, K_FWD)
+        dom, other = (fold_i, fwd_i) if xfms >= xhms else (fwd_i, fold_i)
+        fam_ach = (xhfl + xffl) / ((xhms + xfms) * 1e-3) / 1e12 if (xhms + xfms) > 0 else 0.0
+        line["roofline"] = {"bound": "mfma", "kernel": dom["kernel"] + " -- the instance with the most device time per step",
+                            "achieved": dom["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": dom["frac"],
+                            "traffic": traffic if dom is fwd_i else traffic_fold, "traffic_source": traffic_src,
+                            "mfma_busy_frac_pmc": mfma_pmc if dom is fwd_i else mfma_pmc_fold,   # same kernel, counters of a separate profiled run (profiles/)
+                            "launches_per_step": dom["launches_per_step"], "avg_launch_ms": dom["avg_launch_ms"],
+                            "flops_per_launch": dom["flops_per_launch"], "ms_per_step": dom["ms_per_step"],
+                            "timing": "kernel-alone: HIP events on the launch stream around EVERY launch in %d extra steps after the timed "
+                                      "region, run with the weight gradients on the main stream (with the side stream a bracket around a "
+                                      "backward conv spans two kernels sharing the GPU); profiles/r03_serial_kernel_stats.csv is the "
+                                      "rocprofv3 table of the same serial configuration" % extra_steps,
+                            "other_instance": other,
+                            "halo16_family_flop_weighted": {"achieved": fam_ach, "frac": fam_ach / peak,
+                                                            "launches_per_step": (xhn + xfn) / max(extra_steps, 1)},
+                            "forward_instance_in_timed_region": {
+                                "achieved": ach, "frac": ach / peak, "launches_per_step": hn / args.steps,
+                                "avg_launch_ms": hms / max(htn, 1), "flops_per_launch": htfl / max(htn, 1),
+                                "event_bracketed_launches": htn, "traffic": traffic, "mfma_busy_frac_pmc": mfma_pmc,
+                                "timing": "HIP events around every %dth forward launch of halo16_conv_kernel inside the timed region, "
+                                          "on the launch stream (%d of %d launches)" % (HALO_SAMPLE, htn, hn)},
                             "all_conv_fwd_dgrad_kernels": {"achieved": xfl / (xms * 1e-3) / 1e12 if xms > 0 else 0.0,
                                                            "launches_per_step": xn / max(extra_steps, 1),
                                                            "avg_launch_ms": xms / max(xn, 1),
-                                                           "timing": "%d extra steps after the timed region" % extra_steps}}
+                                                           "timing": "%d extra serial steps after the timed region" % extra_steps}}
         conv_flops_step = (hfl + ofl + wfl) / args.steps
         line["mfma"] = {"executed_conv_tflop_per_step": conv_flops_step / 1e12,
                         "step_mfma_util": conv_flops_step / (ms_per_step * 1e-3) / (peak * 1e12),
                         "conv_launches_per_step": (hn + on + wn) / args.steps,
                         "wgrad_tflops": xwfl / (xwms * 1e-3) / 1e12 if xwms > 0 else 0.0,
                         "conv_kernel_time_over_step_time": (xms + xwms) / max(extra_steps, 1) / ms_per_step,
-                        "timing": "FLOPs counted in the timed region; wgrad / all-conv times from %d extra steps after it.  With the "
-                                  "weight gradients on the side stream (config.weight_gradients_on_side_stream) wgrad kernels and backward "
-                                  "conv kernels run concurrently: their event brackets overlap, so wgrad_tflops and the time ratio are "
-                                  "not kernel-alone figures (the ratio can exceed 1); --no-wgrad-stream gives the serial ones" % extra_steps}
+                        "timing": "FLOPs counted in the timed region; wgrad / all-conv times kernel-alone from %d extra serial steps "
+                                  "after it (weight gradients on the main stream)" % extra_steps}
     if ddp is not None:
         # rank 0's view: time the gradient all-reduces occupied the side stream per backward pass, and the part that ran
         # after backward's last kernel (the optimizer waits for it) -- stream events, measured inside the timed region
-        ddp.update({"collectives_per_step": red.stats["collectives"] / (args.steps + args.warmup),
-                    "allreduce_mb_per_step": red.stats["bytes"] / (args.steps + args.warmup) / 1e6})
+        ddp.update({"collectives_per_step": red_stats["collectives"] / (args.steps + args.warmup),
+                    "allreduce_mb_per_step": red_stats["bytes"] / (args.steps + args.warmup) / 1e6})
         line["ddp"] = ddp
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_bounded()

@@ -646,6 +646,7 @@ static hipError_t gather_gemm_t(const DescPack& pack, const void* src, const voi
     const int threads = 256;
     size_t blocks = ((slab_elems >> 2) + threads - 1) / threads;
     if (blocks > 4096) blocks = 4096;
+    count_launch(K_SPLITK_FINALIZE);
     hipLaunchKernelGGL(splitk_finalize_kernel<T>, dim3((unsigned)blocks), dim3(threads), 0, st, pack, (const float*)ws,
                        pack.ws_atomic ? 1 : zs, slab_elems,
                        bias, (T*)out, ldc, wrows, act);

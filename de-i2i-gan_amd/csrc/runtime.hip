@@ -39,7 +39,7 @@ static ProfState g_prof[PROF_FAMILIES];
 static long long g_launches[K_COUNT];
 void count_launch(int kid) { g_launches[kid]++; }
 static const char* const g_kernel_names[K_COUNT] = {"gather_v1", "gather_v2", "halo_conv", "halo_conv_fp8", "thin_cin", "thin_cout",
-                                                    "wgrad_v1", "wgrad_v2", "wgrad_halo", "wgrad_thin", "halo16_conv"};
+                                                    "wgrad_v1", "wgrad_v2", "wgrad_halo", "wgrad_thin", "halo16_conv", "splitk_finalize"};
 
 void prof_begin(int family, double flops, hipStream_t st) {
   ProfState& p = g_prof[family];

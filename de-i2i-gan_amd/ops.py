@@ -499,7 +499,7 @@ def _wgrad_scratch(lib, d, device, slot="wgrad"):
 # side stream as well (parallel.GradReducer._launch).
 wgrad_side_stream = True
 _wgrad_streams = {}
-_wgrad_join_pending = set()
+_wgrad_join_pending = {}         # device -> graph-task id of the pass whose end-of-pass join is queued
 
 
 def wgrad_stream(device):
@@ -507,9 +507,10 @@ def wgrad_stream(device):
     return _wgrad_streams.get(torch.device(device))
 
 
-def _wgrad_join(device):
+def _wgrad_join(device, tid):
     def join():
-        _wgrad_join_pending.discard(device)
+        if _wgrad_join_pending.get(device) == tid:
+            del _wgrad_join_pending[device]
         torch.cuda.current_stream(device).wait_stream(_wgrad_streams[device])
     return join
 
@@ -521,11 +522,20 @@ def _conv_wgrad(lib, prec, geom, x, g, weight, pro=None, keep=()):
     d = _desc(prec, geom, n, h, w, cins, g.shape[-1])
     dev = x.device
     side = None
-    if wgrad_side_stream and weight.is_leaf and torch._C._current_graph_task_id() >= 0:
+    tid = torch._C._current_graph_task_id()
+    # only when AccumulateGrad will STEAL the tensor (param.grad undefined): with a defined .grad it launches `grad += dw` on the
+    # main stream in the middle of the pass, before the end-of-pass join -- those gradients stay on the main stream
+    if wgrad_side_stream and weight.is_leaf and tid >= 0 and weight.grad is None:
         side = _wgrad_streams.get(dev)
         if side is None:
             side = _wgrad_streams[dev] = torch.cuda.Stream(device=dev)
-    scratch = _wgrad_scratch(lib, d, dev, "wgrad_side" if side is not None else "wgrad")
+    if side is not None:
+        # the side stream's split-K scratch is allocated (and re-grown) ON the side stream: the caching allocator then hands a
+        # dropped buffer's block only to later side-stream allocations, which run behind the kernels that still use it
+        with torch.cuda.stream(side):
+            scratch = _wgrad_scratch(lib, d, dev, "wgrad_side")
+    else:
+        scratch = _wgrad_scratch(lib, d, dev, "wgrad")
     dw, dw_ptr, accumulate = _grad_target(weight, weight.shape, dev)
 
     def launch():
@@ -544,9 +554,9 @@ def _conv_wgrad(lib, prec, geom, x, g, weight, pro=None, keep=()):
     for t in (x, g, dw) + tuple(keep):                        # the allocator must not hand their memory out before the side stream is done
         if t is not None:
             t.record_stream(side)
-    if dev not in _wgrad_join_pending:
-        _wgrad_join_pending.add(dev)
-        torch.autograd.Variable._execution_engine.queue_callback(_wgrad_join(dev))
+    if _wgrad_join_pending.get(dev) != tid:                   # (a pass that raised never ran its callback: its id is stale)
+        _wgrad_join_pending[dev] = tid
+        torch.autograd.Variable._execution_engine.queue_callback(_wgrad_join(dev, tid))
     return dw
 
 

@@ -35,16 +35,31 @@ def load_options(opt):
     (base_options.py:143-149)."""
     path = option_file_path(opt) if getattr(opt, "continue_training", False) else Path(opt.load_from_opt_file)
     with path.open("rb") as f:
-        return pickle.load(f)
+        return _OptionUnpickler(f).load()
 
 
-def update_options_from_file(opt, keep=("name", "load_model_name", "continue_training", "ckpt_dir", "device")):
-    """Apply the stored run's values onto ``opt`` (everything but ``keep``), as the reference's two-pass parse does through
-    parser defaults (base_options.py:135-141: ``name`` / ``load_model_name`` are never taken from the file; values given on
-    the command line -- here: ``continue_training``, where the run lives and the device -- win over the stored ones).
-    Returns ``opt``."""
+class _OptionUnpickler(pickle.Unpickler):
+    """An option namespace is plain data: only the handful of constructors such a file needs are resolvable -- anything else in the
+    stream (an arbitrary callable) is refused instead of imported and called."""
+    _ALLOWED = {("argparse", "Namespace"), ("types", "SimpleNamespace"), ("pathlib", "PosixPath"), ("pathlib", "PurePosixPath"),
+                ("pathlib", "Path"), ("torch", "device"), ("collections", "OrderedDict"), ("builtins", "set"),
+                ("builtins", "frozenset"), ("builtins", "complex"), ("builtins", "slice"), ("builtins", "range")}
+
+    def find_class(self, module, name):
+        if (module, name) in self._ALLOWED:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"option file refers to {module}.{name}: not an option value")
+
+
+def update_options_from_file(opt, explicit=(), keep=("name", "load_model_name", "continue_training", "ckpt_dir", "device")):
+    """Apply the stored run's values onto ``opt``, as the reference's two-pass parse does by installing them as parser DEFAULTS
+    (base_options.py:135-141): ``name`` / ``load_model_name`` are never taken from the file, and anything given on the command
+    line of the continuing run still wins -- ``explicit`` names those options (the reference's argparse knows them by itself; a
+    caller that builds ``opt`` directly passes e.g. ``explicit=("num_epochs", "lr")``), ``keep`` the ones this package always
+    treats as given (``continue_training``, where the run lives, the device).  Returns ``opt``."""
     old = load_options(opt)
+    given = set(keep) | set(explicit)
     for k, v in vars(old).items():
-        if k not in keep and hasattr(opt, k):
+        if k not in given and hasattr(opt, k):
             setattr(opt, k, v)
     return opt

@@ -29,9 +29,10 @@ def ops():
     _ops.fuse_norm, _ops.fuse_pro, _ops.fuse_ring = keep
 
 
-def _counts(reset=True):
+def _counts(reset=True, splitk=False):
+    """launches per MFMA kernel family since the last call (``splitk``: keep the split-K finalize launches too)"""
     from de_i2i_gan_amd import _lib
-    return {k: v for k, v in _lib.launch_counts(reset=reset).items() if v}
+    return {k: v for k, v in _lib.launch_counts(reset=reset).items() if v and (splitk or k != "splitk_finalize")}
 
 
 def maxrel(a, b):
@@ -288,6 +289,68 @@ def test_weight_gradients_on_the_side_stream_are_bit_identical_and_joined():
     assert len(grads[True]) == len(grads[False]) > 50
     for a, b in zip(grads[True], grads[False]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_side_stream_scratch_regrowth_at_default_widths_is_bit_identical():
+    """The side stream's split-K scratch is sized per layer (96 MB for the small weights, ~151 MB for a 256x256x3x3 one, 512 MB for
+    D's enc_blk.5), so at the DEFAULT widths (ngf = ndf = 64) it re-grows inside the first backward pass while earlier side-stream
+    kernels may still be using the buffer it replaces.  It is allocated on the side stream (ops._conv_wgrad), so the dropped block can
+    only be handed to later side-stream allocations.  First D and G backward of a trainer, side stream against single stream, with
+    the workspaces dropped in between (cold path both times): every gradient bit for bit."""
+    from de_i2i_gan_amd import ops
+    from de_i2i_gan_amd.trainers.defectgan_trainer import DefectGanTrainer
+    c = dict(image_size=128, batch=4, num_layers=5, ngf=64, ndf=64, hidden_nc=128)
+    bg, labels, df = O.synthetic_batch(c["batch"], c["image_size"])
+    grads = {}
+    for side in (True, False):
+        ops.wgrad_side_stream = side
+        for k_ in [k_ for k_ in ops._workspaces if k_[1] in ("wgrad_side", "wgrad")]:
+            del ops._workspaces[k_]
+        torch.cuda.empty_cache()
+        try:
+            torch.manual_seed(11)
+            tr = DefectGanTrainer(make_opt(c, "cuda:0", "bf16"))
+            ld = tr.model("discriminator", bg, labels, df)
+            (ld[0] + 2 * ld[1]).backward()
+            ls = tr.model("generator", bg, labels, df)
+            (ls[0] + 5 * ls[1] + 5 * ls[2] + 5 * ls[3] + ls[4]).backward()
+            grads[side] = [p.grad.clone() for net in (tr.model.netD, tr.model.netG) for p in net.parameters() if p.grad is not None]
+            if side:      # the regrow path was actually taken: the slot ended larger than its first size
+                ws = ops._workspaces[(torch.device("cuda:0"), "wgrad_side")]
+                assert ws.numel() * 4 > (96 << 20), ws.numel()
+        finally:
+            ops.wgrad_side_stream = True
+    assert len(grads[True]) == len(grads[False]) > 58
+    for a, b in zip(grads[True], grads[False]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_side_stream_is_not_taken_when_grad_is_already_defined():
+    """Two backward() calls without zero_grad (gradient accumulation): with ``param.grad`` defined AccumulateGrad launches
+    ``grad += dw`` on the main stream in the MIDDLE of the pass, before the end-of-pass join, so those weight gradients must be
+    computed on the main stream (ops._conv_wgrad takes the side stream only when ``weight.grad is None``).  Against
+    wgrad_side_stream = False, bit for bit."""
+    from de_i2i_gan_amd import ops
+    from de_i2i_gan_amd.networks.architecture import Conv2d
+    res = {}
+    for side in (True, False):
+        ops.wgrad_side_stream = side
+        try:
+            torch.manual_seed(5)
+            conv = Conv2d(256, 256, 3, padding="same", padding_mode="reflect", bias=False).to(DEV)
+            x = torch.randn(8, 64, 64, 256, device=DEV).bfloat16()
+            g1 = torch.randn(8, 64, 64, 256, device=DEV).bfloat16()
+            g2 = torch.randn(8, 64, 64, 256, device=DEV).bfloat16()
+            conv(x).backward(g1)
+            first = conv.weight.grad
+            conv(x).backward(g2)                 # .grad defined: accumulated in place by AccumulateGrad
+            assert conv.weight.grad is first
+            res[side] = conv.weight.grad.clone()
+        finally:
+            ops.wgrad_side_stream = True
+    assert torch.isfinite(res[True]).all() and torch.equal(res[True], res[False])
 
 
 @pytest.mark.gpu

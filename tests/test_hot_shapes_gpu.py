@@ -33,9 +33,10 @@ def ops():
     return _ops
 
 
-def _counts(reset=True):
+def _counts(reset=True, splitk=False):
+    """launches per MFMA kernel family since the last call (``splitk``: keep the split-K finalize launches too)"""
     from de_i2i_gan_amd import _lib
-    return {k: v for k, v in _lib.launch_counts(reset=reset).items() if v}
+    return {k: v for k, v in _lib.launch_counts(reset=reset).items() if v and (splitk or k != "splitk_finalize")}
 
 
 def rel_l2(a, b):
@@ -70,6 +71,7 @@ HOT = [
     ("D0 3->64 4x4 s2 @256^2 N=64 +LReLU", 3, 64, 4, 2, 1, False, 256, 256, 64, "leaky_relu", "thin_cin", V1, "wgrad_v1"),
     ("D1 64->128 4x4 s2 @128^2 N=64 +LReLU", 64, 128, 4, 2, 1, False, 128, 128, 64, "leaky_relu", "gather_v2", V2, "wgrad_v1"),
     ("D2 128->256 4x4 s2 @64^2 N=64 +LReLU", 128, 256, 4, 2, 1, False, 64, 64, 64, "leaky_relu", "gather_v2", V2, "wgrad_v2"),
+    ("D3 256->512 4x4 s2 @32^2 N=64 +LReLU", 256, 512, 4, 2, 1, False, 32, 32, 64, "leaky_relu", "gather_v2", V2, "wgrad_v2"),
     ("D4 512->1024 4x4 s2 @16^2 N=64 +LReLU", 512, 1024, 4, 2, 1, False, 16, 16, 64, "leaky_relu", "gather_v2", V2, "wgrad_v2"),
     ("D5 1024->2048 4x4 s2 @8^2 N=64 +LReLU", 1024, 2048, 4, 2, 1, False, 8, 8, 64, "leaky_relu", "gather_v1", V2, "wgrad_v1"),
 ]
@@ -134,6 +136,61 @@ def test_hot_shape_conv_fwd_dgrad_wgrad_vs_oracle(ops, case):
     assert c_fwd == {fam_fwd: 1}, ("forward was served by", c_fwd)
     assert c_dgrad == fam_dgrad, ("dgrad was served by", c_dgrad)
     assert c_wgrad == {fam_wgrad: 1}, ("wgrad was served by", c_wgrad)
+
+
+# The small-M GEMMs of the step, all on the generic gather GEMM with split-K slabs + splitk_finalize (conv_gemm.hip: 128 x {32, 64,
+# 128} tiles; fewer tiles than CUs -> the k range is split):  D's two heads on the 64-image batch (discriminator.py:78-98: src_clf
+# 3x3 reflect 2048 -> 1, cls_clf 4x4 valid 2048 -> 6, both on the 4x4 map) and SPADE's table convs on the 5x5 border-class image
+# (normalization.py:17-22 collapsed, DESIGN.md "SPADE collapse": shared 6 -> 128 and gamma|beta 128 -> 2C, 3x3 zero pad, bias; one
+# 5x5 image per label set).
+# (name, cin, cout, k, pad, reflect, H, W, N, bias, act, split-K expected)
+SMALL_M = [
+    ("D src_clf 2048->1 3x3 reflect @4^2 N=64", 2048, 1, 3, 1, True, 4, 4, 64, False, "none", True),
+    ("D cls_clf 2048->6 4x4 valid @4^2 N=64", 2048, 6, 4, 0, False, 4, 4, 64, False, "none", True),
+    ("SPADE shared 6->128 3x3 zero @5^2 N=32 +bias +ReLU", 6, 128, 3, 1, False, 5, 5, 32, True, "relu", False),
+    ("SPADE gamma|beta 128->512 3x3 zero @5^2 N=32 +bias", 128, 512, 3, 1, False, 5, 5, 32, True, "none", True),
+    ("SPADE gamma|beta 128->128 3x3 zero @5^2 N=32 +bias", 128, 128, 3, 1, False, 5, 5, 32, True, "none", True),
+]
+
+
+@pytest.mark.parametrize("case", SMALL_M, ids=[c[0] for c in SMALL_M])
+def test_small_m_shapes_on_the_split_k_gemm_vs_oracle(ops, case):
+    name, cin, cout, k, pad, reflect, H, W, N, has_bias, act, want_split = case
+    prec = ops.BF16
+    torch.manual_seed(301 + [c[0] for c in SMALL_M].index(name))
+    x = torch.randn(N, cin, H, W).bfloat16().float()
+    w = (torch.randn(cout, cin, k, k) * math.sqrt(2.0 / (cin * k * k))).bfloat16().float()
+    b = torch.randn(cout) * 0.1 if has_bias else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y_ref = O.conv2d(xr, wr, stride=1, pad=pad, mode="reflect" if reflect else "zeros")
+    if b is not None:
+        y_ref = y_ref + b.view(1, -1, 1, 1)
+    if act == "relu":
+        y_ref = torch.relu(y_ref)
+    gy = torch.randn(y_ref.shape).bfloat16().float()
+    gx_ref, gw_ref = torch.autograd.grad(y_ref, [xr, wr], gy)
+    xg = ops.to_nhwc(x.to(DEV), prec).requires_grad_(True)
+    wg = w.to(DEV).requires_grad_(True)
+    bg_ = b.to(DEV) if b is not None else None
+    geom = ops.ConvGeom(cin, cout, k, 1, pad, reflect, False)
+    _counts()
+    y = ops.conv2d(xg, wg, bg_, ops.PackedWeights(), geom, act)
+    torch.cuda.synchronize()
+    c_fwd = _counts(splitk=True)
+    gyh = torch.zeros(N, y.shape[1], y.shape[2], prec.pad(cout), dtype=torch.bfloat16, device=DEV)
+    gyh[..., :cout] = gy.to(DEV).permute(0, 2, 3, 1).to(torch.bfloat16)
+    dx, dw = torch.autograd.grad(y, [xg, wg], gyh)
+    torch.cuda.synchronize()
+    c_bwd = _counts(splitk=True)
+    got_y = ops.to_nchw(y, cout)
+    assert got_y.shape == y_ref.shape
+    assert rel_l2(got_y, y_ref.detach()) < 3e-3, ("fwd", rel_l2(got_y, y_ref.detach()))
+    tol = 4e-3 if act == "none" else 1e-2           # fused ReLU: mask from the bf16-rounded output (see the hot-shape test)
+    assert rel_l2(dx[..., :cin].permute(0, 3, 1, 2), gx_ref) < tol, ("dgrad", rel_l2(dx[..., :cin].permute(0, 3, 1, 2), gx_ref))
+    assert rel_l2(dw, gw_ref) < (1e-3 if act == "none" else 1e-2), ("wgrad", rel_l2(dw, gw_ref))
+    assert c_fwd.get("gather_v1") == 1 and (c_fwd.get("splitk_finalize", 0) == 1) == want_split, c_fwd
+    assert set(c_bwd) <= {"gather_v1", "splitk_finalize", "wgrad_v1"}, c_bwd
+    _seen[name] = {"fwd": c_fwd, "bwd": c_bwd}
 
 
 COS_MIN, L2_MAX = {"D": 0.99, "G": 0.95}, {"D": 0.12, "G": 0.30}
@@ -224,3 +281,73 @@ def test_bf16_step_tracks_f32_mode_at_256_batch_16():
                    "fwd_rel_l2": [rel_l2(a, b) for a, b in zip(b_fwd, f_fwd)]}, f, indent=1)
     assert not bad, bad
     assert report["D"]["full_cos"] >= 0.999 and report["G"]["full_cos"] >= 0.999, (report["D"]["full_cos"], report["G"]["full_cos"])
+
+
+def _place(arena, want_bit31, tensors):
+    """Views into ``arena`` holding copies of ``tensors``, back to back from an address whose LOW 32 bits have bit 31 == want_bit31
+    (and stay on that side of the 2 GiB line for all of them)."""
+    base = arena.data_ptr()
+    need = sum((t.numel() * t.element_size() + 4095) // 4096 * 4096 for t in tensors)
+    assert need < (1 << 31)
+    off = (-base) % 4096
+    while True:
+        lo, hi = (base + off) & 0xFFFFFFFF, (base + off + need - 1) & 0xFFFFFFFF
+        if (lo >> 31) == want_bit31 and (hi >> 31) == want_bit31 and hi > lo:
+            break
+        off += ((1 << 31) - (lo & 0x7FFFFFFF))             # to the next 2 GiB line of the low word
+        assert off + need <= arena.numel()
+    out = []
+    for t in tensors:
+        nb = t.numel() * t.element_size()
+        v = arena[off:off + nb].view(t.dtype).view(t.shape)
+        v.copy_(t)
+        assert ((v.data_ptr() & 0xFFFFFFFF) >> 31) == want_bit31
+        out.append(v)
+        off += (nb + 4095) // 4096 * 4096
+    return out
+
+
+def test_operand_addresses_on_both_sides_of_the_2gib_line():
+    """Regression test for a GPU memory-access fault on record (round 2, development build of wgrad_halo's lean LDS-DMA issue
+    path): ``glds16_asm_s`` (csrc/common.h) hands ``global_load_lds_dwordx4`` a wave-uniform 64-bit base in an SGPR pair, built
+    from two ``readfirstlane``s of the pointer's halves -- the builtin returns *int*, and widening the low half as a signed value
+    put 0xffffffff into the high half whenever the operand's low address word had bit 31 set (fault address 0xffff_b1400000).
+    Whether a run hit it depended on where the allocator put the operand.  Here the operands of the kernels that use the helper
+    (wgrad_halo: x and dy; thin_cout: x) and of their siblings (thin_cin) are placed, inside one 5 GiB arena, once at an address
+    whose low word has bit 31 SET and once CLEAR: same bits out, and the oracle's numbers."""
+    from de_i2i_gan_amd import ops
+    prec = ops.BF16
+    arena = torch.empty(5 << 30, dtype=torch.uint8, device=DEV)
+    cases = [("res 256->256 3x3 @64^2 N=8", 256, 256, 3, 1, 64, 64, 8, {"wgrad_halo"}),
+             ("heads 64->4 3x3 @256^2 N=4", 64, 4, 3, 1, 256, 256, 4, {"thin_cout", "thin_cin", "wgrad_halo"}),
+             ("stem 3->64 7x7 @256^2 N=4", 3, 64, 7, 3, 256, 256, 4, {"thin_cin", "thin_cout", "wgrad_thin"})]
+    for name, cin, cout, k, pad, H, W, N, fams in cases:
+        torch.manual_seed(77)
+        x = torch.randn(N, cin, H, W).bfloat16().float()
+        w = (torch.randn(cout, cin, k, k) * math.sqrt(2.0 / (cin * k * k))).bfloat16().float()
+        gy = torch.randn(N, cout, H, W).bfloat16().float()
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        y_ref = O.conv2d(xr, wr, stride=1, pad=pad, mode="reflect")
+        gx_ref, gw_ref = torch.autograd.grad(y_ref, [xr, wr], gy)
+        x_h = ops.to_nhwc(x.to(DEV), prec)
+        g_h = torch.zeros(N, H, W, prec.pad(cout), dtype=torch.bfloat16, device=DEV)
+        g_h[..., :cout] = gy.to(DEV).permute(0, 2, 3, 1).to(torch.bfloat16)
+        geom = ops.ConvGeom(cin, cout, k, 1, pad, True, False)
+        res = {}
+        for bit in (1, 0):
+            xa, ga = _place(arena, bit, [x_h, g_h])
+            xa = xa.detach().requires_grad_(True)
+            wg = w.to(DEV).requires_grad_(True)
+            _counts()
+            y = ops.conv2d(xa, wg, None, ops.PackedWeights(), geom, "none")
+            dx, dw = torch.autograd.grad(y, [xa, wg], ga)
+            torch.cuda.synchronize()
+            ran = _counts()
+            assert fams <= set(ran), (name, bit, ran)
+            res[bit] = (y.detach().clone(), dx.clone(), dw.clone())
+        for a, b in zip(res[1], res[0]):
+            assert torch.equal(a, b), name
+        y, dx, dw = res[1]
+        assert rel_l2(ops.to_nchw(y, cout), y_ref.detach()) < 3e-3, name
+        assert rel_l2(dx[..., :cin].permute(0, 3, 1, 2), gx_ref) < 4e-3, name
+        assert rel_l2(dw, gw_ref) < 1e-3, name

@@ -13,8 +13,8 @@ Tolerances
   feature map within fp32 rounding of 0 for `fake_defects`, so the golden G grad norms are only matched to 15%
   (diagnosed with tools/diag_gstep.py: with identical D inputs the HIP gradient equals the fp64 oracle to 3e-6)."""
 import functools
-
 import json
+import math
 from pathlib import Path
 
 import numpy as np
@@ -184,13 +184,19 @@ def test_two_train_steps_match_reference_goldens(name, pname):
                 m = ref > 1e-4
                 assert np.max(np.abs(gn[m] - ref[m]) / ref[m]) < max(0.15, c.get("tol_gradnorm", 0))   # see module docstring
             else:
+                # coarse guard (see the step-2 comment below); the tight bf16 gradient bounds are the reference-init tests
                 assert np.isfinite(gn).all()
+                m = ref > 1e-4 * ref.max()
+                assert np.max(np.abs(np.log(gn[m] / ref[m]))) < math.log(3.0), float(np.max(np.abs(np.log(gn[m] / ref[m]))))
         L = tr.losses
         got = [L["gan"]["D"][-1], L["clf"]["D"][-1], L["gan"]["G"][-1], L["clf"]["G"][-1], L["aux"]["rec"][-1],
                L["aux"]["cyc"][-1], L["aux"]["con"][-1]]
-        # step 2 sits behind two sign-like Adam updates; in bf16 the formula-filled nets are chaotic on top of that (a
-        # one-ulp difference grows ~4x per res-block layer, tools/diag_first_use.py): measured 0.05..0.22 run to run and
-        # kernel to kernel, so only a coarse bound is meaningful there -- f32 keeps the recorded noise floor
+        # step 2 sits behind two sign-like Adam updates.  f32 keeps the noise floor recorded with the golden.  bf16 on these
+        # formula-filled nets (He-gain weights, 8..16 channels) is a COARSE guard only: the 2^-9 rounding of every stored
+        # activation grows ~4x per res-block layer there (tools/diag_first_use.py), so against the fp32 golden step-2 losses sit
+        # 0.05..0.22 off (the runs themselves are bit-reproducible: tests/test_full_size_gpu.py).  The tight bf16 bound over two
+        # steps -- every BatchNorm buffer, post-Adam parameters, Adam moments -- is test_bf16_two_steps_track_f32_* below, at the
+        # reference's init and default widths.
         tol = ltol if it == 0 else max(c["tol_step2"], 2e-2 if pname == "f32" else 0.4)
         assert maxrel(np.array(got), arr["losses"][it]) < tol, (it, got, arr["losses"][it].tolist())
     # post-step state: Adam moved the parameters, BatchNorm running stats tracked 8 train-mode forwards
@@ -205,10 +211,10 @@ def test_two_train_steps_match_reference_goldens(name, pname):
             if pname == "f32":
                 assert maxrel(sdg[k], arr["bn::" + k]) < c.get("tol_running", 5e-2), k
             elif k.startswith(("stem.", "enc_blk.0.", "enc_blk.1.")):
-                # bf16: the formula-filled nets are chaotic -- a one-ulp difference grows ~4x per res-block layer
-                # (tools/diag_first_use.py t1 bf16: 1e-4 -> 3e-2 over five layers, run to run) -- so the 2^-9 activation
-                # rounding swamps the deep res-block statistics; only the first three BatchNorms are comparable
-                # (measured <= 0.09).  test_bf16_tracks_f32_with_reference_init covers the realistic case.
+                # bf16, coarse guard: on the formula-filled nets the 2^-9 activation rounding grows ~4x per res-block layer
+                # (tools/diag_first_use.py t1: 1e-4 -> 3e-2 over five layers), which swamps the deep res-block statistics; the
+                # first three BatchNorms are comparable with the fp32 golden (measured <= 0.09).  EVERY BatchNorm buffer is held
+                # tightly against the f32 mode in test_bf16_two_steps_track_f32_* (reference init, default widths).
                 assert maxrel(sdg[k], arr["bn::" + k]) < 0.2, k
     for k in ("enc_blk.0.conv_block.0.weight", "src_clf.conv_block.0.weight"):
         mine = sd[k] if k in sd else sd[k + "_orig"]          # spectral convs keep their parameter under key + "_orig"
@@ -238,6 +244,64 @@ def test_bf16_tracks_f32_with_reference_init():
     for i in (1, 2):
         cos = float(torch.dot(a[i], b[i]) / (a[i].norm() * b[i].norm()))
         assert cos > 0.995, (i, cos)
+
+
+def test_bf16_two_steps_track_f32_at_the_reference_init_and_default_widths():
+    """bf16 mode against the exact-f32 mode (the one the reference-generated goldens pin to 1e-4) over TWO full trainer steps
+    (D update, G update, D update, G update) at the reference's init (N(0, 0.02), base_network.py:27-56) and DEFAULT widths
+    (ngf = ndf = 64, hidden_nc = 128), 64 x 64, batch 4 -- step 2 runs on Adam-updated parameters and updated BatchNorm running
+    statistics.  Runs are bit-reproducible, so these are properties of bf16 arithmetic, not noise bands.  Bounds (measured values
+    are written to gpurun_out/bf16_vs_f32_two_steps.json):
+      * the 7 losses of step 1: 1e-3 relative; of step 2: 5e-3 (behind two sign-like Adam updates: |update| ~ lr per element
+        whatever the gradient's size, so a bf16 sign flip of a near-zero gradient element moves a weight by 2 lr);
+      * EVERY BatchNorm running_mean / running_var buffer after the two steps (8 train-mode forwards): 2e-2 of the buffer's max;
+      * every parameter after two Adam updates: |p_bf16 - p_f32| <= 4.4 lr (two updates, each bounded by ~1.1 lr in either mode),
+        relative L2 of the whole parameter vector 2e-3, norms within 1e-4;
+      * Adam's first moments (the gradients' running mean): cosine >= 0.99 per network."""
+    from de_i2i_gan_amd.trainers.defectgan_trainer import DefectGanTrainer
+    c = dict(image_size=64, batch=4, num_layers=4, ngf=64, ndf=64, hidden_nc=128)
+    bg, labels, df = O.synthetic_batch(c["batch"], c["image_size"])
+    res = {}
+    for pname in ("f32", "bf16"):
+        torch.manual_seed(123)
+        tr = DefectGanTrainer(make_opt(c, DEV, pname))
+        G, D = tr.model.netG, tr.model.netD
+        for _ in range(2):
+            tr.step(bg, labels, df)
+        if hasattr(tr, "flush_losses"):
+            tr.flush_losses()
+        L = tr.losses
+        losses = np.array([[L["gan"]["D"][i], L["clf"]["D"][i], L["gan"]["G"][i], L["clf"]["G"][i], L["aux"]["rec"][i],
+                            L["aux"]["cyc"][i], L["aux"]["con"][i]] for i in range(2)])
+        sd = {"G." + k: v.detach().double().cpu() for k, v in G.state_dict().items()}
+        sd.update({"D." + k: v.detach().double().cpu() for k, v in D.state_dict().items()})
+        moments = {}
+        for net in ("G", "D"):
+            st = tr.optimizers[net].state
+            moments[net] = torch.cat([st[p]["exp_avg"].detach().double().cpu().flatten() for p in tr.optimizers[net].param_groups[0]["params"]
+                                      if p in st and "exp_avg" in st[p]])
+        res[pname] = (losses, sd, moments)
+        lr = tr.optimizers["G"].param_groups[0]["lr"]
+    (lf, sf, mf), (lb, sb, mb) = res["f32"], res["bf16"]
+    report = {"loss_rel_step1": float(np.max(np.abs(lb[0] - lf[0]) / np.maximum(np.abs(lf[0]), 1e-3))),
+              "loss_rel_step2": float(np.max(np.abs(lb[1] - lf[1]) / np.maximum(np.abs(lf[1]), 1e-3)))}
+    bn = {k: maxrel(sb[k], sf[k]) for k in sf if "running_" in k}
+    assert len(bn) == 2 * 9, len(bn)                      # stem, two encoder blocks, six res-block convs
+    assert int(sb["G.stem.conv_block.1.num_batches_tracked"]) == int(sf["G.stem.conv_block.1.num_batches_tracked"]) == 8
+    params = [k for k in sf if "running_" not in k and "num_batches" not in k]
+    dmax = max(float((sb[k] - sf[k]).abs().max()) for k in params)
+    va, vb = torch.cat([sb[k].flatten() for k in params]), torch.cat([sf[k].flatten() for k in params])
+    report.update({"bn_buffer_maxrel_worst": max(bn.values()), "bn_buffers": bn, "param_max_abs_diff_over_lr": dmax / lr,
+                   "param_rel_l2": float((va - vb).norm() / vb.norm()),
+                   "param_norm_rel": max(abs(float(sb[k].norm() / sf[k].norm().clamp_min(1e-30)) - 1) for k in params if float(sf[k].norm()) > 0),
+                   "exp_avg_cos": {n: float(torch.dot(mb[n], mf[n]) / (mb[n].norm() * mf[n].norm())) for n in ("G", "D")}})
+    out = Path(__file__).resolve().parents[1] / "gpurun_out"
+    out.mkdir(exist_ok=True)
+    (out / "bf16_vs_f32_two_steps.json").write_text(json.dumps(report, indent=1))
+    assert report["loss_rel_step1"] < 1e-3 and report["loss_rel_step2"] < 5e-3, report
+    assert report["bn_buffer_maxrel_worst"] < 2e-2, bn
+    assert report["param_max_abs_diff_over_lr"] <= 4.4 and report["param_rel_l2"] < 2e-3 and report["param_norm_rel"] < 1e-4, report
+    assert min(report["exp_avg_cos"].values()) > 0.99, report["exp_avg_cos"]
 
 
 def test_bf16_default_widths_against_the_oracle_with_reference_init():
