@@ -67,6 +67,43 @@ DEI2I_D int lds_read32_asm(int addr) {
 }
 DEI2I_D int sw16(int row) { return ((row >> 2) & 1) << 1; }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+DEI2I_D f32x2 bf16x2_unpack(uint32_t u) { return f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
+
+// Column sums of the epilogues: thread tid of the 512 holds NV partial values for the 8-channel chunk (tid % CPR), taken over the
+// rows it wrote back; the sum over the 512 / CPR threads of a chunk goes to out(q, channel) with q = k / 8, channel = 8 * chunk +
+// k % 8.  Lanes of a wave that share a chunk are CPR apart: butterfly over those lane bits (ds_bpermute), then the 8 waves'
+// sums through `scratch` (8 * CPR * NV floats) in wave order -- ONE barrier, ~NV / 4 LDS writes and 8 reads per thread (the rounds
+// of 32-row column sums this replaces: 4 NV-float writes + 32 reads per output and two barriers per 16 values).  Fixed order:
+// the result does not depend on timing.  `store(q, c, sum)` writes one output; the caller syncs before `scratch` is reused.
+template <int NV, int CPR, typename Store>
+DEI2I_D void reduce_rows16(float (&v)[NV], float* __restrict__ scratch, int tid, Store store) {
+  static_assert(NV % 8 == 0 && (CPR == 16 || CPR == 8), "layout");
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    float t = v[k];
+    if constexpr (CPR == 8) t += __shfl_xor(t, 8, 64);
+    t += __shfl_xor(t, 16, 64);
+    t += __shfl_xor(t, 32, 64);
+    v[k] = t;
+  }
+  if (lane < CPR) {
+    float* mine = scratch + ((size_t)wave * CPR + lane) * NV;
+#pragma unroll
+    for (int k = 0; k < NV; k += 4) *reinterpret_cast<f32x4*>(mine + k) = f32x4{v[k], v[k + 1], v[k + 2], v[k + 3]};
+  }
+  __syncthreads();
+  for (int o = tid; o < CPR * NV; o += 512) {
+    const int q = o / (CPR * 8), c = o % (CPR * 8);
+    const float* col = scratch + (size_t)(c >> 3) * NV + q * 8 + (c & 7);
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) sum += col[(size_t)w * CPR * NV];
+    store(q, c, sum);
+  }
+}
+
 // DIAG: a diagnostic build (option "v2_ablate" = 6) that accumulates s_memtime stamps per wave into `dbg`:
 //   [0] loop cycles  [1] loop s_memrealtime ticks  [2] k-steps  [3] whole-kernel cycles
 //   [4] M: fragment reads issued  [5] M: vmcnt wait  [6] M: lgkmcnt wait  [7] M: barrier  [8] C: MFMA + DMA issue  [9] C: barrier
@@ -657,20 +694,25 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
   // statistics: one record per 8 x 32 half tile, i.e. the record grid of the 8 x 32 tile kernel (conv_halo.hip) and of
   // dei2i_conv2d_stats_chunks: record (2 * tile_row + half, tile_col) of the image
   const int rec0 = img * (2 * tiles_y * tiles_x) + (2 * (trem / tiles_x)) * tiles_x + (trem % tiles_x);
-  // EPIN: the per-channel coefficients of this thread's 8 channels -- kind 1: mean | rstd of the image; kind 2: a | b | mean | rstd
-  float nc[EPIN ? 4 : 1][8];
+  // EPIN: the per-channel coefficients of this thread's 8 channels as 4 pairs (packed fp32 arithmetic below) -- kind 1: mean | rstd
+  // of the image; kind 2: a | b | mean | rstd
+  f32x2 nc[EPIN ? 4 : 1][4];
   u32x4 gmi = {0u, 0u, 0u, 0u}, bti = {0u, 0u, 0u, 0u};      // kind 1: gamma | beta of the interior class (2, 2), packed
   if constexpr (EPIN) {
     if (ncol < ldc) {
+      auto ld8 = [&](const float* q, f32x2 (&d)[4]) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(q), hi = *reinterpret_cast<const f32x4*>(q + 4);
+        d[0] = f32x2{lo.x, lo.y}; d[1] = f32x2{lo.z, lo.w}; d[2] = f32x2{hi.x, hi.y}; d[3] = f32x2{hi.z, hi.w};
+      };
       if ((en.kind & 0xff) == 1) {
-        ldcoef<8>(en.mean + (size_t)img * ldc + ncol, nc[0]);
-        ldcoef<8>(en.rstd + (size_t)img * ldc + ncol, nc[1]);
+        ld8(en.mean + (size_t)img * ldc + ncol, nc[0]);
+        ld8(en.rstd + (size_t)img * ldc + ncol, nc[1]);
         const bf16_t* gp = en.gb + ((size_t)(img * 5 + 2) * 5 + 2) * 2 * ldc + ncol;
         gmi = *reinterpret_cast<const u32x4*>(gp);
         bti = *reinterpret_cast<const u32x4*>(gp + ldc);
       } else {
-        ldcoef<8>(en.a + ncol, nc[0]); ldcoef<8>(en.b + ncol, nc[1]);
-        ldcoef<8>(en.mean + ncol, nc[2]); ldcoef<8>(en.rstd + ncol, nc[3]);
+        ld8(en.a + ncol, nc[0]); ld8(en.b + ncol, nc[1]);
+        ld8(en.mean + ncol, nc[2]); ld8(en.rstd + ncol, nc[3]);
       }
     }
   }
@@ -693,14 +735,18 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
     __syncthreads();
     stage_acc(smem + (wm >> 1) * HALF_BYTES);
   }
+  // EPIN: this thread's 8 channels (4 pairs) x the (up to) 4 sums of the norm's backward, over BOTH halves of the tile: one record
+  // per 16 x 32 tile (dei2i_conv2d_dgrad_norm_chunks), reduced once after the write-back
+  f32x2 ep[EPIN ? 4 : 1][4];
+#pragma unroll
+  for (int q = 0; q < (EPIN ? 4 : 1); ++q)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ep[q][k] = f32x2{0.f, 0.f};
 #pragma unroll 1
   for (int half = 0; half < 2; ++half) {
     float st8[16];                        // sum (0..7) / sum of squares (8..15) of this thread's 8 channels
 #pragma unroll
     for (int k = 0; k < 16; ++k) st8[k] = 0.f;
-    float ep[EPIN ? 32 : 1];              // EPIN: this thread's 8 channels x the (up to) 4 sums of the norm's backward
-#pragma unroll
-    for (int k = 0; k < (EPIN ? 32 : 1); ++k) ep[k] = 0.f;
     // EPIN: this half's x rows of the thread (one 16-byte load per write-back pass) are requested HERE, ahead of the barriers and
     // the ring / corner work on the staged tile, so their HBM latency is off the write-back's path
     constexpr int NPASS = 256 / RPP;
@@ -791,13 +837,11 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
         }
         if constexpr (EPIN) {
           // v = dL/dz of 8 channels of pixel (py, px), as the streaming pass would read it back (bf16): the same per-element
-          // arithmetic as spade_bwd_partial_kernel / bn_bwd_partial_kernel (reduce.hip)
+          // arithmetic as spade_bwd_partial_kernel / bn_bwd_partial_kernel (reduce.hip), on channel PAIRS (v_pk_*_f32)
           const int py = y0 + half * 8 + (row >> 5), px = x0 + (row & 31);
-          float d8[8], x8[8];
-          Elem<bf16_t>::unpack(v, d8);
-          Elem<bf16_t>::unpack(xq[p], x8);
+          const uint32_t dw[4] = {v.x, v.y, v.z, v.w}, xw[4] = {xq[p].x, xq[p].y, xq[p].z, xq[p].w};
           if (en.kind & 0x100) {                         // (timing only, tools/diag_epin.py: no arithmetic -- the loads stay live)
-            ep[0] += x8[0] + d8[0];
+            ep[0][0] += bf16x2_unpack(xw[0]) + bf16x2_unpack(dw[0]);
           } else if ((en.kind & 0xff) == 1) {
             const int cy = border_class(py, g.Ho), cx = border_class(px, g.Wo);
             const bool interior = cy == 2 && cx == 2;
@@ -807,67 +851,57 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
               gq = *reinterpret_cast<const u32x4*>(gp);
               bq2 = *reinterpret_cast<const u32x4*>(gp + ldc);
             }
-            float gm[8], bt[8];
-            Elem<bf16_t>::unpack(gq, gm);
-            Elem<bf16_t>::unpack(bq2, bt);
+            const uint32_t gw[4] = {gq.x, gq.y, gq.z, gq.w}, bw[4] = {bq2.x, bq2.y, bq2.z, bq2.w};
+            const float inm = interior ? 1.f : 0.f;      // the interior class's d gamma, d beta come from here; the frame's classes
+            const f32x2 inm2 = {inm, inm};               // from spade_bwd_border_kernel
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const float xh = (x8[e] - nc[0][e]) * nc[1][e];
-              const float gg = fmaf(xh, 1.f + gm[e], bt[e]) > 0.f ? d8[e] : 0.f;
-              const float dxh = gg * (1.f + gm[e]);
-              ep[e] += dxh;
-              ep[8 + e] = fmaf(dxh, xh, ep[8 + e]);
-              if (interior) { ep[16 + e] += gg * xh; ep[24 + e] += gg; }
+            for (int e = 0; e < 4; ++e) {
+              const f32x2 d2 = bf16x2_unpack(dw[e]);
+              const f32x2 xh = (bf16x2_unpack(xw[e]) - nc[0][e]) * nc[1][e];
+              const f32x2 g1 = bf16x2_unpack(gw[e]) + f32x2{1.f, 1.f};
+              const f32x2 z = __builtin_elementwise_fma(xh, g1, bf16x2_unpack(bw[e]));
+              const f32x2 gg = {z.x > 0.f ? d2.x : 0.f, z.y > 0.f ? d2.y : 0.f};
+              const f32x2 dxh = gg * g1;
+              ep[0][e] += dxh;
+              ep[1][e] = __builtin_elementwise_fma(dxh, xh, ep[1][e]);
+              const f32x2 gi = gg * inm2;
+              ep[2][e] = __builtin_elementwise_fma(gi, xh, ep[2][e]);
+              ep[3][e] += gi;
             }
           } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const float gg = d8[e] * act_grad_from_out(fmaf(nc[0][e], x8[e], nc[1][e]), en.act);
-              ep[e] += gg;
-              ep[8 + e] = fmaf(gg, (x8[e] - nc[2][e]) * nc[3][e], ep[8 + e]);
+            for (int e = 0; e < 4; ++e) {
+              const f32x2 x2 = bf16x2_unpack(xw[e]);
+              const f32x2 zz = __builtin_elementwise_fma(nc[0][e], x2, nc[1][e]);
+              const f32x2 gg = bf16x2_unpack(dw[e]) * f32x2{act_grad_from_out(zz.x, en.act), act_grad_from_out(zz.y, en.act)};
+              ep[0][e] += gg;
+              ep[1][e] = __builtin_elementwise_fma(gg, (x2 - nc[2][e]) * nc[3][e], ep[1][e]);
             }
           }
         }
       }
     }
-    if constexpr (EPIN) {                                // per-thread partials -> LDS -> ordered sums, 16 values per round
-      float* mine = red + ((size_t)rsub * CPR + chunk) * 16;
-      const int nq = (en.kind & 0xff) == 1 ? 4 : 2;
-      for (int round = 0; round < ((en.kind & 0x200) ? 0 : nq / 2); ++round) {      // (0x200: timing only, no reduction)
-        __syncthreads();                                 // (round 0: the write-back's reads of the rows `red` reuses)
-#pragma unroll
-        for (int k = 0; k < 16; k += 4) {
-          f32x4 t;
-          t.x = round ? ep[16 + k] : ep[k]; t.y = round ? ep[17 + k] : ep[k + 1];
-          t.z = round ? ep[18 + k] : ep[k + 2]; t.w = round ? ep[19 + k] : ep[k + 3];
-          *reinterpret_cast<f32x4*>(mine + k) = t;
-        }
-        __syncthreads();
-        for (int o = tid; o < CPR * 16; o += 512) {
-          const int ch = o >> 4, k = o & 15;
-          float sum = 0.f;
-          for (int r = 0; r < RPP; ++r) sum += red[((size_t)r * CPR + ch) * 16 + k];
-          const int c = n0 + ch * 8 + (k & 7);
-          if (c < ldc) en.partial[((size_t)(rec0 + half * tiles_x) * nq + 2 * round + (k >> 3)) * ldc + c] = sum;
-        }
-      }
+    if (!EPIN && stats != nullptr) {                     // kernel-uniform: wave butterflies -> LDS -> the 8 waves' sums in order
+      float* const srow = stats + (size_t)(rec0 + half * tiles_x) * 2 * ldc;
+      reduce_rows16<16, CPR>(st8, red, tid, [&](int q, int c, float sum) {
+        if (n0 + c < ldc) srow[(size_t)q * ldc + n0 + c] = sum;
+      });
     }
-    if (!EPIN && stats != nullptr) {                     // kernel-uniform: per-thread partials -> LDS -> ordered sums
-      float* mine = red + ((size_t)rsub * CPR + chunk) * 16;
+  }
+  if constexpr (EPIN) {
+    // (the reduction scratch is the first rows of half 0's staged tile: every wave is past them since the barrier at the top of
+    //  half 1; one record per TILE)
+    const int nq = (en.kind & 0xff) == 1 ? 4 : 2;
+    if (!(en.kind & 0x200)) {                            // (0x200: timing only, no reduction)
+      float* const prow = en.partial + (size_t)(img * (tiles_y * tiles_x) + trem) * nq * ldc;
+      float flat[32];
 #pragma unroll
-      for (int k = 0; k < 16; k += 4) {
-        f32x4 t;
-        t.x = st8[k]; t.y = st8[k + 1]; t.z = st8[k + 2]; t.w = st8[k + 3];
-        *reinterpret_cast<f32x4*>(mine + k) = t;
-      }
-      __syncthreads();
-      for (int o = tid; o < CPR * 16; o += 512) {
-        const int ch = o >> 4, k = o & 15;
-        float sum = 0.f;
-        for (int r = 0; r < RPP; ++r) sum += red[((size_t)r * CPR + ch) * 16 + k];
-        const int c = n0 + ch * 8 + (k & 7);
-        if (c < ldc) stats[((size_t)(rec0 + half * tiles_x) * 2 + (k >> 3)) * ldc + c] = sum;
-      }
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { flat[q * 8 + 2 * k] = ep[q][k].x; flat[q * 8 + 2 * k + 1] = ep[q][k].y; }
+      reduce_rows16<32, CPR>(flat, reinterpret_cast<float*>(smem), tid, [&](int q, int c, float sum) {
+        if (q < nq && n0 + c < ldc) prow[(size_t)q * ldc + n0 + c] = sum;
+      });
     }
   }
   if (DIAG && drec != nullptr) {

@@ -64,26 +64,44 @@ def apply_mask_token(token: Optional[Tensor], imgs: Tensor, masks: Tensor, kind:
 # --------------------------------------------------------------------------- #
 # losses (models/defectgan_model.py:106-171, 361-383)
 # --------------------------------------------------------------------------- #
-def repair(SG, token, imgs, labels, masks, cfg, kind, mask_ratio, training):
+def repair(SG, token, imgs, labels, masks, cfg, kind, mask_ratio, training, SE=None):
+    """_repair_mask (defectgan_model.py:361-383).  spade: the (N, label_nc, 1, 1) label map; sean (:370-372): the labels as they
+    are plus the style embeddings drawn for them -- ``SE`` = (embeddings dict, the ``random`` module they are drawn with)."""
+    masked = apply_mask_token(token, imgs, masks, kind, mask_ratio)
+    if cfg.style_norm == "sean":
+        feat = O.get_style_embeds(SE[0], labels, cfg, SE[1]) if SE is not None else None       # (--sean_alpha 0: no embeddings)
+        pred, _ = O.generator_forward(SG, masked, labels, cfg, training=training, style_feat=feat)
+        return pred
     seg = labels.reshape(labels.shape[0], labels.shape[1], 1, 1)
-    pred, _ = O.generator_forward(SG, apply_mask_token(token, imgs, masks, kind, mask_ratio), seg, cfg, training=training)
+    pred, _ = O.generator_forward(SG, masked, seg, cfg, training=training)
     return pred
 
 
-def mae_generator_losses(SG, SD, token, imgs, labels, masks, cfg, kind="position", mask_ratio=0.75, split_training=False):
+def mae_generator_losses(SG, SD, token, imgs, labels, masks, cfg, kind="position", mask_ratio=0.75, split_training=False, SE=None):
     """_compute_mae_generator_loss (defectgan_model.py:106-131), G in train mode, D in eval mode -> (rec, gan, clf);
-    --split_training (:119-120): G only sees the L1 loss, (rec, 0, 0)."""
-    pred = repair(SG, token, imgs, labels, masks, cfg, kind, mask_ratio, training=True)
+    --split_training (:119-120): G only sees the L1 loss, (rec, 0, 0).  sean + --style_distill (:108-114,127-128): the SEAN layers'
+    distillation terms are collected over the ONE repair pass -> (rec, gan, clf, mean latent term, mean embed term, the sum every
+    layer back-propagated inside its own forward: normalization.py:181-190)."""
+    distill = cfg.style_norm == "sean" and cfg.style_distill
+    if distill:
+        O.SEAN_CTX.distill = {"latent": [], "embed": [], "backward": []}
+    try:
+        pred = repair(SG, token, imgs, labels, masks, cfg, kind, mask_ratio, training=True, SE=SE)
+    finally:
+        collected, O.SEAN_CTX.distill = O.SEAN_CTX.distill, None
     rec = O.l1(pred, imgs)
     if split_training:
         return rec, torch.zeros([]), torch.zeros([])
     src, cls = O.discriminator_forward(SD, pred, cfg)
     gan = O.bce_logits(src, torch.ones_like(src))
     clf = O.bce_logits(cls, labels.view_as(cls))
+    if distill:
+        return (rec, gan, clf, torch.stack(collected["latent"]).mean(), torch.stack(collected["embed"]).mean(),
+                torch.stack(collected["backward"]).sum())
     return rec, gan, clf
 
 
-def mae_discriminator_losses(SG, SD, token, imgs, labels, masks, cfg, kind="position", mask_ratio=0.75, split_training=False):
+def mae_discriminator_losses(SG, SD, token, imgs, labels, masks, cfg, kind="position", mask_ratio=0.75, split_training=False, SE=None):
     """_compute_mae_discriminator_loss (defectgan_model.py:150-171), G in eval mode under no_grad -> (gan, clf);
     --split_training (:157-158): only the classifier loss on the real images, (0, clf) -- no mask is drawn."""
     real_src, real_cls = O.discriminator_forward(SD, imgs, cfg)
@@ -91,7 +109,7 @@ def mae_discriminator_losses(SG, SD, token, imgs, labels, masks, cfg, kind="posi
     if split_training:
         return torch.zeros([]), clf
     with torch.no_grad():
-        pred = repair(SG, token, imgs, labels, masks, cfg, kind, mask_ratio, training=False)
+        pred = repair(SG, token, imgs, labels, masks, cfg, kind, mask_ratio, training=False, SE=SE)
     fake_src, _ = O.discriminator_forward(SD, pred.detach(), cfg)
     gan = torch.stack([O.bce_logits(fake_src, torch.zeros_like(fake_src)), O.bce_logits(real_src, torch.ones_like(real_src))]).mean()
     return gan, clf
@@ -122,14 +140,14 @@ def adamw_update(S: Dict[str, Tensor], grads: Dict[str, Optional[Tensor]], st: O
 
 
 def step(SG, SD, token: Dict[str, Tensor], stG, stD, imgs, labels, masks_d, masks_g, cfg, *, lr=1.5e-4,
-         loss_weight=(10, 3, 1), kind="position", mask_ratio=0.75, split_training=False):
+         loss_weight=(10, 3, 1), kind="position", mask_ratio=0.75, split_training=False, SE=None, before_g=None):
     """One MAE iteration (mae_trainer.py:97-99, 124-158): D update, then G (+ mask token) update.  ``token`` is a
     one-entry dict {'mask_token': tensor} (empty for the parameter-free kinds) so it shares the Adam bookkeeping."""
     w_rec, w_clf_d, w_clf_g = loss_weight
     tok = token.get("mask_token")
     for k in O.param_keys(SD):
         SD[k].requires_grad_(True)
-    d_gan, d_clf = mae_discriminator_losses(SG, SD, tok, imgs, labels, masks_d, cfg, kind, mask_ratio, split_training)
+    d_gan, d_clf = mae_discriminator_losses(SG, SD, tok, imgs, labels, masks_d, cfg, kind, mask_ratio, split_training, SE=SE)
     gD = O._grads(d_gan + d_clf * w_clf_d, SD)
     adamw_update(SD, gD, stD, lr)
     for k in O.param_keys(SG):
@@ -138,13 +156,21 @@ def step(SG, SD, token: Dict[str, Tensor], stG, stD, imgs, labels, masks_d, mask
         tok.requires_grad_(True)
     for k in O.param_keys(SD):
         SD[k].requires_grad_(False)
-    rec, gan, clf = mae_generator_losses(SG, SD, tok, imgs, labels, masks_g, cfg, kind, mask_ratio, split_training)
+    if before_g is not None:          # (a fixture re-seeds the embeddings' RNG between the two updates, like its reference run)
+        before_g()
+    out = mae_generator_losses(SG, SD, tok, imgs, labels, masks_g, cfg, kind, mask_ratio, split_training, SE=SE)
+    rec, gan, clf = out[:3]
     g_loss = gan + rec * w_rec + clf * w_clf_g
     both = dict(SG)
     if tok is not None:
         both["mask_token"] = tok
-    gG = O._grads(g_loss, both)
+    # --style_distill: the layers' own (0.1 KL_latent + KL_embed).backward() calls land in the same .grad fields (un-scaled;
+    # mae_trainer.py:129 leaves the logged terms out of g_loss)
+    gG = O._grads(g_loss + out[5] if len(out) == 6 else g_loss, both)
     adamw_update(both, gG, stG, lr)
     for k in O.param_keys(SD):
         SD[k].requires_grad_(True)
-    return {"d_gan": float(d_gan), "d_clf": float(d_clf), "g_rec": float(rec), "g_gan": float(gan), "g_clf": float(clf)}, gD, gG
+    losses = {"d_gan": float(d_gan), "d_clf": float(d_clf), "g_rec": float(rec), "g_gan": float(gan), "g_clf": float(clf)}
+    if len(out) == 6:
+        losses.update(distill_latent=float(out[3]), distill_embed=float(out[4]))
+    return losses, gD, gG

@@ -66,5 +66,10 @@ def test_the_one_gpu_bench_line_keeps_the_drivers_contract():
     rf = line["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.2 < rf["frac"] < 1.0
-    assert rf["launches_per_step"] > 0 and rf["event_bracketed_launches"] > 0
+    # the dominant instance kernel-alone (extra serial steps), the other instance, and the forward instance sampled in the timed region
+    assert rf["launches_per_step"] > 0 and rf["avg_launch_ms"] > 0 and "kernel-alone" in rf["timing"]
+    assert rf["other_instance"]["launches_per_step"] > 0 and rf["ms_per_step"] >= rf["other_instance"]["ms_per_step"]
+    assert rf["forward_instance_in_timed_region"]["event_bracketed_launches"] > 0
+    for k in ("defer_loss_sync", "discriminator_passes", "eval_generator_passes_in_d_step", "d_weight_gradients_in_g_step"):
+        assert k in line["config"]
     assert all(v == v for v in line["losses_last_step"].values())

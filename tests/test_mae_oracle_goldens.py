@@ -1,6 +1,7 @@
 """CPU: the MAE-stage oracle (oracle/mae_oracle.py) against the fixtures captured from the reference's MAETrainer
 (tests/golden/gen_mae_goldens.py) -- masks from the same seeded RNG, two D+G iterations."""
 import json
+import random
 from pathlib import Path
 
 import numpy as np
@@ -11,14 +12,17 @@ from oracle import defectgan_oracle as O
 from oracle import mae_oracle as M
 
 GOLD = Path(__file__).resolve().parent / "golden"
-NAMES = ["m0_img32_b2_position", "m1_img64_b2_vector", "m2_img32_b2_split"]        # m2: --split_training
+NAMES = ["m0_img32_b2_position", "m1_img64_b2_vector", "m2_img32_b2_split",         # m2: --split_training
+         "m3_img64_b2_sean_distill"]                                                # m3: SEAN blocks + --style_distill
 
 
 def load(name):
     meta = json.loads((GOLD / f"{name}.json").read_text())
     arr = np.load(GOLD / f"{name}.npz")
     c = meta["config"]
-    cfg = O.Cfg(image_size=c["image_size"], ngf=c["ngf"], ndf=c["ndf"], num_layers=c["num_layers"], hidden_nc=c["hidden_nc"])
+    sean = dict(style_norm="sean", embed_nc=c["embed_nc"], num_embeds=c["num_embeds"], style_distill=bool(c.get("style_distill"))) \
+        if c.get("style_norm") == "sean" else {}
+    cfg = O.Cfg(image_size=c["image_size"], ngf=c["ngf"], ndf=c["ndf"], num_layers=c["num_layers"], hidden_nc=c["hidden_nc"], **sean)
     return meta, arr, c, cfg
 
 
@@ -30,6 +34,9 @@ def test_mae_two_iterations_match_reference(name):
     token = {"mask_token": O.formula_tensor("mask_token", M.mask_token_shape(c["mask_token_type"], 3, c["image_size"])) * 0.25}
     imgs, labels, _ = O.synthetic_batch(c["batch"], c["image_size"])
     stG, stD = O.AdamState(), O.AdamState()
+    sean = cfg.style_norm == "sean"
+    O.SEAN_CTX.reset()
+    SE = (O.synthetic_embeddings(cfg), random) if sean else None       # the embeddings file of the fixture, drawn with ``random``
     torch.manual_seed(meta["seed"])
     got = []
     for it in range(2):
@@ -37,12 +44,16 @@ def test_mae_two_iterations_match_reference(name):
         md = None if split else M.generate_shifted_mask(tuple(imgs.shape), c["patch_size"], c["mask_ratio"])
         mg = M.generate_shifted_mask(tuple(imgs.shape), c["patch_size"], c["mask_ratio"])
         assert [0.0 if split else float(md.sum()), float(mg.sum())] == arr["mask_sums"][it].tolist()          # the reference's masks
+        random.seed(meta["seed"] + 10 * it + 1)
         ol, _, _ = M.step(SG, SD, token, stG, stD, imgs, labels, md, mg, cfg, lr=meta["lr_effective"],
-                          kind=c["mask_token_type"], mask_ratio=c["mask_ratio"], split_training=split)
-        got.append([ol[k] for k in ("d_gan", "d_clf", "g_rec", "g_gan", "g_clf")])
+                          kind=c["mask_token_type"], mask_ratio=c["mask_ratio"], split_training=split, SE=SE,
+                          before_g=lambda it=it: random.seed(meta["seed"] + 10 * it + 2))
+        got.append([ol[k] for k in ("d_gan", "d_clf", "g_rec", "g_gan", "g_clf")] +
+                   ([ol["distill_latent"], ol["distill_embed"]] if sean and cfg.style_distill else []))
     ref = arr["losses"]
-    assert np.abs(np.array(got[0]) - ref[0]).max() < 1e-5
-    assert np.abs(np.array(got[1]) - ref[1]).max() < 5e-3           # behind sign-like first AdamW steps
+    scale = np.maximum(np.abs(ref), 1.0)                # (the embed distillation term is O(500): relative there)
+    assert (np.abs(np.array(got[0]) - ref[0]) / scale[0]).max() < 1e-5
+    assert (np.abs(np.array(got[1]) - ref[1]) / scale[1]).max() < 5e-3           # behind sign-like first AdamW steps
     assert np.abs(token["mask_token"].detach().numpy() - arr["mask_token_post"]).max() < 2e-3
 
 
