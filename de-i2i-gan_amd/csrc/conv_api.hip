@@ -483,7 +483,7 @@ static bool dgrad_norm_shape_ok(const dei2i_conv* c) {
 
 int dei2i_conv2d_dgrad_norm_supported(const dei2i_conv* c) { return dgrad_norm_shape_ok(c) ? 1 : 0; }
 
-int dei2i_conv2d_dgrad_norm_chunks(const dei2i_conv* c) { return (c->H / 8) * (c->W / 32); }
+int dei2i_conv2d_dgrad_norm_chunks(const dei2i_conv* c) { return (c->H / 16) * (c->W / 32); }    // one record per 16 x 32 tile
 
 int dei2i_conv2d_dgrad_input_norm(const dei2i_conv* c, const void* dy, const void* wd_packed, void* dx, const dei2i_epi_norm* en,
                                   dei2i_stream s) {

@@ -677,18 +677,19 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
 
   }
 
-  // ---- epilogue, in two halves of 8 tile rows: stage the half as bf16 [pixel][BN (+8 pad)] (8-byte writes: a lane
-  //      holds 4 consecutive channels of its pixel), write back with 16-byte stores ----
-  // (EPIN: BOTH halves are staged up front -- the loop's buffers are dead, 512 rows fit -- so that no accumulator is live while
-  //  the write-back passes carry the 32 sums of the norm's backward; the reduction scratch then reuses the first half's rows)
+  // ---- epilogue: the whole 16 x 32 tile is staged as bf16 [pixel][BN (+8 pad)] (8-byte writes: a lane holds 4 consecutive
+  //      channels of its pixel) -- the loop's buffers are dead, 512 rows fit --, FOLD launches add the reflect ring and the frame
+  //      corners to the staged rows, then 16 write-back passes of 16-byte stores run without a barrier between them (round 2 staged
+  //      and wrote 8 rows at a time: three barriers per half, half of the waves idle while the other half staged) ----
   constexpr int CROW = BN * 2 + 16;
   constexpr int HALF_BYTES = 256 * CROW;
-  unsigned char* ctile = smem;
-  float* const red = reinterpret_cast<float*>(EPIN ? smem : smem + HALF_BYTES);
-  float* const cred = reinterpret_cast<float*>(smem + (EPIN ? 2 : 1) * HALF_BYTES);
+  unsigned char* const ctile = smem;
+  float* const cred = reinterpret_cast<float*>(smem + 2 * HALF_BYTES);            // corner dot products: 4 x BN floats
+  float* const rscr = cred + 4 * BN;                                              // reduce_rows16 scratch: 8 x (BN / 8) x 32 floats
   const float slope = act_slope(act);
   constexpr int CPR = BN / 8;             // 16-byte chunks per tile row
   constexpr int RPP = 512 / CPR;          // rows per pass
+  constexpr int NPASS = 512 / RPP;        // write-back passes over the tile (8-row half h = passes [h * NPASS / 2, (h + 1) * NPASS / 2))
   const int chunk = tid % CPR, rsub = tid / CPR;
   const int ncol = n0 + chunk * 8;
   // statistics: one record per 8 x 32 half tile, i.e. the record grid of the 8 x 32 tile kernel (conv_halo.hip) and of
@@ -698,6 +699,7 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
   // of the image; kind 2: a | b | mean | rstd
   f32x2 nc[EPIN ? 4 : 1][4];
   u32x4 gmi = {0u, 0u, 0u, 0u}, bti = {0u, 0u, 0u, 0u};      // kind 1: gamma | beta of the interior class (2, 2), packed
+  u32x4 xq[EPIN ? NPASS : 1];
   if constexpr (EPIN) {
     if (ncol < ldc) {
       auto ld8 = [&](const float* q, f32x2 (&d)[4]) {
@@ -716,129 +718,123 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
       }
     }
   }
-  auto stage_acc = [&](unsigned char* const stage) {
+  __syncthreads();                        // every wave is out of the loop's LDS buffers
 #pragma unroll
-    for (int j = 0; j < CB; ++j) {
-      const int col0 = wn * WTN + j * 16 + 4 * kg;
-      float bq[4];
-      uint32_t m01, m23;
-      epi_col_consts(bias, n0 + col0, wrows, bq, m01, m23);
+  for (int j = 0; j < CB; ++j) {
+    const int col0 = wn * WTN + j * 16 + 4 * kg;
+    float bq[4];
+    uint32_t m01, m23;
+    epi_col_consts(bias, n0 + col0, wrows, bq, m01, m23);
 #pragma unroll
-      for (int i = 0; i < PB; ++i) {
-        const int row = ((wm & 1) * 4 + (i >> 1)) * 32 + (i & 1) * 16 + l16;
-        *reinterpret_cast<u32x2*>(stage + row * CROW + col0 * 2) =
-            epi_finish4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3], bq, slope, m01, m23);
+    for (int i = 0; i < PB; ++i) {
+      const int row = (wm * 4 + (i >> 1)) * 32 + (i & 1) * 16 + l16;
+      *reinterpret_cast<u32x2*>(ctile + row * CROW + col0 * 2) =
+          epi_finish4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3], bq, slope, m01, m23);
+    }
+  }
+  if constexpr (EPIN) {
+    // the thread's x rows (one 16-byte load per write-back pass), ALL of them, requested here -- the accumulators are dead --
+    // ahead of the barriers and the ring / corner work on the staged tile: their HBM latency is off the write-back's path
+    if (ncol < ldc) {
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p) {
+        const int row = p * RPP + rsub;
+        const int py = y0 + (row >> 5), px = x0 + (row & 31);
+        const size_t xpix = ((size_t)(img * (g.Ho >> en.up) + (py >> en.up))) * (g.Wo >> en.up) + (px >> en.up);
+        xq[p] = *reinterpret_cast<const u32x4*>(en.x + xpix * ldc + ncol);
       }
     }
-  };
-  if constexpr (EPIN) {
-    __syncthreads();
-    stage_acc(smem + (wm >> 1) * HALF_BYTES);
   }
-  // EPIN: this thread's 8 channels (4 pairs) x the (up to) 4 sums of the norm's backward, over BOTH halves of the tile: one record
-  // per 16 x 32 tile (dei2i_conv2d_dgrad_norm_chunks), reduced once after the write-back
+  __syncthreads();
+  if constexpr (FOLD) {
+    // the ring's reflection: row ring -> tile row 1 (top) / 14 (bottom), then -- after a barrier: pixel (1,1) takes both --
+    // column ring -> column 1 (left) / 30 (right) of each row
+    auto ring_add = [&](int row) {
+#pragma unroll
+      for (int j = 0; j < CB; ++j) {
+        u32x2* p = reinterpret_cast<u32x2*>(ctile + row * CROW + (wn * WTN + j * 16 + 4 * kg) * 2);
+        const u32x2 v = *p;
+        u32x2 o;
+        o.x = (uint32_t)f32_to_bf16(__uint_as_float(v.x << 16) + racc[j][0]) |
+              ((uint32_t)f32_to_bf16(__uint_as_float(v.x & 0xffff0000u) + racc[j][1]) << 16);
+        o.y = (uint32_t)f32_to_bf16(__uint_as_float(v.y << 16) + racc[j][2]) |
+              ((uint32_t)f32_to_bf16(__uint_as_float(v.y & 0xffff0000u) + racc[j][3]) << 16);
+        *p = o;
+      }
+    };
+    if (ring_kind == 1 || ring_kind == 2) ring_add((ring_kind == 1 ? 1 : H16_TH - 2) * 32 + wm * 16 + l16);
+    __syncthreads();
+    if (ring_kind >= 3) ring_add(l16 * 32 + (ring_kind == 3 ? 1 : H16_TW - 2));
+    // the frame's CORNER pixels this tile holds the image of: frame (-1,-1) is read by output (0,0) only, through kernel tap
+    // (0,0), and reflects onto input pixel (1,1): dx[1][1] += W[:,:,0,0]^T dy[0][0]; likewise (-1,W) -> dx[1][W-2] through
+    // tap (0,2) with dy[0][W-1], (H,-1) -> dx[H-2][1] through (2,0) with dy[H-1][0], (H,W) -> dx[H-2][W-2] through (2,2)
+    // with dy[H-1][W-1].  One dot product of length Cs per output channel: 4 threads per channel, summed through LDS.
+    // (a tile is at most 16 rows of the >= 32-row image: it holds the top OR the bottom corner of a side, never both)
+    const bool lef = x0 == 0, rig = x0 + H16_TW == g.Wo, top = y0 == 0, bot = y0 + H16_TH == g.Ho;
+    const bool has = (top || bot) && (lef || rig);      // workgroup-uniform
+    if (has) {
+      const int ky = top ? 0 : 2, kx = lef ? 0 : 2;
+      const int sy = ky ? g.Ho - 1 : 0, sx = kx ? g.Wo - 1 : 0;
+      const int c = tid % BN, part = tid / BN;
+      const int per = g.Cs >> 2;                            // Cs % 32 == 0: a multiple of 8
+      float sum = 0.f;
+      if (part < 4 && n0 + c < wrows) {
+        const bf16_t* wrow = wgt + (size_t)(n0 + c) * g.K + (ky * 3 + kx) * g.Cs + part * per;
+        const bf16_t* dyp = src + ((size_t)(img * g.Hs + sy) * g.Ws + sx) * g.Cs + part * per;
+        for (int q = 0; q < per; q += 8) {
+          float w8[8], d8[8];
+          Elem<bf16_t>::unpack(*reinterpret_cast<const u32x4*>(wrow + q), w8);
+          Elem<bf16_t>::unpack(*reinterpret_cast<const u32x4*>(dyp + q), d8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sum = fmaf(w8[e], d8[e], sum);
+        }
+      }
+      if (part < 4) cred[part * BN + c] = sum;
+    }
+    __syncthreads();
+    if (has && tid < BN) {
+      const int c = tid;
+      const int crow = (top ? 1 : H16_TH - 2) * 32 + (lef ? 1 : H16_TW - 2);
+      const float tot = (cred[c] + cred[BN + c]) + (cred[2 * BN + c] + cred[3 * BN + c]);
+      bf16_t* p = reinterpret_cast<bf16_t*>(ctile + crow * CROW) + c;
+      *p = f32_to_bf16(bf16_to_f32(*p) + tot);
+    }
+    if (has) __syncthreads();
+  }
+  // sums of this thread's 8 channels over the rows it writes back -- EPIN: 4 pairs x the (up to) 4 sums of the norm's backward
+  // over the whole tile (one record per 16 x 32 tile: dei2i_conv2d_dgrad_norm_chunks); statistics: per 8-row half (below)
   f32x2 ep[EPIN ? 4 : 1][4];
 #pragma unroll
   for (int q = 0; q < (EPIN ? 4 : 1); ++q)
 #pragma unroll
     for (int k = 0; k < 4; ++k) ep[q][k] = f32x2{0.f, 0.f};
+  constexpr int HP = NPASS / 2;           // passes per 8-row half
+  // (the two halves are one rolled loop: the 16 passes unrolled are ~16 KB of code with the EPIN arithmetic, and every dispatch
+  //  walks its code once from a cold instruction cache -- measured +0.7 ms per step)
 #pragma unroll 1
   for (int half = 0; half < 2; ++half) {
-    float st8[16];                        // sum (0..7) / sum of squares (8..15) of this thread's 8 channels
+    float st8[16];                        // statistics: sum (0..7) / sum of squares (8..15) of this thread's 8 channels, this half
 #pragma unroll
     for (int k = 0; k < 16; ++k) st8[k] = 0.f;
-    // EPIN: this half's x rows of the thread (one 16-byte load per write-back pass) are requested HERE, ahead of the barriers and
-    // the ring / corner work on the staged tile, so their HBM latency is off the write-back's path
-    constexpr int NPASS = 256 / RPP;
-    u32x4 xq[EPIN ? NPASS : 1];
-    if constexpr (EPIN) {
-      if (ncol < ldc) {
-#pragma unroll
-        for (int p = 0; p < NPASS; ++p) {
-          const int row = p * RPP + rsub;
-          const int py = y0 + half * 8 + (row >> 5), px = x0 + (row & 31);
-          const size_t xpix = ((size_t)(img * (g.Ho >> en.up) + (py >> en.up))) * (g.Wo >> en.up) + (px >> en.up);
-          xq[p] = *reinterpret_cast<const u32x4*>(en.x + xpix * ldc + ncol);
-        }
-      }
-    }
-    __syncthreads();
-    if constexpr (EPIN) ctile = smem + half * HALF_BYTES;
-    if (!EPIN && (wm >> 1) == half) stage_acc(ctile);
-    __syncthreads();
-    if constexpr (FOLD) {
-      // the ring's reflection: row ring -> tile row 1 (top) / 14 (bottom), then -- after a barrier: pixel (1,1) takes both --
-      // column ring -> column 1 (left) / 30 (right) of each row
-      auto ring_add = [&](int row) {
-#pragma unroll
-        for (int j = 0; j < CB; ++j) {
-          u32x2* p = reinterpret_cast<u32x2*>(ctile + row * CROW + (wn * WTN + j * 16 + 4 * kg) * 2);
-          const u32x2 v = *p;
-          u32x2 o;
-          o.x = (uint32_t)f32_to_bf16(__uint_as_float(v.x << 16) + racc[j][0]) |
-                ((uint32_t)f32_to_bf16(__uint_as_float(v.x & 0xffff0000u) + racc[j][1]) << 16);
-          o.y = (uint32_t)f32_to_bf16(__uint_as_float(v.y << 16) + racc[j][2]) |
-                ((uint32_t)f32_to_bf16(__uint_as_float(v.y & 0xffff0000u) + racc[j][3]) << 16);
-          *p = o;
-        }
-      };
-      if ((ring_kind == 1 && half == 0) || (ring_kind == 2 && half == 1)) ring_add((ring_kind == 1 ? 1 : 6) * 32 + wm * 16 + l16);
-      __syncthreads();
-      if (ring_kind >= 3 && (l16 >> 3) == half) ring_add((l16 & 7) * 32 + (ring_kind == 3 ? 1 : H16_TW - 2));
-      __syncthreads();
-      // the frame's CORNER pixel, if this half holds its image: frame (-1,-1) is read by output (0,0) only, through kernel tap
-      // (0,0), and reflects onto input pixel (1,1): dx[1][1] += W[:,:,0,0]^T dy[0][0]; likewise (-1,W) -> dx[1][W-2] through
-      // tap (0,2) with dy[0][W-1], (H,-1) -> dx[H-2][1] through (2,0) with dy[H-1][0], (H,W) -> dx[H-2][W-2] through (2,2)
-      // with dy[H-1][W-1].  One dot product of length Cs per output channel: 4 threads per channel, summed through LDS.
-      {
-        const bool lef = x0 == 0, rig = x0 + H16_TW == g.Wo;
-        const bool has = (half == 0 ? y0 == 0 : y0 + H16_TH == g.Ho) && (lef || rig);      // workgroup-uniform
-        if (has) {
-          const int ky = half == 0 ? 0 : 2, kx = lef ? 0 : 2;
-          const int sy = ky ? g.Ho - 1 : 0, sx = kx ? g.Wo - 1 : 0;
-          const int crow = (half == 0 ? 1 : 6) * 32 + (kx ? H16_TW - 2 : 1);
-          const int c = tid % BN, part = tid / BN;
-          const int per = g.Cs >> 2;                            // Cs % 32 == 0: a multiple of 8
-          float sum = 0.f;
-          if (part < 4 && n0 + c < wrows) {
-            const bf16_t* wrow = wgt + (size_t)(n0 + c) * g.K + (ky * 3 + kx) * g.Cs + part * per;
-            const bf16_t* dyp = src + ((size_t)(img * g.Hs + sy) * g.Ws + sx) * g.Cs + part * per;
-            for (int q = 0; q < per; q += 8) {
-              float w8[8], d8[8];
-              Elem<bf16_t>::unpack(*reinterpret_cast<const u32x4*>(wrow + q), w8);
-              Elem<bf16_t>::unpack(*reinterpret_cast<const u32x4*>(dyp + q), d8);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) sum = fmaf(w8[e], d8[e], sum);
-            }
-          }
-          if (part < 4) cred[part * BN + c] = sum;
-          __syncthreads();
-          if (tid < BN) {
-            const float tot = (cred[c] + cred[BN + c]) + (cred[2 * BN + c] + cred[3 * BN + c]);
-            bf16_t* p = reinterpret_cast<bf16_t*>(ctile + crow * CROW) + c;
-            *p = f32_to_bf16(bf16_to_f32(*p) + tot);
-          }
-          __syncthreads();
-        }
-      }
-    }
     if (ncol < ldc) {
 #pragma unroll
-      for (int p = 0; p < 256 / RPP; ++p) {
-        const int row = p * RPP + rsub;
-        const size_t opix = (size_t)out_pixel(g, img, y0 + half * 8 + (row >> 5), x0 + (row & 31));
+      for (int p = 0; p < HP; ++p) {
+        const int row = (half * HP + p) * RPP + rsub;
+        const int py = y0 + (row >> 5), px = x0 + (row & 31);
+        const size_t opix = (size_t)out_pixel(g, img, py, px);
         const u32x4 v = *reinterpret_cast<const u32x4*>(ctile + row * CROW + chunk * 16);
         *reinterpret_cast<u32x4*>(out + opix * ldc + ncol) = v;
-        if (!EPIN && stats != nullptr) {
-          float fv[8];
-          Elem<bf16_t>::unpack(v, fv);
+        if constexpr (!EPIN) {
+          if (stats != nullptr) {
+            float fv[8];
+            Elem<bf16_t>::unpack(v, fv);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { st8[e] += fv[e]; st8[8 + e] = fmaf(fv[e], fv[e], st8[8 + e]); }
+            for (int e = 0; e < 8; ++e) { st8[e] += fv[e]; st8[8 + e] = fmaf(fv[e], fv[e], st8[8 + e]); }
+          }
         }
         if constexpr (EPIN) {
           // v = dL/dz of 8 channels of pixel (py, px), as the streaming pass would read it back (bf16): the same per-element
           // arithmetic as spade_bwd_partial_kernel / bn_bwd_partial_kernel (reduce.hip), on channel PAIRS (v_pk_*_f32)
-          const int py = y0 + half * 8 + (row >> 5), px = x0 + (row & 31);
           const uint32_t dw[4] = {v.x, v.y, v.z, v.w}, xw[4] = {xq[p].x, xq[p].y, xq[p].z, xq[p].w};
           if (en.kind & 0x100) {                         // (timing only, tools/diag_epin.py: no arithmetic -- the loads stay live)
             ep[0][0] += bf16x2_unpack(xw[0]) + bf16x2_unpack(dw[0]);
@@ -881,16 +877,22 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
         }
       }
     }
-    if (!EPIN && stats != nullptr) {                     // kernel-uniform: wave butterflies -> LDS -> the 8 waves' sums in order
-      float* const srow = stats + (size_t)(rec0 + half * tiles_x) * 2 * ldc;
-      reduce_rows16<16, CPR>(st8, red, tid, [&](int q, int c, float sum) {
-        if (n0 + c < ldc) srow[(size_t)q * ldc + n0 + c] = sum;
-      });
+    if constexpr (EPIN) {                                // the second half's x rows move down (static register indices in the loop)
+#pragma unroll
+      for (int p = 0; p < HP; ++p) xq[p] = xq[HP + p];
+    }
+    // statistics: the 512 / CPR row groups' partials -> wave butterflies -> LDS -> the 8 waves' sums in order (reduce_rows16: one
+    // barrier; each half has its own scratch)
+    if constexpr (!EPIN) {
+      if (stats != nullptr) {                            // kernel-uniform
+        float* const srow = stats + (size_t)(rec0 + half * tiles_x) * 2 * ldc;
+        reduce_rows16<16, CPR>(st8, rscr + half * (8 * CPR * 16), tid, [&](int q, int c, float sum) {
+          if (n0 + c < ldc) srow[(size_t)q * ldc + n0 + c] = sum;
+        });
+      }
     }
   }
   if constexpr (EPIN) {
-    // (the reduction scratch is the first rows of half 0's staged tile: every wave is past them since the barrier at the top of
-    //  half 1; one record per TILE)
     const int nq = (en.kind & 0xff) == 1 ? 4 : 2;
     if (!(en.kind & 0x200)) {                            // (0x200: timing only, no reduction)
       float* const prow = en.partial + (size_t)(img * (tiles_y * tiles_x) + trem) * nq * ldc;
@@ -899,7 +901,7 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int k = 0; k < 4; ++k) { flat[q * 8 + 2 * k] = ep[q][k].x; flat[q * 8 + 2 * k + 1] = ep[q][k].y; }
-      reduce_rows16<32, CPR>(flat, reinterpret_cast<float*>(smem), tid, [&](int q, int c, float sum) {
+      reduce_rows16<32, CPR>(flat, rscr, tid, [&](int q, int c, float sum) {
         if (q < nq && n0 + c < ldc) prow[(size_t)q * ldc + n0 + c] = sum;
       });
     }
@@ -928,7 +930,7 @@ static hipError_t launch_halo16(const GatherDesc& g, const void* src, const void
   const int tiles_m = g.N * (g.Ho / H16_TH) * (g.Wo / H16_TW);
   const int tiles_n = (ldc + BN - 1) / BN;
   constexpr size_t loop_lds = 2 * (size_t)H16_HBYTES + (size_t)STAGES * BN * 64 + H16_GROUPS * 16 * sizeof(int);
-  constexpr size_t epi_lds = 256 * (size_t)(BN * 2 + 16) + 512 * 16 * sizeof(float);
+  constexpr size_t epi_lds = 2 * 256 * (size_t)(BN * 2 + 16) + 4 * BN * sizeof(float) + 8 * (BN / 8) * 32 * sizeof(float);   // tile | corners | reduce scratch
   const size_t lds = std::max(loop_lds, epi_lds);
   const bool diag = g_v2_ablate >= 6 && g_v2_ablate <= 9 && g_v2_dbg != nullptr && STAGES == 8 && !fold;
   constexpr bool S8 = STAGES == 8 && BN == 128;   // the diagnostic builds exist for the shipped ring depth and the 128-channel tile only

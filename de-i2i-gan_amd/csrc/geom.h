@@ -231,7 +231,7 @@ struct ConvPro {
 //   kind 1: z = relu(IN(x)*(1+gamma)+beta), gamma / beta from the (N,5,5,2C) class table (normalization.py:24-37):
 //           partial[((n*chunks + chunk)*4 + q)*C + c], q = sum dxhat | sum dxhat*xhat | interior sum dgamma | interior sum dbeta
 //   kind 2: z = act(a*y + b) (BatchNorm + activation, architecture.py:116-118): partial[(chunk*2 + q)*C + c], q = sum g | sum g*xhat
-// chunk = the 8 x 32 half tile (record grid of dei2i_conv2d_stats_chunks); x / y has the conv input's channel stride; `up`: it
+// chunk = the 16 x 32 tile (dei2i_conv2d_dgrad_norm_chunks records per image); x / y has the conv input's channel stride; `up`: it
 // lives at half the resolution (SPADE behind a nearest x2 upsample).
 struct EpiNorm {
   const uint16_t* x;

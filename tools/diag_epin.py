@@ -37,16 +37,46 @@ def run(kind):
         L.check(lib.dei2i_conv2d_dgrad_input_norm(byref(d), ops._p(g), ops._p(wd), ops._p(dx), byref(en), ops._stream()), "dgrad_norm")
 
 
-for name, kind in (("dgrad alone", None), ("+ SPADE reductions", 1), ("  without the arithmetic", 1 | 0x100), ("  without the reduction", 1 | 0x200),
-                   ("  without both (x loads only)", 1 | 0x300), ("dgrad alone", None), ("+ SPADE reductions", 1)):
+# "cold": 640 MB are written between launches, so the operands come from HBM as they do inside the train step (warm: the 100 MB
+# of g, x and dx stay in the 256 MB Infinity Cache from launch to launch)
+flush = torch.empty(640 << 20, dtype=torch.uint8, device=DEV)
+wf, _ = ops.PackedWeights().get(w, (w,), ops.BF16, geom, cin, cout, need_dgrad=False)
+y = torch.empty(N, H, H, cout, device=DEV, dtype=torch.bfloat16)
+
+
+def fwd():
+    L.check(lib.dei2i_conv2d_fwd(byref(d), ops._p(x), ops._p(wf), None, 0, ops._p(y), ops._p(ws), ws.numel() * 4, ops._stream()), "fwd")
+
+
+def timed(fn, fam, cold):
     for _ in range(3):
-        run(kind)
+        fn()
     torch.cuda.synchronize()
-    lib.dei2i_prof_enable(PROF, 1)
+    lib.dei2i_prof_enable(fam, 1)
     for _ in range(20):
-        run(kind)
+        if cold:
+            flush.fill_(1)
+        fn()
     torch.cuda.synchronize()
     n, ms, fl = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
-    L.check(lib.dei2i_prof_collect(PROF, byref(n), byref(ms), byref(fl)), "prof_collect")
-    lib.dei2i_prof_enable(PROF, 0)
-    print("%-34s %7.1f us/launch (%d launches)" % (name, ms.value * 1e3 / max(n.value, 1), n.value), flush=True)
+    L.check(lib.dei2i_prof_collect(fam, byref(n), byref(ms), byref(fl)), "prof_collect")
+    lib.dei2i_prof_enable(fam, 0)
+    return ms.value * 1e3 / max(n.value, 1)
+
+
+print("%-34s %9s %9s   (us per launch, 20 launches each)" % ("", "warm", "cold"))
+print("%-34s %9.1f %9.1f" % ("forward (pipelined loop)", timed(fwd, 2, False), timed(fwd, 2, True)), flush=True)
+for name, kind in (("dgrad alone (FOLD)", None), ("+ SPADE reductions", 1), ("  without the arithmetic", 1 | 0x100), ("  without the reduction", 1 | 0x200),
+                   ("  without both (x loads only)", 1 | 0x300), ("+ BatchNorm reductions", 2), ("dgrad alone (FOLD)", None), ("+ SPADE reductions", 1)):
+    if kind == 2:
+        a_, b_ = torch.rand(cin, device=DEV) + 0.5, torch.randn(cin, device=DEV)
+        m2, r2 = torch.randn(cin, device=DEV), torch.rand(cin, device=DEV) + 0.5
+        p2 = torch.empty(N * chunks, 2, cin, device=DEV)
+
+        def f(kind=kind):
+            en = L.EpiNormDesc(2, 0, 2, 0, x.data_ptr(), m2.data_ptr(), r2.data_ptr(), None, a_.data_ptr(), b_.data_ptr(), p2.data_ptr())
+            L.check(lib.dei2i_conv2d_dgrad_input_norm(byref(d), ops._p(g), ops._p(wd), ops._p(dx), byref(en), ops._stream()), "dgrad_norm")
+    else:
+        def f(kind=kind):
+            run(kind)
+    print("%-34s %9.1f %9.1f" % (name, timed(f, PROF, False), timed(f, PROF, True)), flush=True)
