@@ -54,8 +54,16 @@ def parse():
                     help="A/B: leaf-weight gradients on the main stream instead of the side stream (ops.wgrad_side_stream = False)")
     ap.add_argument("--no-fuse-bwd", action="store_true",
                     help="A/B: SPADE / BatchNorm backward reductions by a streaming pass instead of the dgrad epilogue (ops.fuse_bwd = False)")
+    ap.add_argument("--no-fold-eval-bn", action="store_true",
+                    help="A/B: eval-mode BatchNorm as its own apply pass instead of folded into the conv weights (ops.fold_eval_bn = False)")
     ap.add_argument("--fuse-pro", action="store_true",
                     help="A/B: BatchNorm / SPADE apply on the consumer conv's operand path (ops.fuse_pro = True; measured slower)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="--gpus 1 only: attach the data-parallel reducer on a ONE-rank RCCL group -- hooks, bucket cat / copy-back, "
+                         "the all-reduce launches on the side stream and the wgrad-stream join all run -- and report what it costs "
+                         "(ddp: collectives and MB per step, side-stream occupancy, exposed ms, step time with / without the reducer)")
+    ap.add_argument("--comm-dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="gradient all-reduce message type (parallel.GradReducer comm_dtype; bf16 halves the bytes on xGMI)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child process of the default run
     ap.add_argument("--spawn-selftest", default=None, help=argparse.SUPPRESS)             # tests: rendezvous of the spawned ranks over gloo, no GPU
     return ap.parse_args()
@@ -217,8 +225,19 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(device))
+    if args.force_collectives and world != 1:
+        raise SystemExit("--force-collectives prices the reducer on ONE GPU (--gpus 1); with --gpus N > 1 the reducer is attached anyway")
+    if world > 1 or args.force_collectives:
+        if world == 1:
+            import socket
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            sk.close()
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(device))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(device))
 
     from de_i2i_gan_amd import _lib
     from de_i2i_gan_amd.parallel import attach_ddp
@@ -230,6 +249,7 @@ def main():
     _ops.fuse_ring = not args.no_fuse_ring
     _ops.wgrad_side_stream = not args.no_wgrad_stream
     _ops.fuse_bwd = not args.no_fuse_bwd
+    _ops.fold_eval_bn = not args.no_fold_eval_bn
     for kv in args.set_option:
         name, val = kv.split("=")
         _lib.check(_lib.load().dei2i_set_option(name.encode(), int(val)), "set_option " + kv)
@@ -242,9 +262,22 @@ def main():
     else:
         tr = DefectGanTrainer(opt)
         step = lambda: tr.step(bg, lab, df)                  # noqa: E731
-    red = attach_ddp(tr, measure=True) if world > 1 else None
     bg, lab, df = synthetic_batch(args.batch, args.image_size, seed=7 + rank)
     bg, lab, df = bg.to(device), lab.to(device), df.to(device)
+    plain_ms = None
+    if args.force_collectives:
+        # the same steps WITHOUT the reducer first, same process, same box: what the hooks, buckets and stream joins cost is the
+        # difference (the one-rank all-reduces themselves move no data over xGMI)
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        plain_ms = 1e3 * (time.perf_counter() - t0) / args.steps
+    red = attach_ddp(tr, measure=True, force_collectives=args.force_collectives, comm_dtype=args.comm_dtype) \
+        if (world > 1 or args.force_collectives) else None
 
     def sync():
         if world > 1:
@@ -342,6 +375,7 @@ def main():
                    "spade_upsample_at_source_resolution": not args.no_fuse_ring,
                    "weight_gradients_on_side_stream": not args.no_wgrad_stream,
                    "norm_backward_reductions_in_dgrad_epilogue": not args.no_fuse_bwd,
+                   "eval_batchnorm_folded_into_conv_weights": not args.no_fold_eval_bn,
                    # what the step does differently from a literal transcription of the reference's step (same function):
                    "defer_loss_sync": bool(opt.defer_loss_sync),      # losses stay on the device; no .item() per update
                    "discriminator_passes": "one batched D pass per step phase (4 image batches in the D step, 2 in the G step: "
@@ -431,12 +465,17 @@ def main():
         # rank 0's view: time the gradient all-reduces occupied the side stream per backward pass, and the part that ran
         # after backward's last kernel (the optimizer waits for it) -- stream events, measured inside the timed region
         ddp.update({"collectives_per_step": red_stats["collectives"] / (args.steps + args.warmup),
-                    "allreduce_mb_per_step": red_stats["bytes"] / (args.steps + args.warmup) / 1e6})
+                    "allreduce_mb_per_step": red_stats["bytes"] / (args.steps + args.warmup) / 1e6,
+                    "comm_dtype": args.comm_dtype})
+        if plain_ms is not None:
+            ddp.update({"ranks": 1, "step_ms_without_reducer": plain_ms, "step_ms_with_reducer": ms_per_step,
+                        "reducer_cost_ms_per_step": ms_per_step - plain_ms,
+                        "note": "one-rank RCCL group (--force-collectives): the reducer's host and stream work at full size, no xGMI traffic"})
         line["ddp"] = ddp
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not args.force_collectives:
         line["cpu_baseline"] = cpu_baseline_bounded()
     print(json.dumps(line))
-    if world > 1:
+    if world > 1 or args.force_collectives:
         dist.destroy_process_group()
 
 

@@ -98,6 +98,7 @@ SIGNATURES = {
     "dei2i_spectral_scratch_floats": (c_size_t, [c_int, c_int]),
     "dei2i_spectral_fwd": (c_int, [c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P]),
     "dei2i_spectral_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
+    "dei2i_fold_bn_weight": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_float, _P, _P, _P]),
     "dei2i_adam_step": (c_int, [_P, c_int, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_float, _P]),
     "dei2i_sgd_rmsprop_step": (c_int, [_P, c_int, c_int64, c_int, c_float, c_float, c_float, c_float, _P]),
     "dei2i_prof_enable": (c_int, [c_int, c_int]),

@@ -211,6 +211,26 @@ static inline int sn_dot_blocks(size_t n) {            // >= 2048 elements (two 
 
 using namespace dei2i;
 
+// Eval-mode BatchNorm folded into the conv in front of it (architecture.py:116-118 with running statistics: z = act(a * conv(x, W)
+// + b), a = weight * rsqrt(running_var + eps), b = bias - running_mean * a, a fixed per-channel affine): W_eff[co] = a[co] * W[co],
+// b_eff = b -- the conv's own epilogue (bias + activation) then writes z, and the BatchNorm-apply pass over the conv's output is
+// not run.  One launch per conv: row co of W (K floats) scaled by a[co]; block 0 also writes b_eff.
+__global__ __launch_bounds__(256) void fold_bn_weight_kernel(const float* __restrict__ W, const float* __restrict__ bn_w,
+                                                             const float* __restrict__ bn_b, const float* __restrict__ rm,
+                                                             const float* __restrict__ rv, const float eps, const int Cout, const int K,
+                                                             float* __restrict__ w_eff, float* __restrict__ b_eff) {
+  const size_t n = (size_t)Cout * K;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int co = (int)(i / K);
+    w_eff[i] = W[i] * (bn_w[co] * rsqrtf(rv[co] + eps));
+  }
+  if (blockIdx.x == 0)
+    for (int co = threadIdx.x; co < Cout; co += 256) {
+      const float a = bn_w[co] * rsqrtf(rv[co] + eps);
+      b_eff[co] = bn_b[co] - rm[co] * a;
+    }
+}
+
 extern "C" {
 
 size_t dei2i_spectral_scratch_floats(int Cout, int K) { return (size_t)K + Cout + (size_t)((K + SN_COLS - 1) / SN_COLS) + Cout + 1024; }
@@ -251,6 +271,15 @@ int dei2i_spectral_bwd(int Cout, int K, const float* G, const float* w_eff, cons
   else
     hipLaunchKernelGGL(sn_bwd_apply_kernel<false>, dim3(grid_for(n, 256)), dim3(256), 0, st, G, (const float*)scratch, nb, scal,
                        u_used, v_used, Cout, K, dW, accumulate);
+  return (int)hipGetLastError();
+}
+
+
+int dei2i_fold_bn_weight(int Cout, int K, const float* W, const float* bn_weight, const float* bn_bias, const float* running_mean,
+                         const float* running_var, float eps, float* w_eff, float* b_eff, dei2i_stream s) {
+  if (Cout <= 0 || K <= 0 || !W || !bn_weight || !bn_bias || !running_mean || !running_var || !w_eff || !b_eff) return DEI2I_ERR_BAD_ARG;
+  hipLaunchKernelGGL(fold_bn_weight_kernel, dim3(grid_for((size_t)Cout * K, 256)), dim3(256), 0, (hipStream_t)s, W, bn_weight, bn_bias,
+                     running_mean, running_var, eps, Cout, K, w_eff, b_eff);
   return (int)hipGetLastError();
 }
 

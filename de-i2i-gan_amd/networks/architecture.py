@@ -244,10 +244,22 @@ class ConvBlock(nn.Module):
             assert res is None
             return ops.instance_norm_act(self.conv_block[0](x, stats=True), self._act)
         if self._has_norm:
-            y = self.conv_block[0](x, stats=True)
-            return self.conv_block[1](y, self._act, res, stats=out_stats)
+            conv, bn = self.conv_block[0], self.conv_block[1]
+            if res is None and self.folds_eval_bn():
+                # eval-mode BatchNorm is a fixed per-channel affine: folded into the conv's weights, BN + activation run in the
+                # conv's epilogue and the apply pass over its output is not launched (ops.fold_bn_weight)
+                w_eff, b_eff = ops.fold_bn_weight(conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+                return ops.conv2d(x, w_eff, b_eff, ops.PackedWeights(), conv.geom(False), self._act, sources=(w_eff,), stats=out_stats)
+            y = conv(x, stats=bn.training)
+            return bn(y, self._act, res, stats=out_stats)
         assert res is None
         return self.conv_block[0](x, self._act)
+
+    def folds_eval_bn(self):
+        """conv -> BatchNorm (running statistics) -> act as ONE conv launch: eval mode, no autograd graph, a plain conv without bias"""
+        conv, bn = self.conv_block[0], self.conv_block[1]
+        return (ops.fold_eval_bn and self._has_norm and not bn.training and not torch.is_grad_enabled() and type(conv) is Conv2d
+                and conv.bias is None)
 
 
 class DeConvBlock(nn.Module):
@@ -292,6 +304,10 @@ class ResBlock(nn.Module):
             h = self.res_block[2](ops.avgpool2(self.res_block[0](x)))
             return ops.add(h, ops.avgpool2(self.conv_s[0](x)), stats=out_stats)
         first, second = self.res_block[0], self.res_block[1]
+        if first._has_norm and second._has_norm and first.folds_eval_bn():
+            # eval mode: the first BatchNorm + LeakyReLU in the first conv's epilogue; second conv -> BN + identity add (one kernel)
+            y2 = second.conv_block[0](first(x), stats=False)
+            return second.conv_block[1](y2, second._act, x, stats=out_stats)
         if first._has_norm and second._has_norm:
             # conv -> [BN + LeakyReLU on the second conv's operand path] -> conv -> BN + identity add (one kernel)
             y1 = first.conv_block[0](x, stats=True)

@@ -239,6 +239,28 @@ def spectral_weight(weight_orig, u, v, iterate: bool):
     return _SpectralWeight.apply(weight_orig, u, v, bool(iterate))
 
 
+# ---- eval-mode BatchNorm folded into the conv in front of it ------------------------------------------------------
+# The generator passes of the D step (defectgan_model.py:251-262) and inference run BatchNorm on its RUNNING statistics: a fixed
+# per-channel affine.  Folded into the conv's weights (and a bias), BN + LeakyReLU happen in the conv's own epilogue and the
+# BatchNorm-apply pass over the conv's output -- a read and a write of the largest tensors of the pass -- is not run.
+fold_eval_bn = True
+
+
+def fold_bn_weight(weight, bn_weight, bn_bias, running_mean, running_var, eps: float):
+    """-> (w_eff = a[co] * weight[co], b_eff = bn_bias - running_mean * a) with a = bn_weight * rsqrt(running_var + eps); no
+    autograd (eval / no-grad passes only).  ``w_eff`` is marked as derived per call: its packed copy travels with the call."""
+    _require_gpu(weight, "fold_bn_weight")
+    w = weight.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        raise TypeError("fold_bn_weight expects a contiguous fp32 weight")
+    cout, k = w.shape[0], w[0].numel()
+    w_eff, b_eff = torch.empty_like(w), torch.empty(cout, dtype=torch.float32, device=w.device)
+    L.check(_lib_for(w).dei2i_fold_bn_weight(cout, k, _p(w), _p(bn_weight.detach()), _p(bn_bias.detach()), _p(running_mean), _p(running_var),
+                                             float(eps), _p(w_eff), _p(b_eff), _stream()), "fold_bn_weight")
+    w_eff._dei2i_per_call = True
+    return w_eff, b_eff
+
+
 # ---- NoiseInjection's draw (architecture.py:385-389): N(0,1) on the activations' device; tests install a provider ----
 noise_source = None
 

@@ -20,6 +20,10 @@ MI355X node (8 GPUs, point-to-point xGMI, no switch):
   network, like torch DDP does at construction: replicas start identical whatever each rank's seed or checkpoint was.
 * ``measure=True`` brackets every collective with events on the side stream and marks the end of backward on the compute
   stream; ``overlap_report()`` then says how much of the exchange ran under backward kernels (bench.py prints it).
+* ``comm_dtype="bf16"``: the messages travel as bf16 (half the bytes on the per-link-bound xGMI rings: D's step is 180 MB in fp32,
+  134 MB of it one tensor): each gradient is rounded to bf16 on the side stream, summed by RCCL in bf16, and widened back into
+  the fp32 gradient the optimizer reads; the 1/world stays in Adam.  One rounding of every addend and of every partial sum
+  (2^-9 relative each): tests/test_ddp_gloo.py bounds the error against the fp32 exchange.  Default fp32 (bit-exact sums).
 """
 from __future__ import annotations
 
@@ -31,7 +35,7 @@ import torch.distributed as dist
 
 class GradReducer:
     def __init__(self, process_group=None, bucket_bytes: int = 16 << 20, direct_bytes: int = 4 << 20, overlap: bool = True,
-                 force_collectives: bool = False, measure: bool = False):
+                 force_collectives: bool = False, measure: bool = False, comm_dtype: str = "fp32"):
         if not dist.is_initialized():
             raise RuntimeError("GradReducer needs an initialised torch.distributed process group")
         self.pg = process_group
@@ -45,6 +49,9 @@ class GradReducer:
         self._inflight = []          # (work, flat, [grads]) to finish in reduce()
         self.stats = {"collectives": 0, "bytes": 0}
         self.measure = measure
+        if comm_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"comm_dtype [{comm_dtype}] is not supported (fp32 | bf16)")
+        self.comm_dtype = torch.bfloat16 if comm_dtype == "bf16" else torch.float32
         self._spans = []             # measure: (start event, end event) of every collective, on the side stream
         self._bwd_done = []          # measure: compute-stream event at the entry of reduce() = backward's last kernel
         self._span_marks = []        # index into _spans at each reduce() call
@@ -106,15 +113,20 @@ class GradReducer:
             if self.measure and side is not None:
                 e0 = torch.cuda.Event(enable_timing=True)
                 e0.record(side)
+            narrow = self.comm_dtype != grads[0].dtype
             if flat:
                 buf = torch.cat([g.reshape(-1) for g in grads])
                 for g in grads:
                     if side is not None:
                         g.record_stream(side)
+                if narrow:
+                    buf = buf.to(self.comm_dtype)
             else:
                 buf = grads[0]
                 if side is not None:
                     buf.record_stream(side)
+                if narrow:
+                    buf, flat = buf.reshape(-1).to(self.comm_dtype), True       # (copied back into the fp32 gradient in reduce())
             work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
             if self.measure and side is not None:
                 work.wait()                       # stream-ordered on the side stream (no host block for NCCL work)
@@ -146,12 +158,13 @@ class GradReducer:
             ctx = torch.cuda.stream(side) if side is not None else _NullCtx()
             with ctx:
                 work.wait()
-                if flat is not None:
-                    off = 0
+                if flat is not None:                    # bucket (or narrowed message) -> the fp32 gradients, ONE multi-tensor launch
+                    views, off = [], 0
                     for g in grads:
                         n = g.numel()
-                        g.copy_(flat[off:off + n].view_as(g))
+                        views.append(flat[off:off + n].view_as(g))
                         off += n
+                    torch._foreach_copy_(grads, views)
         for dev, side in self._side.items():
             torch.cuda.current_stream(dev).wait_stream(side)    # optimizer kernels run after the reduced grads land
         self._inflight = []

@@ -233,6 +233,12 @@ int dei2i_spectral_fwd(int Cout, int K, const float* W, float* u, float* v, int 
 int dei2i_spectral_bwd(int Cout, int K, const float* G, const float* w_eff, const float* u_used, const float* v_used,
                        const float* scal, float* scratch, float* dW, int accumulate, dei2i_stream s);
 
+/* Eval-mode BatchNorm folded into the weights of the conv in front of it (the ConvBlock of architecture.py:79-118 with running
+ * statistics -- the generator passes of the D step, defectgan_model.py:251-262, and inference): w_eff[co] = a[co] * W[co],
+ * b_eff[co] = bias[co] - running_mean[co] * a[co], a = weight * rsqrt(running_var + eps).  W / w_eff: Cout x K fp32 (OIHW). */
+int dei2i_fold_bn_weight(int Cout, int K, const float* W, const float* bn_weight, const float* bn_bias, const float* running_mean,
+                         const float* running_var, float eps, float* w_eff, float* b_eff, dei2i_stream s);
+
 /* ---- in-library kernel timing (bench.py roofline leg): HIP events around every launch of one kernel family ---- */
 #define DEI2I_PROF_GATHER_GEMM 0  /* the other conv forward / dgrad kernels: gather GEMM v1 / v2, thin convs */
 #define DEI2I_PROF_WGRAD 1

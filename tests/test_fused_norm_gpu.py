@@ -472,3 +472,52 @@ def test_norm_backward_reductions_are_not_used_when_dz_has_a_second_consumer(con
         ops.fuse_bwd, ops.fuse_pro = keep
     for a, b in zip(res[True], res[False]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_eval_mode_batchnorm_folded_into_the_conv_weights():
+    """ops.fold_eval_bn: in the no-grad eval-mode generator pass (the D step's two passes, defectgan_model.py:251-262; inference) every
+    conv -> BatchNorm(running statistics) -> LeakyReLU block is ONE conv launch on weights scaled per output channel (architecture.py:
+    116-118 is then a fixed affine).  (a) the folded weights / bias against the formula; (b) the generator's eval output with the
+    fold against the three-kernel formulation: exact-f32 mode 1e-5 (fp32 rounding of w * a), bf16 within the bf16 tolerances of the
+    model tests -- and against the oracle's eval forward in f32 mode (1e-3)."""
+    from de_i2i_gan_amd import ops
+    from de_i2i_gan_amd.networks.generator import DefectGanGenerator
+    from helpers import formula_fill
+    torch.manual_seed(2)
+    w = torch.randn(48, 24, 3, 3, device=DEV)
+    bw, bb = torch.rand(48, device=DEV) + 0.5, torch.randn(48, device=DEV)
+    rm, rv = torch.randn(48, device=DEV), torch.rand(48, device=DEV) + 0.1
+    w_eff, b_eff = ops.fold_bn_weight(w, bw, bb, rm, rv, 1e-5)
+    a = bw * torch.rsqrt(rv + 1e-5)
+    assert maxrel(w_eff, w * a.view(-1, 1, 1, 1)) < 1e-6 and maxrel(b_eff, bb - rm * a) < 1e-6
+    c = dict(image_size=64, batch=2, num_layers=4, ngf=16, ndf=16, hidden_nc=32)
+    cfg = O.Cfg(image_size=64, ngf=16, ndf=16, num_layers=4, hidden_nc=32)
+    bg, labels, _ = O.synthetic_batch(2, 64)
+    SG = O.make_state(O.generator_state_shapes(cfg))
+    with torch.no_grad():
+        ref, ref_p = O.generator_forward(SG, bg, labels.reshape(2, 6, 1, 1), cfg, training=False)
+    keep = ops.fold_eval_bn
+    try:
+        for pname in ("f32", "bf16"):
+            G = DefectGanGenerator(make_opt(c, DEV, pname)).to(DEV)
+            formula_fill(G)
+            G.eval()
+            outs = {}
+            for on in (True, False):
+                ops.fold_eval_bn = on
+                with torch.no_grad():
+                    outs[on] = G(bg.to(DEV), labels.to(DEV))
+            for a_, b_ in zip(outs[True], outs[False]):
+                if pname == "f32":
+                    assert maxrel(a_, b_) < 1e-5
+                else:
+                    assert rel_l2(a_, b_) < 0.12
+            if pname == "f32":
+                assert maxrel(outs[True][0], ref) < 1e-3 and maxrel(outs[True][1], ref_p) < 1e-3
+            # with autograd on (an eval-mode pass that is differentiated) nothing is folded: same numbers as the unfolded pass
+            ops.fold_eval_bn = True
+            out_g = G(bg.to(DEV), labels.to(DEV))
+            assert torch.equal(out_g[0].detach(), outs[False][0])
+    finally:
+        ops.fold_eval_bn = keep
