@@ -557,6 +557,8 @@ static bool to_pro(const dei2i_conv* c, const dei2i_pro* p, ConvPro& out) {
 
 static bool halo_fwd_shape_ok(const dei2i_conv* c, int want_pro) {
   if (!valid_conv(c) || c->dtype != DT_BF16) return false;
+  if (c->kh == 4 && c->kw == 4 && c->stride == 2 && c->pad == 1 && !want_pro)          // the stride-2 form (conv_halo16.hip S2)
+    return halo16_s2_shape_ok(make_fwd_desc(to_shape(c), c->CinS), c->CoutS, num_cu());
   if (c->kh != 3 || c->kw != 3 || c->stride != 1 || c->pad != 1) return false;
   const int Ho = c->H << c->up, Wo = c->W << c->up;
   if (c->CinS % 64 != 0 || Ho % 8 != 0 || Wo % 32 != 0 || c->CoutS < 64) return false;

@@ -122,7 +122,14 @@ DEI2I_D void reduce_rows16(float (&v)[NV], float* __restrict__ scratch, int tid,
 // PIPE: the software-pipelined main loop (see there) instead of the two-phase one
 // EPIN: the epilogue also takes the backward reductions of the normalisation layer in front of this conv (geom.h: EpiNorm) from
 // the finished dz tile -- FOLD launches only (every conv of the generator is reflect-padded)
-template <int BN, int STAGES, int DIAG = 0, bool FOLD = false, int ABL = 0, bool PIPE = false, bool EPIN = false>
+// S2: a 4x4 STRIDE-2 conv (generator.py:107-116, discriminator.py:60-77) on the same tile.  Output pixel (oy, ox), tap (ky, kx)
+// reads input (2 oy + ky - pad, 2 ox + kx - pad): with ky = 2 ty + dy, kx = 2 tx + dx that is pixel (oy + ty, ox + tx) of the
+// parity plane (dy, dx) of the padded input -- a 2x2 STRIDE-1 conv over 4 planes.  The planes exist only in LDS: a slice is
+// (plane, 32 channels), its halo is 17 x 33 plane pixels gathered by the LDS-DMA through a per-plane source-offset table (reflect
+// padding is in the table), its 4 taps read tap-shifted fragments exactly like the 3x3 kernel -- so the input is fetched ONCE per
+// tile and channel tile (the gather GEMM streams every input pixel four times, once per tap that reads it: 48 KB per k-step
+// against 8 KB of weights + 9 KB of halo here).  HBM layout and the packed weights ([Cout][4x4][CinS]) are the generic ones.
+template <int BN, int STAGES, int DIAG = 0, bool FOLD = false, int ABL = 0, bool PIPE = false, bool EPIN = false, bool S2 = false>
 __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, const bf16_t* __restrict__ src,
                                                           const bf16_t* __restrict__ wgt, const int wrows,
                                                           const float* __restrict__ bias, bf16_t* __restrict__ out,
@@ -165,18 +172,22 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
   const int y0 = (trem / tiles_x) * H16_TH, x0 = (trem % tiles_x) * H16_TW;
   const int n0 = tile_n * BN;
 
-  const int hwd = H16_TW + g.tw - 1;                  // halo width in pixels
-  const int npix = (H16_TH + g.th - 1) * hwd;
-  const int hy0 = y0 + g.by0 + (g.ys < 0 ? -(g.th - 1) : 0);
-  const int hx0 = x0 + g.bx0 + (g.xs < 0 ? -(g.tw - 1) : 0);
+  static_assert(!S2 || (!FOLD && !PIPE && !EPIN && DIAG == 0 && ABL == 0 && STAGES == 4), "the stride-2 form runs the two-phase loop on a 4-stage ring");
+  const int lth = S2 ? 2 : g.th, ltw = S2 ? 2 : g.tw;  // taps of the loop (S2: per parity plane)
+  const int hwd = H16_TW + ltw - 1;                   // halo width in pixels
+  const int npix = (H16_TH + lth - 1) * hwd;
+  const int hy0 = S2 ? y0 : y0 + g.by0 + (g.ys < 0 ? -(g.th - 1) : 0);
+  const int hx0 = S2 ? x0 : x0 + g.bx0 + (g.xs < 0 ? -(g.tw - 1) : 0);
+  constexpr int HTAB = H16_GROUPS * 16;               // entries of one source-offset table
 
-  // ---- halo source-offset table (element offset of each halo pixel's channel 0, -1 = contributes zero) ----
-  for (int p = tid; p < H16_GROUPS * 16; p += 512) {
+  // ---- halo source-offset table (element offset of each halo pixel's channel 0, -1 = contributes zero); S2: one per parity plane ----
+  for (int p = tid; p < (S2 ? 4 : 1) * HTAB; p += 512) {
     int off = -1;
-    if (p < npix) {
-      const int hy = p / hwd, hx = p - hy * hwd;
-      const int y = bound_coord(hy0 + hy, g.Hl, g.pad_mode);
-      const int x = bound_coord(hx0 + hx, g.Wl, g.pad_mode);
+    const int par = S2 ? p / HTAB : 0, q = S2 ? p - par * HTAB : p;
+    if (q < npix) {
+      const int hy = q / hwd, hx = q - hy * hwd;
+      const int y = bound_coord(S2 ? 2 * (hy0 + hy) + (par >> 1) + g.by0 : hy0 + hy, g.Hl, g.pad_mode);
+      const int x = bound_coord(S2 ? 2 * (hx0 + hx) + (par & 1) + g.bx0 : hx0 + hx, g.Wl, g.pad_mode);
       if ((y | x) >= 0) {
         if (zring != nullptr && !(ring_interior(y, g.Hl) && ring_interior(x, g.Wl)))
           off = -2 - (img * ring_pix + ring_index(y, x, g.Hl, g.Wl)) * g.Cs;       // <= -2: element offset -2 - off into zring
@@ -210,23 +221,41 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
     b_ptr = n < wrows ? wgt + (size_t)n * g.K + ((lslot ^ sw16(r)) << 3) : nullptr;
   }
 
-  const int ntaps = __builtin_amdgcn_readfirstlane(g.th * g.tw);
-  const int nslices = __builtin_amdgcn_readfirstlane(g.Cs >> 5);
+  const int ntaps = __builtin_amdgcn_readfirstlane(lth * ltw);
+  const int ncb = __builtin_amdgcn_readfirstlane(g.Cs >> 5);                    // 32-channel blocks of the input
+  const int nslices = S2 ? 4 * ncb : ncb;              // S2: slice = (parity plane, channel block), plane-major
   const int nk = ntaps * nslices;
 
   auto issue_halo = [&](int slice) {
     unsigned char* hb = halo + (slice & 1) * H16_HBYTES;
-    const int ci0 = slice << 5;
+    if constexpr (S2) {
+      const int par = slice / ncb, ci0 = (slice - par * ncb) << 5;
 #pragma unroll
-    for (int j = 0; j < H16_HL; ++j) {
-      const bf16_t* p = h_off[j] >= 0 ? src + ((size_t)(unsigned)h_off[j] + (unsigned)ci0) : zero;
-      if (h_off[j] < -1) p = zring + ((size_t)(unsigned)(-2 - h_off[j]) + (unsigned)ci0);
-      glds16x(p, hb + h_group[j] * 1024);
+      for (int j = 0; j < H16_HL; ++j) {
+        const int pix = h_group[j] * 16 + lrow;
+        const int o = htab[par * HTAB + pix];
+        const bf16_t* p = o >= 0 ? src + ((size_t)(unsigned)(o + ((lslot ^ sw16(pix)) << 3)) + (unsigned)ci0) : zero;
+        glds16x(p, hb + h_group[j] * 1024);
+      }
+    } else {
+      const int ci0 = slice << 5;
+#pragma unroll
+      for (int j = 0; j < H16_HL; ++j) {
+        const bf16_t* p = h_off[j] >= 0 ? src + ((size_t)(unsigned)h_off[j] + (unsigned)ci0) : zero;
+        if (h_off[j] < -1) p = zring + ((size_t)(unsigned)(-2 - h_off[j]) + (unsigned)ci0);
+        glds16x(p, hb + h_group[j] * 1024);
+      }
     }
   };
   int is_tap = 0, is_slice = 0;                        // (tap, slice) of the next weight k-step to issue
   auto issue_b = [&](int stage) {
-    const int kb = is_tap * g.Cs + (is_slice << 5);
+    int kb;
+    if constexpr (S2) {                                // plane (dy, dx), loop tap (ty, tx) -> kernel tap (2 ty + dy, 2 tx + dx) of the 4x4 grid
+      const int par = is_slice / ncb, cb = is_slice - par * ncb;
+      kb = ((2 * (is_tap >> 1) + (par >> 1)) * 4 + 2 * (is_tap & 1) + (par & 1)) * g.Cs + (cb << 5);
+    } else {
+      kb = is_tap * g.Cs + (is_slice << 5);
+    }
     const bf16_t* p = b_ptr != nullptr ? b_ptr + kb : zero;
     glds16x(p, ring + stage * B_STAGE + rg * 1024);
     if (++is_tap == ntaps) { is_tap = 0; ++is_slice; }
@@ -278,8 +307,8 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
   }
   int ld_tx = 0, ld_ty = 0, ld_slice = 0, ld_stage = 0;
   const int step_x = g.xs > 0 ? 1 : -1, step_y = g.ys > 0 ? hwd : -hwd;
-  int ld_toff = (g.ys > 0 ? 0 : (g.th - 1) * hwd) + (g.xs > 0 ? 0 : g.tw - 1);     // halo pixel offset of tap (0,0)
-  const int toff_row_wrap = step_y - (g.tw - 1) * step_x;
+  int ld_toff = (g.ys > 0 ? 0 : (lth - 1) * hwd) + (g.xs > 0 ? 0 : ltw - 1);       // halo pixel offset of tap (0,0)
+  const int toff_row_wrap = step_y - (ltw - 1) * step_x;
   const int toff_origin = ld_toff;
   auto read_frags = [&](Frags& f) {
     const unsigned char* hb = halo + (ld_slice & 1) * H16_HBYTES;
@@ -302,9 +331,9 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
     }
 #pragma unroll
     for (int j = 0; j < CB; ++j) f.b[j] = *reinterpret_cast<const u32x4*>(sb + b_addr[j]);
-    if (++ld_tx == g.tw) {
+    if (++ld_tx == ltw) {
       ld_tx = 0;
-      if (++ld_ty == g.th) { ld_ty = 0; ++ld_slice; ld_toff = toff_origin; }
+      if (++ld_ty == lth) { ld_ty = 0; ++ld_slice; ld_toff = toff_origin; }
       else ld_toff += toff_row_wrap;
     } else {
       ld_toff += step_x;
@@ -588,7 +617,9 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
       if constexpr (DIAG != 3 && !(ABL & 2)) read_frags(f);
       __builtin_amdgcn_sched_barrier(0);
       const unsigned long long q1 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
-      const bool halo_young = tap >= 2 && tap <= STAGES - 1 && slice + 1 < nslices;
+      // the next slice's halo went out in C(tap 1): while it is younger than weights(j+1) it may stay in flight -- but not at the
+      // slice's last tap, whose barrier is the last one before M(next slice, tap 0) reads it (short tap grids: S2)
+      const bool halo_young = tap >= 2 && tap <= STAGES - 1 && tap <= ntaps - 2 && slice + 1 < nslices;
       if constexpr (DIAG != 2 && !(ABL & 1)) {
         if (j + STAGES - 2 >= nk) wait_vm16<0>();
         else if (halo_young) wait_vm16<(STAGES - 3) * LB + H16_HL>();
@@ -926,10 +957,30 @@ int g_halo16_stages = 8;
 template <int BN, int STAGES>
 static hipError_t launch_halo16(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out,
                                 int ldc, int act, hipStream_t st, float* stats, const void* ring = nullptr, bool fold = false,
-                                const EpiNorm* en = nullptr) {
+                                const EpiNorm* en = nullptr, bool s2 = false) {
   const int tiles_m = g.N * (g.Ho / H16_TH) * (g.Wo / H16_TW);
   const int tiles_n = (ldc + BN - 1) / BN;
-  constexpr size_t loop_lds = 2 * (size_t)H16_HBYTES + (size_t)STAGES * BN * 64 + H16_GROUPS * 16 * sizeof(int);
+  if (s2) {                                             // the 4x4 stride-2 form: two-phase loop, 4-stage weight ring
+    if constexpr (STAGES == 4) {
+      constexpr size_t lds2 = std::max(2 * (size_t)H16_HBYTES + 4 * (size_t)BN * 64 + 4 * H16_GROUPS * 16 * sizeof(int),
+                                       2 * 256 * (size_t)(BN * 2 + 16) + 4 * BN * sizeof(float) + 8 * (BN / 8) * 32 * sizeof(float));
+      auto k2 = halo16_conv_kernel<BN, 4, 0, false, 0, false, false, true>;
+      static bool attr2 = false;
+      if (!attr2) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        if (e != hipSuccess) return e;
+        attr2 = true;
+      }
+      count_launch(K_HALO16_S2);
+      prof_begin(PROF_GATHER_GEMM, 2.0 * (double)g.M * (double)(g.th * g.tw) * (double)g.Clog * (double)wrows, st);
+      hipLaunchKernelGGL(k2, dim3(tiles_m * tiles_n), dim3(512), lds2, st, g, (const bf16_t*)src, (const bf16_t*)wgt, wrows, bias,
+                         (bf16_t*)out, ldc, act, tiles_n, stats, (unsigned long long*)nullptr, (const bf16_t*)nullptr, 0, EpiNorm{});
+      prof_end(PROF_GATHER_GEMM, st);
+      return hipGetLastError();
+    }
+    return hipErrorNotSupported;
+  }
+  constexpr size_t loop_lds = 2 * (size_t)H16_HBYTES + (size_t)STAGES * BN * 64 + 4 * H16_GROUPS * 16 * sizeof(int);   // (4 tables: S2)
   constexpr size_t epi_lds = 2 * 256 * (size_t)(BN * 2 + 16) + 4 * BN * sizeof(float) + 8 * (BN / 8) * 32 * sizeof(float);   // tile | corners | reduce scratch
   const size_t lds = std::max(loop_lds, epi_lds);
   const bool diag = g_v2_ablate >= 6 && g_v2_ablate <= 9 && g_v2_dbg != nullptr && STAGES == 8 && !fold;
@@ -1013,8 +1064,35 @@ static hipError_t launch_halo16(const GatherDesc& g, const void* src, const void
 // ring: see the kernel (SPADE -> upsample -> conv with z kept at the source resolution); only the 8-wave kernel takes it
 // fold: the launch is the interior input gradient of a reflect-padded 3x3 conv and also folds the frame's ring and corners
 // into the border rows / columns -- see the kernel
+int g_halo16_s2 = 1;           // A/B option "halo16_s2": 0 = the 4x4 stride-2 convs stay on the gather GEMM
+
+// the 4x4 stride-2 forward convs (kernel template S2): reflect or zero padding 1, 64 input channels.  Measured against the LDS-DMA
+// gather GEMM on the step's shapes, operands cold (tools/bench_s2.py): 64 -> 128 @256^2 x16 115 vs 135 us, x32 207 vs 235, D's
+// 64 -> 128 @128^2 x64 109 vs 135 -- but 128 -> 256 @128^2 x16 98 vs 86 and D's 128 -> 256 @64^2 x64 83 vs 80: per k-step this form
+// moves 8 KB of weights + 9 KB of halo (a plane's halo serves 4 taps, the 3x3 kernel's 9), and the gather GEMM's 128-channel
+// k-steps are twice as efficient as its 64-channel ones -- so only the 64-channel inputs are taken.
+bool halo16_s2_shape_ok(const GatherDesc& g, int ldc, int num_cu) {
+  if (!g_halo16_s2 || !g_halo16 || g_halo_bn != 0 || g_halo_stages != 0) return false;
+  if (g.sh != 2 || g.sw != 2 || g.th != 4 || g.tw != 4 || g.ys != 1 || g.xs != 1 || g.by0 != -1 || g.bx0 != -1 || g.up || g.wK != g.K || g.wtw != 4) return false;
+  if (g.Cs != 64 && g_halo16_s2 != 2) return false;                                        // (option value 2: every channel count, for A/B)
+  if (g.Cs % 32 != 0 || g.Cs < 64 || g.Ho % H16_TH != 0 || g.Wo % H16_TW != 0 || g.M != g.N * g.Ho * g.Wo || !g.out_identity) return false;
+  if (g.Hl != 2 * g.Ho || g.Wl != 2 * g.Wo) return false;
+  if ((long long)g.N * g.Hs * g.Ws * g.Cs >= (1ll << 31)) return false;                   // 32-bit offset table
+  if (ldc < 128 || ldc % 8 != 0) return false;                                             // (the 128-channel tile)
+  const int tiles_m = g.N * (g.Ho / H16_TH) * (g.Wo / H16_TW);
+  return tiles_m * ((ldc + 127) / 128) >= (num_cu * 7) / 8;
+}
+
+static hipError_t halo16_conv_s2(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out,
+                                 int ldc, int act, int num_cu, hipStream_t st, float* stats) {
+  if (!halo16_s2_shape_ok(g, ldc, num_cu)) return hipErrorNotSupported;
+  return launch_halo16<128, 4>(g, src, wgt, wrows, bias, out, ldc, act, st, stats, nullptr, false, nullptr, true);
+}
+
 hipError_t halo16_conv(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out, int ldc,
                        int act, int num_cu, hipStream_t st, float* stats, const void* ring, bool fold, const EpiNorm* en) {
+  if (g.sh == 2 && g.sw == 2 && !fold && en == nullptr && ring == nullptr)
+    return halo16_conv_s2(g, src, wgt, wrows, bias, out, ldc, act, num_cu, st, stats);
   if (en != nullptr && (!fold || ((en->kind & 0xff) != 1 && (en->kind & 0xff) != 2))) return hipErrorNotSupported;
   if (fold && (!g_halo16_fold || g.ys >= 0 || g.xs >= 0 || g.pad_mode != PAD_ZERO || g.up || g.Ho < 2 * H16_TH || g.Wo < 2 * H16_TW ||
                bias != nullptr || act != ACT_NONE || stats != nullptr || ring != nullptr))

@@ -13,7 +13,7 @@ enum ProfFamily : int { PROF_GATHER_GEMM = 0, PROF_WGRAD = 1, PROF_HALO_CONV = 2
 // host-side launch counters, one per MFMA kernel family (dei2i_launch_counts: the tests assert WHICH kernel served a shape,
 // so that a silent fall-through to the generic GEMM cannot pass a parity test meant for a tuned kernel)
 enum KernelId : int { K_GATHER_V1 = 0, K_GATHER_V2, K_HALO_CONV, K_HALO_CONV_FP8, K_THIN_CIN, K_THIN_COUT, K_WGRAD_V1, K_WGRAD_V2,
-                      K_WGRAD_HALO, K_WGRAD_THIN, K_HALO16_CONV, K_SPLITK_FINALIZE, K_COUNT };
+                      K_WGRAD_HALO, K_WGRAD_THIN, K_HALO16_CONV, K_SPLITK_FINALIZE, K_HALO16_S2, K_COUNT };
 void count_launch(int kid);
 void prof_begin(int family, double flops, hipStream_t st);
 void prof_end(int family, hipStream_t st);
@@ -49,6 +49,7 @@ hipError_t halo_conv(const GatherDesc& g, const void* src, const void* wgt, int 
 hipError_t halo16_conv(const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias, void* out, int ldc,
                        int act, int num_cu, hipStream_t st, float* stats = nullptr, const void* ring = nullptr, bool fold = false,
                        const EpiNorm* en = nullptr);
+bool halo16_s2_shape_ok(const GatherDesc& g, int ldc, int num_cu);     // the 4x4 stride-2 form of the 16 x 32 tile kernel takes this conv
 hipError_t gather_gemm(int dtype, const GatherDesc& g, const void* src, const void* wgt, int wrows, const float* bias,
                        void* out, float* ws, size_t ws_bytes, int ldc, int act, hipStream_t st);
 hipError_t gather_gemm_multi(int dtype, const GatherDesc* descs, const long long* woffs, int n, const void* src,

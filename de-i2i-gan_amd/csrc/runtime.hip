@@ -17,7 +17,7 @@ extern int g_use_wgrad_thin;
 extern int g_wt_splits_per_cu;
 extern int g_halo_mfma32;
 extern int g_halo_bn, g_halo_stages;
-extern int g_halo16, g_halo16_stages, g_halo16_fold;
+extern int g_halo16, g_halo16_stages, g_halo16_fold, g_halo16_s2;
 extern unsigned long long* g_v2_dbg;
 static int g_cus = 256;
 void set_num_cu_rt(int n) { g_cus = n > 0 ? n : 256; }
@@ -39,7 +39,7 @@ static ProfState g_prof[PROF_FAMILIES];
 static long long g_launches[K_COUNT];
 void count_launch(int kid) { g_launches[kid]++; }
 static const char* const g_kernel_names[K_COUNT] = {"gather_v1", "gather_v2", "halo_conv", "halo_conv_fp8", "thin_cin", "thin_cout",
-                                                    "wgrad_v1", "wgrad_v2", "wgrad_halo", "wgrad_thin", "halo16_conv", "splitk_finalize"};
+                                                    "wgrad_v1", "wgrad_v2", "wgrad_halo", "wgrad_thin", "halo16_conv", "splitk_finalize", "halo16_s2"};
 
 void prof_begin(int family, double flops, hipStream_t st) {
   ProfState& p = g_prof[family];
@@ -105,6 +105,7 @@ int dei2i_set_option(const char* name, int value) {
   }
   if (std::string(name) == "halo16") { g_halo16 = value; return 0; }
   if (std::string(name) == "halo16_fold") { g_halo16_fold = value; return 0; }
+  if (std::string(name) == "halo16_s2") { g_halo16_s2 = value; return 0; }
   if (std::string(name) == "halo16_stages") {
     if (value != 4 && value != 6 && value != 8) return DEI2I_ERR_BAD_ARG;
     g_halo16_stages = value;

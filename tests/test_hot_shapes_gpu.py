@@ -58,20 +58,22 @@ def maxrel(a, b):
 # DESIGN.md as open): D's first-conv dgrad (64 -> 3 channels, stride 2), the wgrads of the 64-channel-input stride-2 convs
 # and of D's first and last conv, D's last conv forward (M = 1024 rows: split-K generic GEMM).
 R, V2, V1 = {"halo_conv": 1, "gather_v1": 1}, {"gather_v2": 1}, {"gather_v1": 1}
+# "halo16_s2": the 16 x 32 tile kernel's stride-2 form (parity planes in LDS) -- taken for the 64-channel inputs, where it beats the
+# gather GEMM (conv_halo16.hip: halo16_s2_shape_ok)
 R16 = {"halo16_conv": 1}                            # 16 x 32 tile kernel: interior, reflect ring and the four frame corners in ONE launch
 HOT = [
     ("res 256->256 3x3 @64^2 N=16", 256, 256, 3, 1, 1, False, 64, 64, 16, "none", "halo16_conv", R16, "wgrad_halo"),
     ("res 256->256 3x3 @64^2 N=8", 256, 256, 3, 1, 1, False, 64, 64, 8, "none", "halo_conv", R, "wgrad_halo"),
     ("dec0 256->128 up @128^2 N=16", 256, 128, 3, 1, 1, True, 64, 64, 16, "none", "halo16_conv", V2, "wgrad_halo"),
     ("dec1 128->64 up @256^2 N=16", 128, 64, 3, 1, 1, True, 128, 128, 16, "none", "halo16_conv", V2, "wgrad_halo"),
-    ("enc0 64->128 4x4 s2 @256^2 N=16", 64, 128, 4, 2, 1, False, 256, 256, 16, "none", "gather_v2", V2, "wgrad_v1"),
+    ("enc0 64->128 4x4 s2 @256^2 N=16", 64, 128, 4, 2, 1, False, 256, 256, 16, "none", "halo16_s2", V2, "wgrad_v1"),
     ("enc1 128->256 4x4 s2 @128^2 N=16", 128, 256, 4, 2, 1, False, 128, 128, 16, "none", "gather_v2", V2, "wgrad_v2"),
     ("stem 3->64 7x7 @256^2 N=16", 3, 64, 7, 1, 3, False, 256, 256, 16, "none", "thin_cin", {"thin_cout": 1, "gather_v1": 1}, "wgrad_thin"),
     ("heads 64->4 3x3 @256^2 N=16", 64, 4, 3, 1, 1, False, 256, 256, 16, "none", "thin_cout", {"thin_cin": 1, "gather_v1": 1}, "wgrad_halo"),
     ("D0 3->64 4x4 s2 @256^2 N=64 +LReLU", 3, 64, 4, 2, 1, False, 256, 256, 64, "leaky_relu", "thin_cin", V1, "wgrad_v1"),
-    ("D1 64->128 4x4 s2 @128^2 N=64 +LReLU", 64, 128, 4, 2, 1, False, 128, 128, 64, "leaky_relu", "gather_v2", V2, "wgrad_v1"),
+    ("D1 64->128 4x4 s2 @128^2 N=64 +LReLU", 64, 128, 4, 2, 1, False, 128, 128, 64, "leaky_relu", "halo16_s2", V2, "wgrad_v1"),
     ("D2 128->256 4x4 s2 @64^2 N=64 +LReLU", 128, 256, 4, 2, 1, False, 64, 64, 64, "leaky_relu", "gather_v2", V2, "wgrad_v2"),
-    ("D3 256->512 4x4 s2 @32^2 N=64 +LReLU", 256, 512, 4, 2, 1, False, 32, 32, 64, "leaky_relu", "gather_v2", V2, "wgrad_v2"),
+    ("D3 256->512 4x4 s2 @32^2 N=64 +LReLU", 256, 512, 4, 2, 1, False, 32, 32, 64, "leaky_relu", "gather_v2", V2, "wgrad_v2"),   # 16x16 outputs: below the 16x32 tile
     ("D4 512->1024 4x4 s2 @16^2 N=64 +LReLU", 512, 1024, 4, 2, 1, False, 16, 16, 64, "leaky_relu", "gather_v2", V2, "wgrad_v2"),
     ("D5 1024->2048 4x4 s2 @8^2 N=64 +LReLU", 1024, 2048, 4, 2, 1, False, 8, 8, 64, "leaky_relu", "gather_v1", V2, "wgrad_v1"),
 ]
@@ -351,3 +353,39 @@ def test_operand_addresses_on_both_sides_of_the_2gib_line():
         assert rel_l2(ops.to_nchw(y, cout), y_ref.detach()) < 3e-3, name
         assert rel_l2(dx[..., :cin].permute(0, 3, 1, 2), gx_ref) < 4e-3, name
         assert rel_l2(dw, gw_ref) < 1e-3, name
+
+
+@pytest.mark.parametrize("cin,cout,H,W,N,reflect,act", [(128, 256, 128, 128, 16, True, "none"), (64, 128, 64, 128, 64, False, "leaky_relu"),
+                                                        (256, 136, 64, 64, 64, True, "none"), (96, 128, 64, 128, 64, True, "leaky_relu")])
+def test_stride2_halo_form_on_other_channel_counts_vs_gather_gemm_and_oracle(ops, cin, cout, H, W, N, reflect, act):
+    """The stride-2 form of the 16 x 32 tile kernel (conv_halo16.hip S2) is dispatched for 64-channel inputs only (where it is the
+    faster kernel); option halo16_s2 = 2 sends every shape it can take to it: 128 / 256 / 96 input channels (several channel blocks per
+    parity plane, two output-channel tiles, a ragged last channel tile), zero padding, non-square images -- against the oracle's conv and
+    bit-for-bit statistics against the stored output."""
+    from de_i2i_gan_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(41)
+    x = torch.randn(N, cin, H, W).bfloat16().float()
+    w = (torch.randn(cout, cin, 4, 4) * math.sqrt(2.0 / (cin * 16))).bfloat16().float()
+    y_ref = O.conv2d(x, w, stride=2, pad=1, mode="reflect" if reflect else "zeros")
+    if act == "leaky_relu":
+        y_ref = O.leaky_relu(y_ref)
+    xg = ops.to_nhwc(x.to(DEV), ops.BF16)
+    geom = ops.ConvGeom(cin, cout, 4, 2, 1, reflect, False)
+    _lib.check(lib.dei2i_set_option(b"halo16_s2", 2), "set_option")
+    try:
+        _counts()
+        y = ops.conv2d(xg, w.to(DEV), None, ops.PackedWeights(), geom, act, stats=True)
+        torch.cuda.synchronize()
+        fam = _counts()
+    finally:
+        _lib.check(lib.dei2i_set_option(b"halo16_s2", 1), "set_option")
+    assert fam == {"halo16_s2": 1}, fam
+    got = ops.to_nchw(y, cout)
+    assert rel_l2(got, y_ref) < 3e-3 and maxrel(got, y_ref) < 1.5e-2, (rel_l2(got, y_ref), maxrel(got, y_ref))
+    if ops.BF16.pad(cout) > cout:
+        assert float(y[..., cout:].abs().max()) == 0.0
+    partial, chunks = y._dei2i_stats                       # the epilogue's statistics records of the stored (rounded) output
+    yf = y.float()
+    assert maxrel(partial.double().sum(dim=1)[:, 0], yf.sum(dim=(1, 2)).double()) < 1e-4
+    assert maxrel(partial.double().sum(dim=1)[:, 1], (yf * yf).sum(dim=(1, 2)).double()) < 1e-5
