@@ -183,6 +183,14 @@ class DefectGanModel(BaseModel):
         gan_loss = self._mean([self._cal_loss(fake_src, 0.0, "bce"), self._cal_loss(real_src, 1.0, "bce")])
         return gan_loss, clf_loss
 
+    def _forks_generator_chains(self, bg_data, nm_feat):
+        """The plain SPADE generator only: spectral norm iterates (u, v) in place per forward and NoiseInjection draws from one RNG
+        -- both are ordered by the reference's pass order --, the style variants bring a second trained network into the passes."""
+        o = self.opt
+        return (ops.forked_chains and bg_data.is_cuda and nm_feat is None and o.style_norm_block_type == "spade"
+                and not getattr(o, "use_spectral", False) and not getattr(o, "add_noise", False) and not getattr(o, "cycle_gan", False)
+                and not os.environ.get("DEI2I_SPLIT_D"))
+
     def _compute_generator_loss(self, bg_data, df_labels, df_data):
         """defectgan_model.py:173-249"""
         nm_labels, df_labels = self._get_labels(df_labels)
@@ -195,10 +203,35 @@ class DefectGanModel(BaseModel):
             self.netG.enable_sean_distill_loss(True)
         if sean and getattr(self.opt, "use_running_stats", False):
             self.netG.track_running_stats = True
-        fake_defects, df_prob = self.netG(bg_data, df_labels, df_feat)
-        recover_normals, rec_df_prob = self.netG(fake_defects, nm_labels, nm_feat)
-        fake_normals, nm_prob = self.netG(df_data, nm_labels, nm_feat)
-        recover_defects, rec_nm_prob = self.netG(fake_normals, df_labels, df_feat)
+        if self._forks_generator_chains(bg_data, nm_feat):
+            # bg -> fake_defects -> recover_normals and df -> fake_normals -> recover_defects share nothing but the parameters: two
+            # streams (ops.forked_chains).  BatchNorm's four running-statistics updates are replayed in the reference's pass order
+            # after the join (ops.bn_running_deferred); everything downstream (D, the losses) runs on the joining stream.
+            main = torch.cuda.current_stream(bg_data.device)
+            chain_a, chain_b = ops.chain_streams(bg_data.device)
+            with ops.bn_running_deferred() as running:
+                chain_a.wait_stream(main)
+                chain_b.wait_stream(main)
+                with torch.cuda.stream(chain_a):
+                    running.pass_index = 0
+                    fake_defects, df_prob = self.netG(bg_data, df_labels, df_feat)
+                    running.pass_index = 1
+                    recover_normals, rec_df_prob = self.netG(fake_defects, nm_labels, nm_feat)
+                with torch.cuda.stream(chain_b):
+                    running.pass_index = 2
+                    fake_normals, nm_prob = self.netG(df_data, nm_labels, nm_feat)
+                    running.pass_index = 3
+                    recover_defects, rec_nm_prob = self.netG(fake_normals, df_labels, df_feat)
+                main.wait_stream(chain_a)
+                main.wait_stream(chain_b)
+                running.apply()
+            for t in (fake_defects, df_prob, recover_normals, rec_df_prob, fake_normals, nm_prob, recover_defects, rec_nm_prob):
+                t.record_stream(main)                       # (allocated on a chain's stream, consumed on the joining one)
+        else:
+            fake_defects, df_prob = self.netG(bg_data, df_labels, df_feat)
+            recover_normals, rec_df_prob = self.netG(fake_defects, nm_labels, nm_feat)
+            fake_normals, nm_prob = self.netG(df_data, nm_labels, nm_feat)
+            recover_defects, rec_nm_prob = self.netG(fake_normals, df_labels, df_feat)
         distill = None
         if self._sean_distill():
             distill = self.netG.get_sean_distill_loss()

@@ -141,11 +141,27 @@ _workspaces = {}
 
 
 def _workspace(device, nbytes: int, slot: str = "splitk") -> torch.Tensor:
-    ws = _workspaces.get((device, slot))
+    """Scratch of one kernel launch (split-K slabs, the padded dgrad frame, ...), reused launch after launch ON ONE STREAM: every
+    stream that runs ops has its own set (two chains of a forked pass -- ``forked_chains`` -- must not share slabs)."""
+    key = (torch.device(device), slot)
+    sid = torch.cuda.current_stream(device).cuda_stream
+    if sid != _default_stream_id(key[0]):
+        key = key + (sid,)
+    ws = _workspaces.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
         ws = torch.empty(max(nbytes // 4 + 1, 1 << 20), dtype=torch.float32, device=device)
-        _workspaces[(device, slot)] = ws
+        _workspaces[key] = ws
     return ws
+
+
+_default_stream_ids = {}
+
+
+def _default_stream_id(device):
+    sid = _default_stream_ids.get(device)
+    if sid is None:
+        sid = _default_stream_ids[device] = torch.cuda.default_stream(device).cuda_stream
+    return sid
 
 
 # ---- in-place accumulation of parameter gradients within one backward pass --------------------------------------
@@ -163,19 +179,25 @@ def _workspace(device, nbytes: int, slot: str = "splitk") -> torch.Tensor:
 _grad_slots = {}
 
 
-def _grad_target(param, shape, device):
-    """-> (tensor to return to autograd or None, its address, accumulate flag)"""
+def _grad_target(param, shape, device, stream=None):
+    """-> (tensor to return to autograd or None, its address, accumulate flag); ``stream``: the stream the caller's kernels run on
+    when that is not the current one (the weight-gradient side stream)"""
     tid = torch._C._current_graph_task_id()
     key = param.data_ptr() if (param.is_leaf and tid >= 0) else None
+    # (in-place accumulation is a read-modify-write ordered by ONE stream: a node that runs on another stream -- the two chains of
+    #  a forked pass -- returns its own tensor and autograd sums them, with its own stream synchronisation)
+    sid = 0
+    if key is not None and torch.device(device).type == "cuda":
+        sid = (stream if stream is not None else torch.cuda.current_stream(device)).cuda_stream
     if key is not None:
         slot = _grad_slots.get(key)
-        if slot is not None and slot[0] == tid and slot[2] == tuple(shape):
+        if slot is not None and slot[0] == tid and slot[2] == tuple(shape) and slot[3] == sid:
             first = slot[1]()
             if first is not None:                       # still the tensor in autograd's input buffer
                 return None, first.data_ptr(), 1
     t = torch.empty(shape, dtype=torch.float32, device=device)
     if key is not None:
-        _grad_slots[key] = (tid, weakref.ref(t), tuple(shape))
+        _grad_slots[key] = (tid, weakref.ref(t), tuple(shape), sid)
     return t, t.data_ptr(), 0
 
 
@@ -353,6 +375,16 @@ class PackedWeights:
         self.fwd = None
         self.dgrad = None
         self.fp8 = None            # (packed e4m3 forward weights, dequant scalar) of the fp8 forward mode
+        self._packed_on = None     # (stream id, event) of the last pack launch: another stream waits for it before reading
+
+    def _mark_packed(self):
+        ev = torch.cuda.Event()
+        ev.record()
+        self._packed_on = (torch.cuda.current_stream().cuda_stream, ev)
+
+    def _await_pack(self):
+        if self._packed_on is not None and self._packed_on[0] != torch.cuda.current_stream().cuda_stream:
+            torch.cuda.current_stream().wait_event(self._packed_on[1])
 
     @staticmethod
     def _stamp(t: torch.Tensor):
@@ -372,16 +404,23 @@ class PackedWeights:
         w = weight.detach()
         if w.dtype != torch.float32 or not w.is_contiguous():
             w = w.float().contiguous()
+        self._await_pack()            # (copies packed by a launch on ANOTHER stream: the two chains of a forked pass share weights)
+        packed = False
         if need_fwd and need_dgrad and self.fwd is None and self.dgrad is None:       # the training path: one launch
             self.fwd = torch.empty(lib.dei2i_packed_fwd_elems(byref(d)), dtype=prec.dtype, device=weight.device)
             self.dgrad = torch.empty(lib.dei2i_packed_dgrad_elems(byref(d)), dtype=prec.dtype, device=weight.device)
             L.check(lib.dei2i_pack_weight_both(byref(d), _p(w), _p(self.fwd), _p(self.dgrad), _stream()), "pack_weight_both")
+            packed = True
         if need_fwd and self.fwd is None:
             self.fwd = torch.empty(lib.dei2i_packed_fwd_elems(byref(d)), dtype=prec.dtype, device=weight.device)
             L.check(lib.dei2i_pack_weight_fwd(byref(d), _p(w), _p(self.fwd), _stream()), "pack_weight_fwd")
+            packed = True
         if need_dgrad and self.dgrad is None:
             self.dgrad = torch.empty(lib.dei2i_packed_dgrad_elems(byref(d)), dtype=prec.dtype, device=weight.device)
             L.check(lib.dei2i_pack_weight_dgrad(byref(d), _p(w), _p(self.dgrad), _stream()), "pack_weight_dgrad")
+            packed = True
+        if packed:
+            self._mark_packed()
         return self.fwd, self.dgrad
 
     def get_fp8(self, weight: torch.Tensor, sources, prec: Precision, geom: ConvGeom, cins: int, couts: int):
@@ -533,7 +572,11 @@ def _wgrad_join(device, tid):
     def join():
         if _wgrad_join_pending.get(device) == tid:
             del _wgrad_join_pending[device]
-        torch.cuda.current_stream(device).wait_stream(_wgrad_streams[device])
+        side = _wgrad_streams[device]
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.default_stream(device).wait_stream(side)
+        for st in _chain_streams.get(torch.device(device), ()):       # (whichever stream the caller goes on with)
+            st.wait_stream(side)
     return join
 
 
@@ -558,7 +601,9 @@ def _conv_wgrad(lib, prec, geom, x, g, weight, pro=None, keep=()):
             scratch = _wgrad_scratch(lib, d, dev, "wgrad_side")
     else:
         scratch = _wgrad_scratch(lib, d, dev, "wgrad")
-    dw, dw_ptr, accumulate = _grad_target(weight, weight.shape, dev)
+    # (all leaf-weight gradients of a pass run on the ONE side stream, whichever stream their node belongs to: they accumulate in place
+    #  across the chains of a forked pass too -- and no autograd add ever reads them before the end-of-pass join)
+    dw, dw_ptr, accumulate = _grad_target(weight, weight.shape, dev, stream=side)
 
     def launch():
         if pro is None:
@@ -739,6 +784,63 @@ def to_nchw(x_nhwc, c: int):
 # --------------------------------------------------------------------------------------------------------------
 # BatchNorm2d (+ LeakyReLU) (+ residual)
 # --------------------------------------------------------------------------------------------------------------
+forked_chains = True             # the G loss's two independent chains of generator passes on two streams (models/defectgan_model.py)
+_chain_streams = {}
+
+
+def chain_streams(device):
+    """The two streams the chains of a forked pass run on (created once per device)."""
+    dev = torch.device(device)
+    st = _chain_streams.get(dev)
+    if st is None:
+        st = _chain_streams[dev] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+    return st
+
+
+# ---- two independent chains of generator passes on two streams ---------------------------------------------------
+# The G loss runs the generator four times (defectgan_model.py:185-190): fake_defects -> recover_normals and fake_normals ->
+# recover_defects are two chains that share nothing but the parameters.  On two streams the kernels of one chain fill the other
+# chain's kernel tails and launch boundaries (a dependent kernel boundary is ~1.7 us and the step has ~1 350 of them) and its
+# HBM-bound passes run beside the other's MFMA-bound ones.  What has to stay ordered is BatchNorm's running-statistics update
+# (running = (1 - m) * running + m * batch, four times, in the reference's pass order): inside a ``bn_running_deferred`` scope a
+# training-mode BatchNorm leaves m * batch of its pass in a buffer of its own, and ``apply()`` replays the updates in the order
+# the passes were NUMBERED, on the joining stream.
+class bn_running_deferred:
+    current = None
+
+    def __init__(self):
+        self.updates = []            # (pass index, running_mean, running_var, num_batches_tracked, m * batch mean, m * batch var, momentum)
+        self.pass_index = 0
+
+    def __enter__(self):
+        self.prev, bn_running_deferred.current = bn_running_deferred.current, self
+        return self
+
+    def __exit__(self, *exc):
+        bn_running_deferred.current = self.prev
+        return False
+
+    def take(self, running_mean, running_var, num_batches_tracked, momentum):
+        zm, zv = torch.zeros_like(running_mean), torch.zeros_like(running_var)
+        self.updates.append((self.pass_index, running_mean, running_var, num_batches_tracked, zm, zv, momentum))
+        return zm, zv
+
+    def apply(self):
+        """running <- (1 - m) * running + (m * batch) for every recorded update, passes in index order (on the current stream,
+        which must already wait for the streams the passes ran on)"""
+        for k in sorted({u[0] for u in self.updates}):
+            ups = [u for u in self.updates if u[0] == k]
+            for m in sorted({u[6] for u in ups}):
+                sel = [u for u in ups if u[6] == m]
+                run = [u[1] for u in sel] + [u[2] for u in sel]
+                torch._foreach_mul_(run, 1.0 - m)
+                torch._foreach_add_(run, [u[4] for u in sel] + [u[5] for u in sel])
+            counters = [u[3] for u in ups if u[3] is not None]
+            if counters:
+                torch._foreach_add_(counters, 1)
+        self.updates = []
+
+
 def _bn_coefs(lib, y, prec, weight, bias, running_mean, running_var, training, momentum, eps, num_batches_tracked):
     """BatchNorm2d statistics + affine coefficients of an NHWC tensor: a[c] = weight * rstd, b[c] = bias - mean * a (batch
     statistics in training mode, running statistics otherwise; running buffers and the counter are updated in place).
@@ -752,6 +854,10 @@ def _bn_coefs(lib, y, prec, weight, bias, running_mean, running_var, training, m
     if nf > c or running_mean.numel() != nf or running_var.numel() != nf:
         raise ValueError(f"batchnorm_act: {nf} features for a {c}-channel activation")
     rm, rv = running_mean, running_var
+    deferred = bn_running_deferred.current if training else None
+    if deferred is not None:                     # this pass's m * batch statistics go to buffers of their own (see bn_running_deferred)
+        rm, rv = deferred.take(running_mean, running_var, num_batches_tracked, float(momentum))
+        running_mean, running_var, num_batches_tracked = rm, rv, None
     if nf < c:
         # the channel stride is padded to a 16-byte vector (c > num_features: widths that are no multiple of 8 / 4): the
         # kernels index every per-channel vector up to c, so hand them padded copies -- weight = bias = 0 makes the

@@ -317,8 +317,8 @@ def test_side_stream_scratch_regrowth_at_default_widths_is_bit_identical():
             (ls[0] + 5 * ls[1] + 5 * ls[2] + 5 * ls[3] + ls[4]).backward()
             grads[side] = [p.grad.clone() for net in (tr.model.netD, tr.model.netG) for p in net.parameters() if p.grad is not None]
             if side:      # the regrow path was actually taken: the slot ended larger than its first size
-                ws = ops._workspaces[(torch.device("cuda:0"), "wgrad_side")]
-                assert ws.numel() * 4 > (96 << 20), ws.numel()
+                ws = [v for k_, v in ops._workspaces.items() if k_[1] == "wgrad_side"]      # (keyed by device, slot and side stream)
+                assert len(ws) == 1 and ws[0].numel() * 4 > (96 << 20), [w_.numel() for w_ in ws]
         finally:
             ops.wgrad_side_stream = True
     assert len(grads[True]) == len(grads[False]) > 58
@@ -521,3 +521,46 @@ def test_eval_mode_batchnorm_folded_into_the_conv_weights():
             assert torch.equal(out_g[0].detach(), outs[False][0])
     finally:
         ops.fold_eval_bn = keep
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pname", ["f32", "bf16"])
+def test_generator_chains_on_two_streams_equal_the_one_stream_pass(pname):
+    """ops.forked_chains: the G loss's passes bg -> fake_defects -> recover_normals and df -> fake_normals -> recover_defects
+    (defectgan_model.py:185-190) on two streams, joined before D.  Same kernels on the same operands: the five losses are the
+    one-stream pass's BITS; BatchNorm's running statistics after the four ordered updates (replayed after the join,
+    ops.bn_running_deferred) and the counter agree to fp32 rounding of the update formula; the parameter gradients differ only by
+    the order in which the two chains' contributions are summed (in-place within a chain, one autograd add across chains)."""
+    from de_i2i_gan_amd import ops
+    from de_i2i_gan_amd.trainers.defectgan_trainer import DefectGanTrainer
+    c = dict(image_size=128, batch=4, num_layers=4, ngf=32, ndf=32, hidden_nc=64)
+    bg, labels, df = O.synthetic_batch(c["batch"], c["image_size"])
+    res = {}
+    keep = ops.forked_chains
+    try:
+        for fork in (True, False):
+            ops.forked_chains = fork
+            torch.manual_seed(11)
+            tr = DefectGanTrainer(make_opt(c, "cuda:0", pname))
+            G = tr.model.netG
+            assert tr.model._forks_generator_chains(bg.to(DEV), None) == fork
+            for it in range(2):                      # the second pass reuses the chains' streams, workspaces and packed weights
+                for p in G.parameters():
+                    p.grad = None
+                ls = tr.model("generator", bg, labels, df)
+                (ls[0] + 5 * ls[1] + 5 * ls[2] + 5 * ls[3] + ls[4]).backward()
+            torch.cuda.synchronize()
+            res[fork] = ([float(v) for v in ls], {k: p.grad.clone() for k, p in G.named_parameters() if p.grad is not None},
+                         {k: v.clone() for k, v in G.state_dict().items() if "running_" in k or "num_batches" in k})
+    finally:
+        ops.forked_chains = keep
+    (lf, gf, bf), (l1, g1, b1) = res[True], res[False]
+    assert lf == l1, (lf, l1)
+    assert gf.keys() == g1.keys() and len(gf) > 50
+    for k in gf:
+        assert rel_l2(gf[k], g1[k]) < (1e-5 if pname == "f32" else 2e-5) or float(g1[k].norm()) < 1e-6 * max(float(v.norm()) for v in g1.values()), k
+    for k in bf:
+        if "num_batches" in k:
+            assert int(bf[k]) == int(b1[k]) == 8
+        else:
+            assert maxrel(bf[k], b1[k]) < 1e-6, k
