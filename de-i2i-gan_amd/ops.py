@@ -808,9 +808,12 @@ def chain_streams(device):
 class bn_running_deferred:
     current = None
 
+    _arenas = {}                     # device -> flat fp32 zeros the passes' buffers are carved from (zeroed again by apply(): one fill per step)
+
     def __init__(self):
         self.updates = []            # (pass index, running_mean, running_var, num_batches_tracked, m * batch mean, m * batch var, momentum)
         self.pass_index = 0
+        self._used = {}
 
     def __enter__(self):
         self.prev, bn_running_deferred.current = bn_running_deferred.current, self
@@ -821,7 +824,15 @@ class bn_running_deferred:
         return False
 
     def take(self, running_mean, running_var, num_batches_tracked, momentum):
-        zm, zv = torch.zeros_like(running_mean), torch.zeros_like(running_var)
+        dev, n = running_mean.device, running_mean.numel()
+        arena, off = bn_running_deferred._arenas.get(dev), self._used.get(dev, 0)
+        if arena is None or off + 2 * n > arena.numel() or running_mean.dtype != torch.float32:
+            zm, zv = torch.zeros_like(running_mean), torch.zeros_like(running_var)          # (first step / an odd buffer: its own zeros)
+            if running_mean.dtype == torch.float32:
+                self._want = getattr(self, "_want", 0) + 2 * n
+        else:
+            zm, zv = arena[off:off + n], arena[off + n:off + 2 * n]
+            self._used[dev] = off + 2 * n
         self.updates.append((self.pass_index, running_mean, running_var, num_batches_tracked, zm, zv, momentum))
         return zm, zv
 
@@ -838,7 +849,16 @@ class bn_running_deferred:
             counters = [u[3] for u in ups if u[3] is not None]
             if counters:
                 torch._foreach_add_(counters, 1)
+        devs = {u[1].device for u in self.updates}
         self.updates = []
+        for dev in devs:                         # the arena is all zeros again for the next scope; grown to what this one asked for
+            need = self._used.get(dev, 0) + getattr(self, "_want", 0)
+            arena = bn_running_deferred._arenas.get(dev)
+            if arena is None or arena.numel() < need:
+                bn_running_deferred._arenas[dev] = torch.zeros(max(need, 1 << 12), dtype=torch.float32, device=dev)
+            elif self._used.get(dev, 0):
+                arena[:self._used[dev]].zero_()
+        self._used, self._want = {}, 0
 
 
 def _bn_coefs(lib, y, prec, weight, bias, running_mean, running_var, training, momentum, eps, num_batches_tracked):
