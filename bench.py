@@ -337,6 +337,7 @@ def main():
         # kernel sharing the GPU and prices neither
         extra_steps = min(3, args.steps)
         _ops.wgrad_side_stream = False
+        _ops.forked_chains = False                      # (one stream: nothing runs beside the bracketed kernel)
         for name, fid in fams:
             lib.dei2i_prof_enable(fid, 1)
         for _ in range(extra_steps):
@@ -344,6 +345,7 @@ def main():
         sync()
         fam_extra = collect()
         _ops.wgrad_side_stream = not args.no_wgrad_stream
+        _ops.forked_chains = not args.no_forked_chains
     if hasattr(tr, "flush_losses"):
         tr.flush_losses()
     if rank == 0:
@@ -441,9 +443,9 @@ def main():
                             "launches_per_step": dom["launches_per_step"], "avg_launch_ms": dom["avg_launch_ms"],
                             "flops_per_launch": dom["flops_per_launch"], "ms_per_step": dom["ms_per_step"],
                             "timing": "kernel-alone: HIP events on the launch stream around EVERY launch in %d extra steps after the timed "
-                                      "region, run with the weight gradients on the main stream (with the side stream a bracket around a "
-                                      "backward conv spans two kernels sharing the GPU); profiles/r03_serial_kernel_stats.csv is the "
-                                      "rocprofv3 table of the same serial configuration" % extra_steps,
+                                      "region, run on ONE stream (weight gradients on the main stream, the generator chains not forked: with "
+                                      "side streams a bracket around a conv spans two kernels sharing the GPU); "
+                                      "profiles/r03_serial_kernel_stats.csv is the rocprofv3 table of the same serial configuration" % extra_steps,
                             "other_instance": other,
                             "halo16_family_flop_weighted": {"achieved": fam_ach, "frac": fam_ach / peak,
                                                             "launches_per_step": (xhn + xfn) / max(extra_steps, 1)},

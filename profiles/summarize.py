@@ -29,6 +29,8 @@ def family(name):
         return "halo16_conv_fwd"
     if "halo16_conv_kernel<128, 8, 0, true" in name:
         return "halo16_conv_fold"
+    if "halo16_conv_kernel<128, 4, 0, false, 0, false, false, true" in name:
+        return "halo16_conv_s2"         # the stride-2 4x4 form (parity planes in LDS)
     for fam, key in FAMILIES:
         if key + "<" in name or key + "(" in name:
             return fam
