@@ -226,51 +226,63 @@ hipError_t thin_cin_conv(const GatherDesc& g, const void* src, const void* wgt, 
 // result goes straight to memory as 8-byte stores -- a wave writes 32 pixels x 16 B = 512 contiguous bytes.
 // =====================================================================================================================
 constexpr int TO_MAXCO = 8;
+constexpr int TO_MAXG = 9;                         // LDS-DMA pieces per wave and tile (7x7: 34 groups x 2 planes = 68 -> 9 per wave)
 
+DEI2I_D int sw_to(int row) { return ((row >> 2) & 1) << 1; }
+
+// Round 3 form: 16x16x32 MFMAs (A = 16 weight rows of which <= 8 are live, B = 16 pixels x 32 channels).  The 32x32x16 form this
+// replaces spent a 32-row A operand on 8 live rows (75 % of the matrix work wasted: the 7x7 input gradient of the stem ran 196
+// MFMAs of 32 cycles per 32 pixels) and re-read the weight fragment from LDS for every MFMA in every wave -- the 3x3 heads were
+// LDS-bound at twice their MFMA time.  Here a tap of a 32-pixel tile row is 4 MFMAs of 16 cycles on 4 fragment reads, the <= 9-tap
+// weights (18 fragments) live in registers for the whole launch (WREG), the 49-tap ones stream one fragment per (tap, k-block).
+//   halo in LDS : two PLANES (channels 0..31 | 32..63) of [pixel][64 B] rows, 16-byte chunk c of row r at slot c ^ (((r >> 2) & 1)
+//                 << 1) -- conv_halo16.hip's image: a ds_read_b128 of 16 consecutive pixels x 4 k-groups is conflict-free at any
+//                 tap shift; one LDS-DMA piece = 16 pixels of one plane
+//   D           : lane (px = l16, kg) holds channels 4kg .. 4kg+3 of its pixel: lanes kg < 2 store 8 bytes each
+template <bool WREG>
 __global__ __launch_bounds__(512) void thin_cout_conv_kernel(const GatherDesc g, const bf16_t* __restrict__ src,
                                                              const bf16_t* __restrict__ wgt, const int wrows,
                                                              const float* __restrict__ bias, bf16_t* __restrict__ out,
                                                              const int ldc, const int act, const int ntiles, const int halo_bytes,
                                                              const int nbuf) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const halo = smem;                                  // [nbuf][halo_bytes], 128-byte pixel rows, XOR-swizzled
-  unsigned char* const wl = smem + nbuf * halo_bytes;                   // [9 rows][K*2 B]: 8 weight rows + one zero row
+  unsigned char* const halo = smem;                                  // [nbuf][2 planes][plane_bytes]
+  unsigned char* const wl = smem + nbuf * halo_bytes;                // !WREG: [8 rows][K*2 B] weights
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // tile row of this wave
-  const int lr = lane & 31, lh = lane >> 5;
+  const int l16 = lane & 15, kg = lane >> 4;
   const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_thin);
   const int ntaps = g.th * g.tw;
   const int wrow_bytes = g.K * 2;
+  const int plane_bytes = halo_bytes >> 1;
 
-  for (int i = tid; i < (TO_MAXCO + 1) * (wrow_bytes >> 4); i += 512) {
-    const int row = i / (wrow_bytes >> 4), ch = i - row * (wrow_bytes >> 4);
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (row < wrows) v = *reinterpret_cast<const u32x4*>(wgt + (size_t)row * g.K + ch * 8);
-    *reinterpret_cast<u32x4*>(wl + row * wrow_bytes + ch * 16) = v;
+  if constexpr (!WREG) {
+    for (int i = tid; i < TO_MAXCO * (wrow_bytes >> 4); i += 512) {
+      const int row = i / (wrow_bytes >> 4), ch = i - row * (wrow_bytes >> 4);
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (row < wrows) v = *reinterpret_cast<const u32x4*>(wgt + (size_t)row * g.K + ch * 8);
+      *reinterpret_cast<u32x4*>(wl + row * wrow_bytes + ch * 16) = v;
+    }
   }
 
   const int hwd = TC_TW + g.tw - 1, hht = TC_TH + g.th - 1;
   const int npix = hwd * hht;
-  const int ngroups = (npix + 7) >> 3;                               // 8-pixel LDS-DMA groups
+  const int ngroups = (npix + 15) >> 4;                              // 16-pixel LDS-DMA groups per plane
+  const int npieces = 2 * ngroups;
   const int tiles_x = g.Wo / TC_TW, tiles_y = g.Ho / TC_TH;
   const int tiles_img = tiles_x * tiles_y;
 
-  // Per-lane constants of this wave's halo pieces (group wave + 8 i: pixel p = 8 grp + lane / 8), hoisted by hand: the halo row /
-  // column of the pixel and its swizzled channel offset.  The address chain per piece was ~60 instructions (a division by the
-  // halo width, two bounds checks, 64-bit products) against 36 MFMAs of compute per 3x3 tile: the issue phase, not the stream,
-  // set the kernel's time (wgrad_halo.hip has the measurement of the same pattern).  Reflect-padded launches (the heads) issue a
-  // piece as a wave-uniform image base + a 32-bit per-lane byte offset; zero-padded ones (the stem's interior dgrad) keep the
-  // per-lane pointer with its zero-page select.
-  constexpr int TO_MAXG = 9;                                           // 7x7: 67 groups -> 9 per wave
+  // Per-lane constants of this wave's halo pieces (piece q = wave + 8 i: plane q & 1, group q >> 1, pixel 16 grp + lane / 4), hoisted:
+  // the halo row / column of the pixel and its swizzled channel offset (the address chain per piece was the issue phase's time).
   int hyx[TO_MAXG], coff[TO_MAXG];
 #pragma unroll
   for (int i = 0; i < TO_MAXG; ++i) {
-    const int grp = wave + 8 * i;
-    const int p = grp * 8 + (lane >> 3);
+    const int q = wave + 8 * i;
+    const int grp = q >> 1, p = grp * 16 + (lane >> 2);
     const int hy = p / hwd, hx = p - hy * hwd;
-    hyx[i] = (grp < ngroups && p < npix) ? ((hy << 16) | hx) : -1;
-    coff[i] = ((lane & 7) ^ ((p >> 1) & 7)) << 3;
+    hyx[i] = (q < npieces && p < npix) ? ((hy << 16) | hx) : -1;
+    coff[i] = (q & 1) * 32 + (((lane & 3) ^ sw_to(p)) << 3);           // channel offset of this lane's 16-byte chunk
     asm volatile("" : "+v"(hyx[i]), "+v"(coff[i]));
   }
   const bool fast = g.pad_mode == PAD_REFLECT;
@@ -284,14 +296,15 @@ __global__ __launch_bounds__(512) void thin_cout_conv_kernel(const GatherDesc g,
     const bf16_t* ibase = src + (size_t)img * ((size_t)g.Hs * g.Ws * 64);                    // wave-uniform
 #pragma unroll
     for (int i = 0; i < TO_MAXG; ++i) {
-      const int grp = wave + 8 * i;
-      if (grp >= ngroups) break;                                     // wave-uniform
+      const int q = wave + 8 * i;
+      if (q >= npieces) break;                                       // wave-uniform
+      const unsigned dst = (unsigned)(buf * halo_bytes + (q & 1) * plane_bytes + (q >> 1) * 1024);
       if (fast) {
-        const int q = hyx[i] < 0 ? 0 : hyx[i];                       // padding slots of the last group: any valid pixel (never read)
-        const int vy = hy0 + (q >> 16), vx = hx0 + (q & 0xffff);
+        const int hq = hyx[i] < 0 ? 0 : hyx[i];                      // padding rows of the last group: any valid pixel (never read)
+        const int vy = hy0 + (hq >> 16), vx = hx0 + (hq & 0xffff);
         const int ay = max(vy, -vy), ax = max(vx, -vx);
         const int y = min(ay, 2 * g.Hl - 2 - ay), x = min(ax, 2 * g.Wl - 2 - ax);
-        glds16_asm_s(ibase, (unsigned)((((y >> g.up) * g.Ws + (x >> g.up)) << 6) + coff[i]) * 2u, halo_lds + buf * halo_bytes + grp * 1024);
+        glds16_asm_s(ibase, (unsigned)((((y >> g.up) * g.Ws + (x >> g.up)) << 6) + coff[i]) * 2u, halo_lds + dst);
       } else {
         const bf16_t* ptr = zero;
         if (hyx[i] >= 0) {
@@ -299,18 +312,31 @@ __global__ __launch_bounds__(512) void thin_cout_conv_kernel(const GatherDesc g,
           const int x = bound_coord(hx0 + (hyx[i] & 0xffff), g.Wl, g.pad_mode);
           if ((y | x) >= 0) ptr = ibase + (unsigned)((((y >> g.up) * g.Ws + (x >> g.up)) << 6) + coff[i]);
         }
-        glds16tc(ptr, halo + buf * halo_bytes + grp * 1024);
+        glds16tc(ptr, halo + dst);
       }
     }
   };
 
-  // weight fragment address of this lane: row lr (rows >= 8 -> the zero row), 8 channels at k = 16*kblock + 8*lh
-  const unsigned char* const wbase = wl + (lr < TO_MAXCO ? lr : TO_MAXCO) * wrow_bytes + lh * 16;
-  const int pix0 = (wave + (g.ys < 0 ? g.th - 1 : 0)) * hwd + lr + (g.xs < 0 ? g.tw - 1 : 0);
+  // weight fragments: A row = output channel l16 (rows >= 8: zeros), k = 32 (kb) + 8 kg .. +7 of tap t
+  constexpr int NWF = WREG ? 18 : 1;
+  u32x4 wf[NWF];
+  if constexpr (WREG) {
+#pragma unroll
+    for (int f = 0; f < 18; ++f) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (l16 < wrows && (f >> 1) < ntaps) v = *reinterpret_cast<const u32x4*>(wgt + (size_t)l16 * g.K + (f >> 1) * 64 + (f & 1) * 32 + kg * 8);
+      wf[f] = v;
+    }
+  }
+  const unsigned char* const wbase = wl + (l16 < TO_MAXCO ? l16 : 0) * wrow_bytes + kg * 16;
+  const bool wlive = l16 < TO_MAXCO;
+  // byte address (plane 0, before the swizzle) of this lane's chunk of pixel (tile row `wave`, column l16) at tap (0,0); columns
+  // 16..31 are 16 rows = 1024 bytes further (same swizzle bit)
+  const int pix0 = (wave + (g.ys < 0 ? g.th - 1 : 0)) * hwd + l16 + (g.xs < 0 ? g.tw - 1 : 0);
   const int step_x = g.xs > 0 ? 1 : -1, step_y = g.ys > 0 ? hwd : -hwd;
   float bv[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) bv[k] = (bias != nullptr && 4 * lh + k < wrows) ? bias[4 * lh + k] : 0.f;
+  for (int k = 0; k < 4; ++k) bv[k] = (bias != nullptr && 4 * kg + k < wrows) ? bias[4 * kg + k] : 0.f;
 
   int t = blockIdx.x;
   if (t < ntiles && nbuf == 2) issue_halo(0, t);
@@ -318,49 +344,67 @@ __global__ __launch_bounds__(512) void thin_cout_conv_kernel(const GatherDesc g,
     const int tn = t + gridDim.x;
     const unsigned char* hb = halo;
     if (nbuf == 2) {                                                 // halo of tile t+1 streams in under tile t
-      if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (one output store per tile stays in flight)
-      else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (two output stores per tile stay in flight)
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       __syncthreads();
       if (tn < ntiles) issue_halo((it + 1) & 1, tn);
       hb = halo + (it & 1) * halo_bytes;
-    } else {                                                         // 7x7: one 67 KB halo buffer next to 56 KB of weights
+    } else {                                                         // 7x7: one 68 KB halo buffer next to 50 KB of weights
       __syncthreads();                                               // everyone is done with the previous tile
       issue_halo(0, t);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
 
-    f32x16 acc;
+    typedef __attribute__((ext_vector_type(4))) float acc4_t;
+    acc4_t acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    auto tap_mfma = [&](int pix, const u32x4& w0, const u32x4& w1) {
+      const int ad = pix * 64 + ((kg ^ sw_to(pix)) << 4);             // columns 0..15 of the tile row; 16..31 at +1024 (pix + 16: same swizzle bit)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    int ty = 0, tx = 0;                                              // wave-uniform tap walk
-    for (int tap = 0; tap < ntaps; ++tap) {
-      const int pix = pix0 + ty * step_y + tx * step_x;
-      const unsigned char* pa = hb + pix * 128;
-      const int sw = (pix >> 1) & 7;
-      const unsigned char* wa = wbase + tap * 128;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const u32x4 w = *reinterpret_cast<const u32x4*>(wa + ks * 32);
-        const u32x4 a = *reinterpret_cast<const u32x4*>(pa + (((ks * 2 + lh) ^ sw) << 4));
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
+      for (int pb = 0; pb < 2; ++pb) {
+        const u32x4 a0 = *reinterpret_cast<const u32x4*>(hb + ad + pb * 1024);
+        const u32x4 a1 = *reinterpret_cast<const u32x4*>(hb + plane_bytes + ad + pb * 1024);
+        acc[pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w0), __builtin_bit_cast(bf16x8, a0), acc[pb], 0, 0, 0);
+        acc[pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w1), __builtin_bit_cast(bf16x8, a1), acc[pb], 0, 0, 0);
       }
-      if (++tx == g.tw) { tx = 0; ++ty; }
+    };
+    if constexpr (WREG) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap < ntaps) {
+          const int ty = tap / 3, tx = tap - 3 * ty;                  // (WREG launches are 3x3)
+          tap_mfma(pix0 + ty * step_y + tx * step_x, wf[2 * tap], wf[2 * tap + 1]);
+        }
+      }
+    } else {
+      int ty = 0, tx = 0;                                            // wave-uniform tap walk
+      for (int tap = 0; tap < ntaps; ++tap) {
+        u32x4 w0 = {0u, 0u, 0u, 0u}, w1 = {0u, 0u, 0u, 0u};
+        if (wlive) {
+          w0 = *reinterpret_cast<const u32x4*>(wbase + tap * 128);
+          w1 = *reinterpret_cast<const u32x4*>(wbase + tap * 128 + 64);
+        }
+        tap_mfma(pix0 + ty * step_y + tx * step_x, w0, w1);
+        if (++tx == g.tw) { tx = 0; ++ty; }
+      }
     }
 
-    // D row = channel (e&3) + 8(e>>2) + 4lh, col = pixel lr: registers 0..3 are channels 4lh .. 4lh+3 of pixel lr
-    {
+    // D row = channel 4 kg + e, col = pixel l16: lanes kg < 2 hold the 8 output channels
+    if (kg < 2) {
       const int img = t / tiles_img;
       const int rem = t - img * tiles_img;
       const int tyi = rem / tiles_x;
-      const size_t opix = (size_t)out_pixel(g, img, tyi * TC_TH + wave, (rem - tyi * tiles_x) * TC_TW + lr);
-      float v[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = 4 * lh + k < wrows ? apply_act(acc[k] + bv[k], act) : 0.f;
-      u32x2 pk;
-      pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-      pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-      *reinterpret_cast<u32x2*>(out + opix * ldc + 4 * lh) = pk;
+      for (int pb = 0; pb < 2; ++pb) {
+        const size_t opix = (size_t)out_pixel(g, img, tyi * TC_TH + wave, (rem - tyi * tiles_x) * TC_TW + pb * 16 + l16);
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = 4 * kg + k < wrows ? apply_act(acc[pb][k] + bv[k], act) : 0.f;
+        u32x2 pk;
+        pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+        pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+        *reinterpret_cast<u32x2*>(out + opix * ldc + 4 * kg) = pk;
+      }
     }
     t = tn;
   }
@@ -376,21 +420,24 @@ hipError_t thin_cout_conv(const GatherDesc& g, const void* src, const void* wgt,
   const int ntiles = g.N * (g.Ho / TC_TH) * (g.Wo / TC_TW);
   if (ntiles < num_cu) return hipErrorNotSupported;
   const int hwd = TC_TW + g.tw - 1, hht = TC_TH + g.th - 1;
-  const int halo_bytes = ((hwd * hht + 7) / 8) * 1024;
-  const size_t wbytes = (size_t)(TO_MAXCO + 1) * g.K * 2;
+  const int halo_bytes = 2 * ((hwd * hht + 15) / 16) * 1024;          // two channel planes of 16-pixel groups
+  if (2 * ((hwd * hht + 15) / 16) > 8 * TO_MAXG) return hipErrorNotSupported;
+  const bool wreg = g.th == 3 && g.tw == 3;                            // 18 weight fragments in registers
+  const size_t wbytes = wreg ? 0 : (size_t)TO_MAXCO * g.K * 2;
   int nbuf = 2;
   if (2 * (size_t)halo_bytes + wbytes > 160 * 1024) nbuf = 1;
   const size_t lds = nbuf * (size_t)halo_bytes + wbytes;
   if (lds > 160 * 1024) return hipErrorNotSupported;
-  static size_t lds_set = 0;
-  if (lds > lds_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(thin_cout_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  auto kern = wreg ? thin_cout_conv_kernel<true> : thin_cout_conv_kernel<false>;
+  static size_t lds_set[2] = {0, 0};
+  if (lds > lds_set[wreg ? 1 : 0]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    lds_set = lds;
+    lds_set[wreg ? 1 : 0] = lds;
   }
   count_launch(K_THIN_COUT);
   prof_begin(PROF_GATHER_GEMM, 2.0 * (double)g.M * (double)(g.th * g.tw) * (double)g.Clog * (double)wrows, st);
-  hipLaunchKernelGGL(thin_cout_conv_kernel, dim3(std::min(ntiles, num_cu)), dim3(512), lds, st, g, (const bf16_t*)src,
+  hipLaunchKernelGGL(kern, dim3(std::min(ntiles, num_cu)), dim3(512), lds, st, g, (const bf16_t*)src,
                      (const bf16_t*)wgt, wrows, bias, (bf16_t*)out, ldc, act, ntiles, halo_bytes, nbuf);
   prof_end(PROF_GATHER_GEMM, st);
   return hipGetLastError();
