@@ -115,6 +115,7 @@ SIGNATURES = {
     "dei2i_conv2d_dgrad_norm_chunks": (c_int, [_CD]),
     "dei2i_conv2d_dgrad_input_norm": (c_int, [_CD, _P, _P, _P, _ED, _P]),
     "dei2i_in_act_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P]),
+    "dei2i_in_affine_act_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P]),
     "dei2i_avgpool2_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "dei2i_avgpool2_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "dei2i_spade_bwd_border": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),

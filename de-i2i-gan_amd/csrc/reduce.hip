@@ -372,7 +372,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void spade_bwd_border_kernel(const T* __restrict__ dz, const T* __restrict__ x,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const T* __restrict__ gb, T* __restrict__ dgb_cls, int H,
-                                                               int W, int C, int up) {
+                                                               int W, int C, int up, float slope = 0.f) {
   constexpr int VEC = Elem<T>::VEC;
   extern __shared__ float smem[];
   const int cls = blockIdx.x, n = blockIdx.y;
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void spade_bwd_border_kernel(const T* __restri
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         const float xh = (xv[e] - mv[e]) * rv[e];
-        const float g = fmaf(xh, 1.f + gm[e], bt[e]) > 0.f ? d[e] : 0.f;
+        const float g = fmaf(xh, 1.f + gm[e], bt[e]) > 0.f ? d[e] : slope * d[e];
         v[0][e] = fmaf(g, xh, v[0][e]);
         v[1][e] += g;
       }
@@ -1025,6 +1025,43 @@ int dei2i_in_act_bwd(int dtype, int N, int H, int W, int C, const void* dz, cons
   else
     hipLaunchKernelGGL(spade_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dz, (const float*)x, mean, rstd,
                        (const float*)zero_table, 1, (const float*)coef, (const float*)addend, (float*)dx, N, H, W, C, 0, slope);
+  return (int)hipGetLastError();
+}
+
+/* Backward of z = act(IN(x) * (1 + gamma) + beta) with per-(n, c) gamma / beta -- AdaIN (stargan-v2/core/model.py:69-80) and
+ * InstanceNorm2d(affine=True) (model.py:39-40, 333: gamma = weight - 1, beta = bias for every image) followed by LeakyReLU(0.2)
+ * (or any activation of the ReLU family with negative slope `slope`; 1: none): the SPADE backward kernels in class mode on a
+ * (N,5,5,2C) table that holds the same (gamma | beta) in all 25 classes, with the activation's slope.  dgb_table: the table's
+ * gradient (the caller sums its 25 classes); partial (N, dei2i_moments_chunks(H*W), 4, C) and coef (N, 2, C) floats are scratch. */
+int dei2i_in_affine_act_bwd(int dtype, int N, int H, int W, int C, const void* dz, const void* x, const float* mean,
+                            const float* rstd, float slope, const void* gb_table, void* dgb_table, float* partial, float* coef,
+                            const void* addend, void* dx, dei2i_stream s) {
+  const int vec = dtype == DT_BF16 ? 8 : 4;
+  if (N <= 0 || H < 4 || W < 4 || !cv_ok(dtype, C) || !dz || !x || !mean || !rstd || !gb_table || !dgb_table || !partial || !coef || !dx)
+    return DEI2I_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)s;
+  const int chunks = dei2i_moments_chunks(H * W);
+  const size_t total = (size_t)N * H * W * (C / vec);
+  const unsigned grid = grid_for(total, 256, 256u * 16u);
+  if (dtype == DT_BF16) {
+    hipLaunchKernelGGL(spade_bwd_partial_kernel<bf16_t>, dim3(chunks, N), dim3(256), combine_lds(dtype, 4), st, (const bf16_t*)dz,
+                       (const bf16_t*)x, mean, rstd, (const bf16_t*)gb_table, 1, (bf16_t*)nullptr, partial, H, W, C, 0, chunks, slope);
+    hipLaunchKernelGGL(spade_bwd_border_kernel<bf16_t>, dim3(25, N), dim3(256), combine_lds(dtype, 2), st, (const bf16_t*)dz,
+                       (const bf16_t*)x, mean, rstd, (const bf16_t*)gb_table, (bf16_t*)dgb_table, H, W, C, 0, slope);
+  } else {
+    hipLaunchKernelGGL(spade_bwd_partial_kernel<float>, dim3(chunks, N), dim3(256), combine_lds(dtype, 4), st, (const float*)dz,
+                       (const float*)x, mean, rstd, (const float*)gb_table, 1, (float*)nullptr, partial, H, W, C, 0, chunks, slope);
+    hipLaunchKernelGGL(spade_bwd_border_kernel<float>, dim3(25, N), dim3(256), combine_lds(dtype, 2), st, (const float*)dz,
+                       (const float*)x, mean, rstd, (const float*)gb_table, (float*)dgb_table, H, W, C, 0, slope);
+  }
+  hipLaunchKernelGGL(spade_bwd_finalize_kernel, dim3(C, N), dim3(combine_threads(chunks)), 0, st, (const float*)partial, N, chunks, C,
+                     (double)H * (double)W, coef, dgb_table, dtype);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(spade_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)x, mean, rstd,
+                       (const bf16_t*)gb_table, 1, (const float*)coef, (const bf16_t*)addend, (bf16_t*)dx, N, H, W, C, 0, slope);
+  else
+    hipLaunchKernelGGL(spade_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dz, (const float*)x, mean, rstd,
+                       (const float*)gb_table, 1, (const float*)coef, (const float*)addend, (float*)dx, N, H, W, C, 0, slope);
   return (int)hipGetLastError();
 }
 

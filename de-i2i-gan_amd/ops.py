@@ -627,6 +627,62 @@ def _conv_wgrad(lib, prec, geom, x, g, weight, pro=None, keep=()):
     return dw
 
 
+# ---- double backward (stargan-v2's R1 penalty, core/solver.py:573-583) ---------------------------------------------
+# r1_reg differentiates d sum(D(x)) / dx with create_graph=True and back-propagates 0.5 * |that|^2 into D's parameters: the
+# BACKWARD pass of D's input gradient is itself differentiated.  While such a graph is being recorded (grad mode on inside a
+# backward: create_graph=True) the ops below compute their input gradients with autograd Functions of their own
+# -- each a linear map whose transpose is again one of the kernels: the conv's input gradient (transpose: the forward conv;
+# with respect to the weight: the wgrad kernel on (incoming, dy)), the activation mask, the average pool, the layout changes.
+# Parameter gradients of that first-order pass are not needed (r1_reg asks for the input gradient only) and stay on the plain path.
+def _second_order(g) -> bool:
+    # grad mode is ON inside a backward pass exactly when it runs with create_graph=True; the incoming gradient itself need not
+    # require grad (the seed of d sum(D(x)) is a constant) -- the result still depends on the weights
+    return torch.is_grad_enabled() and g is not None
+
+
+class _ActBwd(torch.autograd.Function):
+    """g = dy * act'(z) with the mask taken from the activation's OUTPUT z (ReLU family): linear in dy, mask constant"""
+
+    @staticmethod
+    def forward(ctx, dy, z, act: int):
+        dy = dy.contiguous()
+        g = torch.empty_like(dy)
+        L.check(_lib_for(dy).dei2i_act_bwd(precision_of(dy).code, dy.numel(), _p(dy), _p(z), act, _p(g), _stream()), "act_bwd")
+        ctx.act = act
+        ctx.save_for_backward(z)
+        return g
+
+    @staticmethod
+    def backward(ctx, gg):
+        (z,) = ctx.saved_tensors
+        return _ActBwd.apply(gg.contiguous(), z, ctx.act), None, None
+
+
+class _ConvDgradFn(torch.autograd.Function):
+    """dx = W^T (*) g: the conv's input gradient as a function of (g, W).  Its own gradients: with respect to g the FORWARD conv of
+    the incoming gradient, with respect to W the weight-gradient kernel on (x := incoming, dy := g).  Plain geometry only (zero
+    padding, no fused upsample): what the discriminators differentiated twice use."""
+
+    @staticmethod
+    def forward(ctx, g, weight, cache, sources, geom: ConvGeom, x_shape, prec):
+        lib = _lib_for(g)
+        g = g.contiguous()
+        ctx.geom, ctx.cache, ctx.sources, ctx.prec = geom, cache, sources, prec
+        ctx.save_for_backward(g, weight)
+        return _conv_dgrad(lib, prec, geom, tuple(x_shape), g.shape[-1], g, weight, cache, sources, False, g.dtype, g.device)
+
+    @staticmethod
+    def backward(ctx, gdx):
+        g, weight = ctx.saved_tensors
+        gdx = gdx.contiguous()
+        dg = dw = None
+        if ctx.needs_input_grad[0]:
+            dg = _Conv2d.apply(gdx, weight.detach(), None, ctx.cache, ctx.sources, ctx.geom, L.ACT_NONE, False)
+        if _wants_grad(ctx, 1):
+            dw = _conv_wgrad(_lib_for(g), ctx.prec, ctx.geom, gdx, g, weight)
+        return dg, dw, None, None, None, None, None
+
+
 class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, cache: PackedWeights, sources, geom: ConvGeom, act: int, want_stats: bool = False):
@@ -692,6 +748,16 @@ class _Conv2d(torch.autograd.Function):
         dy = dy.contiguous()
         couts = dy.shape[-1]
         st = _stream()
+        if _second_order(dy):                                # the input gradient as a differentiable function of dy (see _ConvDgradFn)
+            if (geom.reflect and geom.pad > 0) or geom.up or ctx.per_call:
+                raise NotImplementedError("double backward through a reflect-padded / upsample-fused / per-call-weight conv is not built")
+            g2 = _ActBwd.apply(dy, y, act) if act != L.ACT_NONE else dy
+            dx2 = _ConvDgradFn.apply(g2, weight, ctx.cache, ctx.sources, geom, tuple(x.shape), prec) if ctx.needs_input_grad[0] else None
+            dw2 = _conv_wgrad(lib, prec, geom, x, g2.detach(), weight) if _wants_grad(ctx, 1) else None
+            db2 = None
+            if ctx.has_bias and _wants_grad(ctx, 2):
+                db2 = g2.detach().float().sum(dim=(0, 1, 2))[:geom.cout]
+            return dx2, dw2, db2, None, None, None, None, None
         if act != L.ACT_NONE:
             g = torch.empty_like(dy)
             L.check(lib.dei2i_act_bwd(prec.code, dy.numel(), _p(dy), _p(y), act, _p(g), st), "act_bwd")
@@ -742,6 +808,8 @@ class _ToNHWC(torch.autograd.Function):
         if ctx.resized:
             raise RuntimeError("to_nhwc with nearest resize is only differentiable w.r.t. nothing (label maps)")
         n, c, h, w = ctx.shape
+        if _second_order(g):                              # R1-style penalties differentiate this backward: the conversion is linear
+            return _ToNCHW.apply(g, c), None, None
         g = g.contiguous()
         dx = torch.empty((n, c, h, w), dtype=torch.float32, device=g.device)
         lib = _lib_for(g)
@@ -764,6 +832,8 @@ class _ToNCHW(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if _second_order(g):
+            return _ToNHWC.apply(g, ctx.prec, None), None
         g = g.contiguous().float()
         n, c, h, w = g.shape
         dx = torch.empty((n, h, w, ctx.cs), dtype=ctx.prec.dtype, device=g.device)
@@ -1425,6 +1495,127 @@ def instance_norm_act(x, act="none", res=None, eps=1e-5):
     return _InstanceNormAct.apply(x, slope, res, float(eps))
 
 
+class _Scale(torch.autograd.Function):
+    """x * s on an NHWC activation (stargan-v2's "/ sqrt(2)" after every residual add, core/model.py:67,121)"""
+
+    @staticmethod
+    def forward(ctx, x, s: float):
+        _require_gpu(x, "scale")
+        x = x.contiguous()
+        c = x.shape[-1]
+        out = torch.empty_like(x)
+        L.check(_lib_for(x).dei2i_affine_act_fwd(precision_of(x).code, x.numel() // c, c, _p(x), _p(_const_vec(x.device, c, float(s))),
+                                                 _p(_const_vec(x.device, c, 0.0)), None, L.ACT_NONE, _p(out), None, 1.0, _stream()), "scale")
+        ctx.s = s
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return _Scale.apply(g, ctx.s), None
+
+
+def scale(x, s: float):
+    return _Scale.apply(x, float(s))
+
+
+class _Act(torch.autograd.Function):
+    """a stand-alone activation of the ReLU family on an NHWC activation (stargan-v2 applies LeakyReLU(0.2) to a tensor whose
+    un-activated value also feeds the block's shortcut, core/model.py:52-63)"""
+
+    @staticmethod
+    def forward(ctx, x, act: int):
+        _require_gpu(x, "act")
+        x = x.contiguous()
+        c = x.shape[-1]
+        out = torch.empty_like(x)
+        L.check(_lib_for(x).dei2i_affine_act_fwd(precision_of(x).code, x.numel() // c, c, _p(x), _p(_const_vec(x.device, c, 1.0)),
+                                                 _p(_const_vec(x.device, c, 0.0)), None, act, _p(out), None, 1.0, _stream()), "act")
+        ctx.act = act
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        return _ActBwd.apply(g.contiguous(), out, ctx.act), None
+
+
+def leaky_relu(x):
+    return _Act.apply(x, L.ACT_LRELU)
+
+
+class _InAffineAct(torch.autograd.Function):
+    """z = act(InstanceNorm2d(x) * (1 + gamma) + beta), gamma / beta (N, C) fp32 -- stargan-v2's AdaIN (core/model.py:69-80) and its
+    InstanceNorm2d(affine=True) (gamma = weight - 1, beta = bias for every image) with the LeakyReLU(0.2) that follows both at every
+    call site (model.py:53-61,104-112,333-334).  Forward: statistics -> per-image coefficients A = rstd (1 + gamma), B = beta - mean A
+    -> one affine + activation pass.  Backward: dei2i_in_affine_act_bwd (the SPADE backward kernels in class mode with the
+    activation's slope); the table's 25 classes are summed back to (N, C).  gamma / beta are rounded to the compute dtype first, so
+    that forward and backward see the same values."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, slope: float, eps: float):
+        _require_gpu(x, "in_affine_act")
+        prec = precision_of(x)
+        x = x.contiguous()
+        n, h, w, c = x.shape
+        lib = _lib_for(x)
+        st, dev = _stream(), x.device
+        cl = gamma.shape[1]
+        gb = torch.zeros((n, 2 * c), dtype=prec.dtype, device=dev)
+        gb[:, :cl] = gamma.detach().to(prec.dtype)
+        gb[:, c:c + cl] = beta.detach().to(prec.dtype)
+        mean = torch.empty((n, c), dtype=torch.float32, device=dev)
+        rstd = torch.empty((n, c), dtype=torch.float32, device=dev)
+        have = _stats_of(x, n, h * w, c) if fuse_norm else None
+        if have is not None:
+            partial, chunks = have
+        else:
+            chunks = lib.dei2i_moments_chunks(h * w)
+            partial = torch.empty((n, chunks, 2, c), dtype=torch.float32, device=dev)
+            L.check(lib.dei2i_moments_partial(prec.code, n, h * w, c, _p(x), _p(partial), st), "moments_partial")
+        L.check(lib.dei2i_in_finalize_chunks(n, h * w, c, chunks, _p(partial), eps, _p(mean), _p(rstd), st), "in_finalize")
+        a = rstd * (1.0 + gb[:, :c].float())
+        b = gb[:, c:].float() - mean * a
+        out = torch.empty_like(x)
+        cv = c // (8 if prec is BF16 else 4)
+        if 256 % cv == 0 or cv % 256 == 0:
+            L.check(lib.dei2i_affine_act_img_fwd(prec.code, n, h * w, c, _p(x), _p(a), _p(b), slope, _p(out), st), "affine_act_img")
+        else:
+            act = {1.0: L.ACT_NONE, 0.0: L.ACT_RELU, 0.2: L.ACT_LRELU}[slope]
+            for i in range(n):
+                L.check(lib.dei2i_affine_act_fwd(prec.code, h * w, c, _p(x[i]), _p(a[i].contiguous()), _p(b[i].contiguous()), None, act,
+                                                 _p(out[i]), None, 1.0, st), "affine_act")
+        ctx.prec, ctx.slope, ctx.cl = prec, slope, cl
+        ctx.save_for_backward(x, mean, rstd, gb)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, mean, rstd, gb = ctx.saved_tensors
+        prec = ctx.prec
+        n, h, w, c = x.shape
+        if h < 4 or w < 4:
+            raise NotImplementedError("in_affine_act backward needs H, W >= 4 (class-mode SPADE kernels)")
+        lib = _lib_for(x)
+        dout = dout.contiguous()
+        table = gb.view(n, 1, 1, 2 * c).expand(n, 5, 5, 2 * c).contiguous()
+        dtable = torch.empty_like(table)
+        chunks = lib.dei2i_moments_chunks(h * w)
+        partial = torch.empty((n, chunks, 4, c), dtype=torch.float32, device=x.device)
+        coef = torch.empty((n, 2, c), dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        L.check(lib.dei2i_in_affine_act_bwd(prec.code, n, h, w, c, _p(dout), _p(x), _p(mean), _p(rstd), ctx.slope, _p(table), _p(dtable),
+                                            _p(partial), _p(coef), None, _p(dx), _stream()), "in_affine_act_bwd")
+        dgb = dtable.float().sum(dim=(1, 2))              # (N, 2C): the 25 classes hold the same (gamma | beta)
+        return dx, dgb[:, :ctx.cl], dgb[:, c:c + ctx.cl], None, None
+
+
+def in_affine_act(x, gamma, beta, act="leaky_relu", eps=1e-5):
+    """act(InstanceNorm2d(x) * (1 + gamma) + beta) on an NHWC activation; gamma / beta: (N, C) fp32 (autograd flows into them)"""
+    slope = {"none": 1.0, "relu": 0.0, "leaky_relu": 0.2}[act or "none"]
+    return _InAffineAct.apply(x, gamma, beta, slope, float(eps))
+
+
 class _AvgPool2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -1439,6 +1630,8 @@ class _AvgPool2(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if _second_order(dout):
+            return _AvgPool2Bwd.apply(dout, ctx.shape)
         n, h, w, c = ctx.shape
         dout = dout.contiguous()
         dx = torch.empty(ctx.shape, dtype=dout.dtype, device=dout.device)
@@ -1446,9 +1639,32 @@ class _AvgPool2(torch.autograd.Function):
         return dx
 
 
+class _AvgPool2Bwd(torch.autograd.Function):
+    """the average pool's input gradient as a function of the output gradient (each value / 4 to its 2x2 cell); transpose: the pool"""
+
+    @staticmethod
+    def forward(ctx, dout, shape):
+        n, h, w, c = shape
+        dout = dout.contiguous()
+        dx = torch.empty(shape, dtype=dout.dtype, device=dout.device)
+        L.check(_lib_for(dout).dei2i_avgpool2_bwd(precision_of(dout).code, n, h, w, c, _p(dout), _p(dx), _stream()), "avgpool2_bwd")
+        return dx
+
+    @staticmethod
+    def backward(ctx, gdx):
+        return _AvgPool2.apply(gdx), None
+
+
 def avgpool2(x):
     """nn.AvgPool2d(2, 2) on an NHWC activation (H, W even)"""
     return _AvgPool2.apply(x)
+
+
+def upsample2(x):
+    """nearest x2 upsample of an NHWC activation that no conv absorbs (stargan-v2's AdainResBlk shortcut when the channel count does not
+    change, core/model.py:101-105): the average pool's adjoint spreads a value / 4 over its 2x2 cell, so this is 4 x that kernel"""
+    n, h, w, c = x.shape
+    return scale(_AvgPool2Bwd.apply(x, (n, 2 * h, 2 * w, c)), 4.0)
 
 
 # --------------------------------------------------------------------------------------------------------------

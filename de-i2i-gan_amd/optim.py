@@ -14,11 +14,14 @@ from . import ops
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, weight_decay=0.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, weight_decay=0.0, decoupled=True):
+        """``decoupled=False``: torch.optim.Adam's weight decay (L2: the gradient becomes g + wd * p before the moments -- what
+        stargan-v2's optimizers use, core/solver.py:52-56) instead of AdamW's"""
         if lr < 0.0 or eps < 0.0 or weight_decay < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0):
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.grad_scale = float(grad_scale)
+        self.decoupled = bool(decoupled)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -42,8 +45,13 @@ class FusedAdam(torch.optim.Optimizer):
                 st["step"] += 1
                 by_step.setdefault(st["step"], []).append(p)
             b1, b2 = group["betas"]
+            wd = float(group.get("weight_decay", 0.0))
             for t, plist in by_step.items():
-                self._launch(plist, t, float(group["lr"]), b1, b2, group["eps"], float(group.get("weight_decay", 0.0)))
+                if wd > 0.0 and not self.decoupled:          # coupled L2 decay: one multi-tensor launch on the gradients, then plain Adam
+                    if self.grad_scale != 1.0:
+                        raise NotImplementedError("coupled weight decay with a gradient scale")
+                    torch._foreach_add_([p.grad for p in plist], [p.data for p in plist], alpha=wd)
+                self._launch(plist, t, float(group["lr"]), b1, b2, group["eps"], wd if self.decoupled else 0.0)
         return loss
 
     def _launch(self, plist, t, lr, b1, b2, eps, weight_decay=0.0):

@@ -324,6 +324,14 @@ int dei2i_conv2d_dgrad_input_norm(const dei2i_conv* c, const void* dy, const voi
  * compute dtype; partial (N, dei2i_moments_chunks(H*W), 4, C) and coef (N, 2, C) floats are scratch; addend (optional) is added to dx. */
 int dei2i_in_act_bwd(int dtype, int N, int H, int W, int C, const void* dz, const void* x, const float* mean, const float* rstd,
                      float slope, const void* zero_table, float* partial, float* coef, const void* addend, void* dx, dei2i_stream s);
+/* The same with a real (gamma | beta): z = act(IN(x) * (1 + gamma) + beta), gamma / beta per (n, c) -- AdaIN (stargan-v2/core/model.py:
+ * 69-80) and InstanceNorm2d(affine=True) + LeakyReLU (model.py:39-40,56-61,333-334: gamma = weight - 1, beta = bias).  gb_table: the
+ * (N,5,5,2C) class table holding the same (gamma | beta) in all 25 classes (compute dtype); dgb_table: its gradient, same shape (the
+ * caller sums the 25 classes).  Forward of the op: dei2i_in_finalize + dei2i_affine_act_img_fwd with A = rstd (1 + gamma),
+ * B = beta - mean A. */
+int dei2i_in_affine_act_bwd(int dtype, int N, int H, int W, int C, const void* dz, const void* x, const float* mean,
+                            const float* rstd, float slope, const void* gb_table, void* dgb_table, float* partial, float* coef,
+                            const void* addend, void* dx, dei2i_stream s);
 /* nn.AvgPool2d(2, 2) on NHWC (N, H, W, C), H and W even (architecture.py:157-168); out / dout: (N, H/2, W/2, C) */
 int dei2i_avgpool2_fwd(int dtype, int N, int H, int W, int C, const void* x, void* out, dei2i_stream s);
 int dei2i_avgpool2_bwd(int dtype, int N, int H, int W, int C, const void* dout, void* dx, dei2i_stream s);
