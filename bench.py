@@ -56,6 +56,8 @@ def parse():
                     help="A/B: SPADE / BatchNorm backward reductions by a streaming pass instead of the dgrad epilogue (ops.fuse_bwd = False)")
     ap.add_argument("--no-fold-eval-bn", action="store_true",
                     help="A/B: eval-mode BatchNorm as its own apply pass instead of folded into the conv weights (ops.fold_eval_bn = False)")
+    ap.add_argument("--no-paired-passes", action="store_true",
+                    help="A/B: the G loss's four generator passes as four passes (ops.paired_passes = False) instead of two over 2 x batch")
     ap.add_argument("--no-forked-chains", action="store_true",
                     help="A/B: the G loss's four generator passes on one stream instead of two chains on two streams (ops.forked_chains = False)")
     ap.add_argument("--fuse-pro", action="store_true",
@@ -253,6 +255,7 @@ def main():
     _ops.fuse_bwd = not args.no_fuse_bwd
     _ops.fold_eval_bn = not args.no_fold_eval_bn
     _ops.forked_chains = not args.no_forked_chains
+    _ops.paired_passes = not args.no_paired_passes
     for kv in args.set_option:
         name, val = kv.split("=")
         _lib.check(_lib.load().dei2i_set_option(name.encode(), int(val)), "set_option " + kv)
@@ -381,7 +384,9 @@ def main():
                    "weight_gradients_on_side_stream": not args.no_wgrad_stream,
                    "norm_backward_reductions_in_dgrad_epilogue": not args.no_fuse_bwd,
                    "eval_batchnorm_folded_into_conv_weights": not args.no_fold_eval_bn,
-                   "generator_chains_on_two_streams": not args.no_forked_chains and not args.use_spectral and not args.add_noise,
+                   "generator_passes_paired_over_2x_batch": not args.no_paired_passes and not args.use_spectral and not args.add_noise,
+                   "generator_chains_on_two_streams": (args.no_paired_passes and not args.no_forked_chains and not args.use_spectral
+                                                       and not args.add_noise),
                    # what the step does differently from a literal transcription of the reference's step (same function):
                    "defer_loss_sync": bool(opt.defer_loss_sync),      # losses stay on the device; no .item() per update
                    "discriminator_passes": "one batched D pass per step phase (4 image batches in the D step, 2 in the G step: "

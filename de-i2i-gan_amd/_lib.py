@@ -26,7 +26,7 @@ class ProDesc(Structure):
 
 class EpiNormDesc(Structure):
     """struct dei2i_epi_norm: the backward reductions of the norm layer in front of a conv, from that conv's dgrad epilogue"""
-    _fields_ = [("kind", c_int), ("up", c_int), ("act", c_int), ("reserved", c_int), ("x", c_void_p), ("mean", c_void_p),
+    _fields_ = [("kind", c_int), ("up", c_int), ("act", c_int), ("group_images", c_int), ("x", c_void_p), ("mean", c_void_p),
                 ("rstd", c_void_p), ("gb", c_void_p), ("a", c_void_p), ("b", c_void_p), ("partial", c_void_p)]
 
 

@@ -491,12 +491,14 @@ int dei2i_conv2d_dgrad_input_norm(const dei2i_conv* c, const void* dy, const voi
   if (!en->x || !en->mean || !en->rstd || !en->partial || en->up < 0 || en->up > 1) return DEI2I_ERR_BAD_ARG;
   const int kind = en->kind & 0xff;            // (bits 8+: timing-only switches of tools/diag_epin.py)
   if (kind == 1 ? !en->gb : (kind != 2 || !en->a || !en->b || en->up)) return DEI2I_ERR_BAD_ARG;
+  if (en->group_images < 0 || (en->group_images > 0 && c->N % en->group_images != 0)) return DEI2I_ERR_BAD_ARG;
   ConvShape sh = to_shape(c);
   sh.pad_mode = PAD_ZERO;
   const GatherDesc interior = make_dgrad_desc(sh, c->CoutS, 0, 0);
   EpiNorm e;
   e.x = (const uint16_t*)en->x; e.mean = en->mean; e.rstd = en->rstd; e.gb = (const uint16_t*)en->gb; e.a = en->a; e.b = en->b;
   e.partial = en->partial; e.kind = en->kind; e.up = en->up; e.act = en->act;
+  e.group_images = kind == 2 ? en->group_images : 0;
   hipError_t ef = halo16_conv(interior, dy, wd_packed, c->Cin, nullptr, dx, c->CinS, ACT_NONE, num_cu(), (hipStream_t)s, nullptr, nullptr,
                               true, &e);
   return ef == hipErrorNotSupported ? DEI2I_ERR_BAD_ARG : (int)ef;

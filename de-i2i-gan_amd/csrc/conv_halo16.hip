@@ -744,8 +744,9 @@ __global__ __launch_bounds__(512) void halo16_conv_kernel(const GatherDesc g, co
         gmi = *reinterpret_cast<const u32x4*>(gp);
         bti = *reinterpret_cast<const u32x4*>(gp + ldc);
       } else {
-        ld8(en.a + ncol, nc[0]); ld8(en.b + ncol, nc[1]);
-        ld8(en.mean + ncol, nc[2]); ld8(en.rstd + ncol, nc[3]);
+        const size_t grow = en.group_images > 0 ? (size_t)(img / en.group_images) * ldc + ncol : (size_t)ncol;
+        ld8(en.a + grow, nc[0]); ld8(en.b + grow, nc[1]);
+        ld8(en.mean + grow, nc[2]); ld8(en.rstd + grow, nc[3]);
       }
     }
   }

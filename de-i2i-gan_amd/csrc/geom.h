@@ -244,6 +244,7 @@ struct EpiNorm {
   int kind;
   int up;
   int act;
+  int group_images;      // kind 2: a / b / mean / rstd are (groups, C), image n takes row n / group_images (0: one row for the batch)
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -98,7 +98,14 @@ class DefectGanModel(BaseModel):
         if os.environ.get("DEI2I_SPLIT_D") or per_call_state:     # (env: A/B switch)
             return [self.netD(t) for t in images]
         sizes = [t.shape[0] for t in images]
-        src, cls = self.netD(torch.cat(images, 0))
+        whole = images[0]._base if len(images) > 1 else None
+        if (whole is not None and all(t._base is whole and t.is_contiguous() for t in images) and whole.is_contiguous()
+                and whole.shape[0] == sum(sizes) and whole.shape[1:] == images[0].shape[1:]
+                and all(t.data_ptr() == whole[sum(sizes[:i]):].data_ptr() for i, t in enumerate(images))):
+            batch = whole                                   # the batches ARE the consecutive slices of one tensor (paired generator passes)
+        else:
+            batch = torch.cat(images, 0)
+        src, cls = self.netD(batch)
         return list(zip(src.split(sizes), cls.split(sizes)))
 
     # ---- MAE-GAN pre-training stage (defectgan_model.py:106-171, 361-383) ----------------------------------------
@@ -183,27 +190,53 @@ class DefectGanModel(BaseModel):
         gan_loss = self._mean([self._cal_loss(fake_src, 0.0, "bce"), self._cal_loss(real_src, 1.0, "bce")])
         return gan_loss, clf_loss
 
-    def _forks_generator_chains(self, bg_data, nm_feat):
+    def _forks_generator_chains(self, bg_data, nm_feat, flag=None):
         """The plain SPADE generator only: spectral norm iterates (u, v) in place per forward and NoiseInjection draws from one RNG
         -- both are ordered by the reference's pass order --, the style variants bring a second trained network into the passes."""
         o = self.opt
-        return (ops.forked_chains and bg_data.is_cuda and nm_feat is None and o.style_norm_block_type == "spade"
+        return ((ops.forked_chains if flag is None else flag) and bg_data.is_cuda and nm_feat is None and o.style_norm_block_type == "spade"
                 and not getattr(o, "use_spectral", False) and not getattr(o, "add_noise", False) and not getattr(o, "cycle_gan", False)
                 and not os.environ.get("DEI2I_SPLIT_D"))
+
+    def _pairs_generator_passes(self, bg_data, df_data, nm_feat):
+        """One pass over [bg | df] and one over [fake_defects | fake_normals] instead of four (ops.bn_batch_groups): the same
+        generators as _forks_generator_chains takes, in training mode (BatchNorm per group of the batch), equal batch sizes."""
+        return (ops.paired_passes and self._forks_generator_chains(bg_data, nm_feat, flag=True) and self.netG.training
+                and bg_data.shape == df_data.shape)
 
     def _compute_generator_loss(self, bg_data, df_labels, df_data):
         """defectgan_model.py:173-249"""
         nm_labels, df_labels = self._get_labels(df_labels)
         nm_feat, df_feat = self._style_feats(bg_data, nm_labels, df_labels, df_data)
         self.netG.clear_spade_cache()
-        if not os.environ.get("DEI2I_SPLIT_D") and nm_feat is None:
+        paired = self._pairs_generator_passes(bg_data, df_data, nm_feat)
+        if paired:
+            head_labels, tail_labels = torch.cat([df_labels, nm_labels], 0), torch.cat([nm_labels, df_labels], 0)
+            self.netG.prime_spade((head_labels, tail_labels))
+        elif not os.environ.get("DEI2I_SPLIT_D") and nm_feat is None:
             self.netG.prime_spade((df_labels, nm_labels))        # both label sets' SPADE tables in one pass
         sean = self.opt.style_norm_block_type == "sean"       # defectgan_model.py:177-182,192-197: what the four passes also feed
         if self._sean_distill():
             self.netG.enable_sean_distill_loss(True)
         if sean and getattr(self.opt, "use_running_stats", False):
             self.netG.track_running_stats = True
-        if self._forks_generator_chains(bg_data, nm_feat):
+        if paired:
+            # the chain heads bg -> fake_defects | df -> fake_normals as one pass over 2 x batch, the chain tails -> recover_normals |
+            # -> recover_defects as another: everything in this generator acts per sample except training-mode BatchNorm, which
+            # takes its statistics per half of the batch (ops.bn_batch_groups) and replays the four running-statistics updates in
+            # the reference's pass order (ops.bn_running_deferred: heads are passes 0 and 2, tails 1 and 3)
+            n = bg_data.shape[0]
+            with ops.bn_running_deferred() as running, ops.bn_batch_groups(2):
+                running.pass_index = (0, 2)
+                fakes, probs = self.netG(torch.cat([bg_data, df_data], 0), head_labels, None)
+                running.pass_index = (1, 3)
+                recovers, rec_probs = self.netG(fakes, tail_labels, None)
+                running.apply()
+            fake_defects, fake_normals = fakes[:n], fakes[n:]
+            df_prob, nm_prob = probs[:n], probs[n:]
+            recover_normals, recover_defects = recovers[:n], recovers[n:]
+            rec_df_prob, rec_nm_prob = rec_probs[:n], rec_probs[n:]
+        elif self._forks_generator_chains(bg_data, nm_feat):
             # bg -> fake_defects -> recover_normals and df -> fake_normals -> recover_defects share nothing but the parameters: two
             # streams (ops.forked_chains).  BatchNorm's four running-statistics updates are replayed in the reference's pass order
             # after the join (ops.bn_running_deferred); everything downstream (D, the losses) runs on the joining stream.

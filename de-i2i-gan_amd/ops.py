@@ -470,10 +470,11 @@ class _NormBwdHint:
     makes one, hangs it on its output tensor (``_dei2i_bwd_hint``) and keeps it; the conv that reads that tensor picks it up;
     in backward the conv's dgrad fills ``partial`` and the norm's backward -- handed that very dz tensor -- skips its own
     streaming pass.  kind 1: SPADE class mode + ReLU (x, gb, mean, rstd, up); kind 2: BatchNorm + act (x = y, a, b, mean, rstd)."""
-    __slots__ = ("kind", "x", "gb", "mean", "rstd", "a", "b", "act", "up", "partial", "chunks", "dz", "dz_version")
+    __slots__ = ("kind", "x", "gb", "mean", "rstd", "a", "b", "act", "up", "group_images", "partial", "chunks", "dz", "dz_version")
 
-    def __init__(self, kind, x, mean, rstd, gb=None, a=None, b=None, act=0, up=False):
+    def __init__(self, kind, x, mean, rstd, gb=None, a=None, b=None, act=0, up=False, group_images=0):
         self.kind, self.x, self.mean, self.rstd, self.gb, self.a, self.b, self.act, self.up = kind, x, mean, rstd, gb, a, b, act, up
+        self.group_images = group_images                  # kind 2: a / b / mean / rstd are (groups, C) -- images per group, 0: (C,)
         self.partial = self.chunks = self.dz = self.dz_version = None
 
     def give(self, partial, chunks, dz):
@@ -521,7 +522,7 @@ def _conv_dgrad(lib, prec, geom, x_shape, couts, g, weight, cache, sources, per_
             chunks = lib.dei2i_conv2d_dgrad_norm_chunks(byref(d))
             partial = torch.empty((n, chunks, 4 if hint.kind == 1 else 2, cins), dtype=torch.float32, device=device)
             dx = torch.empty(x_shape, dtype=dtype, device=device)
-            en = L.EpiNormDesc(hint.kind, up, hint.act, 0, hint.x.data_ptr(), hint.mean.data_ptr(), hint.rstd.data_ptr(),
+            en = L.EpiNormDesc(hint.kind, up, hint.act, hint.group_images, hint.x.data_ptr(), hint.mean.data_ptr(), hint.rstd.data_ptr(),
                                hint.gb.data_ptr() if hint.gb is not None else None,
                                hint.a.data_ptr() if hint.a is not None else None,
                                hint.b.data_ptr() if hint.b is not None else None, partial.data_ptr())
@@ -867,6 +868,33 @@ def chain_streams(device):
     return st
 
 
+# ---- passes of the same network that share nothing but the parameters, as ONE batch -----------------------------------------
+# The G loss's chain heads (bg -> fake_defects, df -> fake_normals) and its chain tails (-> recover_normals, -> recover_defects)
+# are pairs of independent passes of the same generator (defectgan_model.py:185-190).  Everything in the generator acts per
+# sample except training-mode BatchNorm, whose statistics are per PASS: with ``bn_batch_groups(g)`` a training-mode BatchNorm
+# takes its statistics (and its backward reductions) over each of g equal groups of the batch separately, so that one pass over
+# the concatenated batch is the same function as the g passes -- with half the launches, half the per-launch tails and
+# weight-gradient reductions, and every conv at twice the tile count.  The running statistics are updated per group through
+# ``bn_running_deferred`` (pass_index = one index per group), which replays them in the reference's pass order.
+paired_passes = True             # the G loss's four generator passes as two passes over 2 x batch (models/defectgan_model.py)
+bn_groups = 1
+
+
+class bn_batch_groups:
+    def __init__(self, groups: int):
+        self.groups = int(groups)
+
+    def __enter__(self):
+        global bn_groups
+        self.prev, bn_groups = bn_groups, self.groups
+        return self
+
+    def __exit__(self, *exc):
+        global bn_groups
+        bn_groups = self.prev
+        return False
+
+
 # ---- two independent chains of generator passes on two streams ---------------------------------------------------
 # The G loss runs the generator four times (defectgan_model.py:185-190): fake_defects -> recover_normals and fake_normals ->
 # recover_defects are two chains that share nothing but the parameters.  On two streams the kernels of one chain fill the other
@@ -893,8 +921,9 @@ class bn_running_deferred:
         bn_running_deferred.current = self.prev
         return False
 
-    def take(self, running_mean, running_var, num_batches_tracked, momentum):
+    def take(self, running_mean, running_var, num_batches_tracked, momentum, group=0):
         dev, n = running_mean.device, running_mean.numel()
+        index = self.pass_index[group] if isinstance(self.pass_index, (tuple, list)) else self.pass_index
         arena, off = bn_running_deferred._arenas.get(dev), self._used.get(dev, 0)
         if arena is None or off + 2 * n > arena.numel() or running_mean.dtype != torch.float32:
             zm, zv = torch.zeros_like(running_mean), torch.zeros_like(running_var)          # (first step / an odd buffer: its own zeros)
@@ -903,7 +932,7 @@ class bn_running_deferred:
         else:
             zm, zv = arena[off:off + n], arena[off + n:off + 2 * n]
             self._used[dev] = off + 2 * n
-        self.updates.append((self.pass_index, running_mean, running_var, num_batches_tracked, zm, zv, momentum))
+        self.updates.append((index, running_mean, running_var, num_batches_tracked, zm, zv, momentum))
         return zm, zv
 
     def apply(self):
@@ -929,6 +958,41 @@ class bn_running_deferred:
             elif self._used.get(dev, 0):
                 arena[:self._used[dev]].zero_()
         self._used, self._want = {}, 0
+
+
+def _bn_coefs_grouped(lib, y, prec, weight, bias, running_mean, running_var, momentum, eps, num_batches_tracked, groups):
+    """Training-mode statistics + coefficients per group of the batch (see bn_batch_groups): a, b, mean, rstd of shape (groups, C)."""
+    n, h, w, c = y.shape
+    dev, st = y.device, _stream()
+    w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+    nf = w32.numel()
+    deferred = bn_running_deferred.current
+    if n % groups or nf > c or running_mean.numel() != nf or running_var.numel() != nf:
+        raise ValueError(f"batchnorm_act: {groups} groups over a batch of {n} / {nf} features for a {c}-channel activation")
+    if deferred is None or not isinstance(deferred.pass_index, (tuple, list)) or len(deferred.pass_index) != groups:
+        raise RuntimeError("batchnorm_act: grouped batch statistics want a bn_running_deferred scope with one pass index per group")
+    a, b, mean, rstd = (torch.empty((groups, c), dtype=torch.float32, device=dev) for _ in range(4))
+    have = _stats_of(y, n, h * w, c) if fuse_norm else None
+    if have is not None:
+        partial, chunks = have
+    else:
+        chunks = lib.dei2i_moments_chunks(h * w)
+        partial = torch.empty((n, chunks, 2, c), dtype=torch.float32, device=dev)
+        L.check(lib.dei2i_moments_partial(prec.code, n, h * w, c, _p(y), _p(partial), st), "moments_partial")
+    ng = n // groups
+    if nf < c:                                   # padded channel stride (see _bn_coefs): c-sized vectors for the kernel
+        w32, b32 = (torch.cat([v, v.new_zeros(c - nf)]) for v in (w32, b32))
+    for g in range(groups):
+        rm, rv = live = deferred.take(running_mean, running_var, num_batches_tracked, float(momentum), group=g)
+        if nf < c:
+            rm, rv = torch.zeros(c, dtype=torch.float32, device=dev), torch.zeros(c, dtype=torch.float32, device=dev)
+        L.check(lib.dei2i_bn_finalize_train_chunks(ng, h * w, c, chunks, _p(partial[g * ng:]), _p(w32), _p(b32), _p(rm), _p(rv),
+                                                   momentum, eps, _p(mean[g]), _p(rstd[g]), _p(a[g]), _p(b[g]), None, st),
+                "bn_finalize_train")
+        if nf < c:
+            live[0].copy_(rm[:nf])
+            live[1].copy_(rv[:nf])
+    return a, b, mean, rstd, nf
 
 
 def _bn_coefs(lib, y, prec, weight, bias, running_mean, running_var, training, momentum, eps, num_batches_tracked):
@@ -983,19 +1047,25 @@ def _bn_coefs(lib, y, prec, weight, bias, running_mean, running_var, training, m
 
 def _bn_backward(lib, prec, dout, y, a, b, mean, rstd, act, training, weight, bias, nf, hint=None):
     """-> (dy, dweight, dbias) of z = act(a*y + b) given dL/dz (csrc/reduce.hip: bn_bwd_partial / bn_bwd_apply).  ``hint``: the
-    dgrad of the conv behind the layer may have left the reduction records already (_NormBwdHint)."""
+    dgrad of the conv behind the layer may have left the reduction records already (_NormBwdHint).  a, b, mean, rstd of shape
+    (groups, C): statistics per group of the batch (bn_batch_groups) -- the reductions and the apply run per group, the
+    parameter gradients are summed over the groups."""
     st = _stream()
     have = hint.take(dout) if hint is not None else None
     dout = dout.contiguous()
     n, h, w, c = y.shape
-    pixels = n * h * w
+    groups = a.shape[0] if a.dim() == 2 else 1
+    ng = n // groups
+    pixels = ng * h * w
+    a, b, mean, rstd = (t.view(groups, c) for t in (a, b, mean, rstd))
     if have is not None:
-        partial, chunks = have[0], n * have[1]
+        partial, chunks = have[0], ng * have[1]          # (n, records per image, 2, c): a group's records are contiguous
     else:
         chunks = lib.dei2i_bn_bwd_chunks(pixels)
-        partial = torch.empty((chunks, 2, c), dtype=torch.float32, device=y.device)
-        L.check(lib.dei2i_bn_bwd_partial(prec.code, pixels, c, _p(dout), _p(y), _p(a), _p(b), _p(mean), _p(rstd), act,
-                                         _p(partial), st), "bn_bwd_partial")
+        partial = torch.empty((groups * chunks, 2, c), dtype=torch.float32, device=y.device)
+        for g in range(groups):
+            L.check(lib.dei2i_bn_bwd_partial(prec.code, pixels, c, _p(dout[g * ng:]), _p(y[g * ng:]), _p(a[g]), _p(b[g]), _p(mean[g]),
+                                             _p(rstd[g]), act, _p(partial[g * chunks:]), st), "bn_bwd_partial")
     padded = nf < c               # padded channel stride: c-sized scratch vectors, sliced to num_features below
     if padded:
         tmp_wb = torch.empty((2, c), dtype=torch.float32, device=y.device)
@@ -1016,9 +1086,16 @@ def _bn_backward(lib, prec, dout, y, a, b, mean, rstd, act, training, weight, bi
             tmp = torch.empty((2, c), dtype=torch.float32, device=y.device)
             dw_ptr, db_ptr = tmp.data_ptr(), tmp.data_ptr() + 4 * c
     dy = torch.empty_like(y)
-    L.check(lib.dei2i_bn_bwd_apply(prec.code, pixels, c, _p(dout), _p(y), _p(a), _p(b), _p(mean), _p(rstd), act,
-                                   1 if training else 0, _p(partial), chunks, c_void_p(dw_ptr), c_void_p(db_ptr),
-                                   acc_ptrs[0], acc_ptrs[1], _p(dy), st), "bn_bwd_apply")
+    parts = partial.view(groups, -1)
+    for g in range(groups):
+        if g == 1:                # the later groups add into where the first one's sums went
+            if acc_ptrs[0] is None:
+                acc_ptrs = (c_void_p(dw_ptr), c_void_p(db_ptr))
+            tmp = torch.empty((2, c), dtype=torch.float32, device=y.device)
+            dw_ptr, db_ptr = tmp.data_ptr(), tmp.data_ptr() + 4 * c
+        L.check(lib.dei2i_bn_bwd_apply(prec.code, pixels, c, _p(dout[g * ng:]), _p(y[g * ng:]), _p(a[g]), _p(b[g]), _p(mean[g]),
+                                       _p(rstd[g]), act, 1 if training else 0, _p(parts[g]), chunks, c_void_p(dw_ptr), c_void_p(db_ptr),
+                                       acc_ptrs[0], acc_ptrs[1], _p(dy[g * ng:]), st), "bn_bwd_apply")
     if padded:
         dweight, dbias = tmp_wb[0, :nf].clone(), tmp_wb[1, :nf].clone()
     return dy, dweight, dbias
@@ -1035,22 +1112,34 @@ class _BatchNormAct(torch.autograd.Function):
         lib = _lib_for(y)
         st = _stream()
         dev = y.device
-        a, b, mean, rstd, nf = _bn_coefs(lib, y, prec, weight, bias, running_mean, running_var, training, momentum, eps,
-                                         num_batches_tracked)
+        groups = bn_groups if training else 1
+        if groups > 1:
+            a, b, mean, rstd, nf = _bn_coefs_grouped(lib, y, prec, weight, bias, running_mean, running_var, momentum, eps,
+                                                     num_batches_tracked, groups)
+        else:
+            a, b, mean, rstd, nf = _bn_coefs(lib, y, prec, weight, bias, running_mean, running_var, training, momentum, eps,
+                                             num_batches_tracked)
         out = torch.empty_like(y)
         if res is not None:
             res = res.contiguous()
         xq = torch.empty(out.numel(), dtype=torch.uint8, device=dev) if _fp8_copy_wanted(prec, c) else None
+        ng = n // groups
+        av, bv = a.view(groups, c), b.view(groups, c)
+        partial = None
         if want_stats and fuse_norm and xq is None:
             # the statistics records of the output in the same pass (an InstanceNorm / BatchNorm reads this tensor next)
             chunks = lib.dei2i_moments_chunks(h * w)
             partial = torch.empty((n, chunks, 2, c), dtype=torch.float32, device=dev)
-            L.check(lib.dei2i_affine_act_stats_fwd(prec.code, n, h * w, c, _p(y), _p(a), _p(b), _p(res), act, _p(out), _p(partial), st),
-                    "affine_act_stats")
             _stats_stash.append((partial, chunks))
-        else:
-            L.check(lib.dei2i_affine_act_fwd(prec.code, n * h * w, c, _p(y), _p(a), _p(b), _p(res), act, _p(out), _p(xq), FP8_ACT_SCALE,
-                                             st), "affine_act")
+        for g in range(groups):                           # (one launch per group of the batch: bn_batch_groups)
+            lo = g * ng
+            rg = res[lo:] if res is not None else None
+            if partial is not None:
+                L.check(lib.dei2i_affine_act_stats_fwd(prec.code, ng, h * w, c, _p(y[lo:]), _p(av[g]), _p(bv[g]), _p(rg), act, _p(out[lo:]),
+                                                       _p(partial[lo:]), st), "affine_act_stats")
+            else:
+                L.check(lib.dei2i_affine_act_fwd(prec.code, ng * h * w, c, _p(y[lo:]), _p(av[g]), _p(bv[g]), _p(rg), act, _p(out[lo:]),
+                                                 _p(xq[lo * h * w * c:]) if xq is not None else None, FP8_ACT_SCALE, st), "affine_act")
         if xq is not None:
             _fp8_stash.append(xq)
         ctx.prec, ctx.act, ctx.training, ctx.has_res = prec, act, training, res is not None
@@ -1058,7 +1147,7 @@ class _BatchNormAct(torch.autograd.Function):
         ctx.save_for_backward(y, a, b, mean, rstd)
         ctx.hint = None
         if fuse_bwd and prec is BF16 and ctx.needs_input_grad[0]:
-            ctx.hint = _NormBwdHint(2, y, mean, rstd, a=a, b=b, act=act)
+            ctx.hint = _NormBwdHint(2, y, mean, rstd, a=a, b=b, act=act, group_images=ng if groups > 1 else 0)
             _hint_stash.append(ctx.hint)
         return out
 
@@ -1139,7 +1228,7 @@ class _BnActConv(torch.autograd.Function):
 def bn_act_conv_supported(y1, bn_weight, weight, geom: ConvGeom, need_grad: bool) -> bool:
     """Can conv(act(BatchNorm(y1))) run with the norm on the conv's operand path?  (bf16, halo-resident forward kernel takes
     the shape, and -- when gradients are needed -- so does the halo-resident wgrad kernel; plain weights only)"""
-    if not (fuse_norm and fuse_pro and y1.is_cuda and y1.dtype == torch.bfloat16 and not _fp8_forward):
+    if not (fuse_norm and fuse_pro and y1.is_cuda and y1.dtype == torch.bfloat16 and not _fp8_forward) or bn_groups > 1:
         return False
     if getattr(weight, "_dei2i_per_call", False) or bn_weight.numel() != y1.shape[-1]:
         return False

@@ -305,7 +305,8 @@ typedef struct dei2i_epi_norm {
   int kind;
   int up;
   int act;
-  int reserved;
+  int group_images;   /* kind 2: a / b / mean / rstd hold one row of C per group of this many images (BatchNorm statistics taken
+                         per group of a batch that carries several passes); 0: one row for the whole batch */
   const void* x;
   const float* mean;
   const float* rstd;

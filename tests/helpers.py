@@ -107,3 +107,21 @@ def unbatch_discriminator(tape, ncalls, n):
             out.append(tuple(tape[i][:2]))
             i += 1
     return out
+
+
+def unpair_generator(tape, n):
+    """The product runs the G loss's four generator passes as TWO passes over 2 x batch (ops.paired_passes: heads [bg | df], then
+    tails [fake_defects | fake_normals]); the oracle follows the reference's order bg -> fake_defects, fake_defects ->
+    recover_normals, df -> fake_normals, fake_normals -> recover_defects.  Re-order the generator's records -- the leading run of
+    untagged norm + activation sites over 2n samples, half of it per paired pass -- into that per-pass order."""
+    j = 0
+    while j < len(tape) and len(tape[j]) == 2 and tape[j][0] in ("relu", "leaky") and tape[j][1].shape[0] == 2 * n:
+        j += 1
+    if j == 0 or j % 2:
+        return list(tape)
+    heads, tails = tape[:j // 2], tape[j // 2:j]
+    out = []
+    for lo in (0, n):
+        out.extend((k, t[lo:lo + n]) for k, t in heads)
+        out.extend((k, t[lo:lo + n]) for k, t in tails)
+    return out + list(tape[j:])

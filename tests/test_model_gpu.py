@@ -21,7 +21,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import record_kinks, unbatch_discriminator, formula_fill, load_golden, make_opt
+from helpers import record_kinks, unbatch_discriminator, unpair_generator, formula_fill, load_golden, make_opt
 from oracle import defectgan_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -135,6 +135,8 @@ def test_step_gradients_match_oracle_fp64(name, c, gtol):
         return out
 
     d_tape = unbatch_discriminator(d_tape, 4, c["batch"])        # product: one D pass over 4 batches; oracle: 4 passes
+    if tr.model._pairs_generator_passes(bg.to("cuda:0"), df.to("cuda:0"), None):
+        g_tape = unpair_generator(g_tape, c["batch"])            # product: two G passes over 2 x batch; oracle: four passes
     g_tape = unbatch_discriminator(g_tape, 2, c["batch"])
     d_gan, d_clf, gD = oracle(O.train_discriminator_once, d_tape, SG, SD, None, bg.double(), labels.double(), df.double(), cfg)
     g_losses, gG = oracle(O.train_generator_once, g_tape, {k: v.clone() for k, v in SG.items()},
