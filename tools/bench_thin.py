@@ -32,7 +32,7 @@ def timed(fn, cold):
 
 
 # name, cin, cout, k, stride, pad, H, N, act
-SHAPES = [("stem 3>64 7x7 @256 N16", 3, 64, 7, 1, 3, 256, 16, "none"), ("heads 64>4 3x3 @256 N16", 64, 4, 3, 1, 1, 256, 16, "none"),
+SHAPES = [("stem 3>64 7x7 @256 N32", 3, 64, 7, 1, 3, 256, 32, "none"), ("heads 64>4 3x3 @256 N16", 64, 4, 3, 1, 1, 256, 16, "none"),
           ("D0 3>64 4x4 s2 @256 N64", 3, 64, 4, 2, 1, 256, 64, "leaky_relu")]
 print("%-28s %10s %18s %18s   (us per launch, warm / cold)" % ("", "", "forward", "input gradient"))
 for name, cin, cout, k, s, pad, H, N, act in SHAPES:
