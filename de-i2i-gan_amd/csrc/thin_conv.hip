@@ -247,7 +247,7 @@ __global__ __launch_bounds__(512) void thin_cout_conv_kernel(const GatherDesc g,
                                                              const int nbuf) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const halo = smem;                                  // [nbuf][2 planes][plane_bytes]
-  unsigned char* const wl = smem + nbuf * halo_bytes;                // !WREG: [wrows][K*2 B] weights (only the live rows: see the launcher)
+  unsigned char* const wl = smem + nbuf * halo_bytes;                // !WREG: [8 rows][K*2 B] weights
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // tile row of this wave
@@ -258,9 +258,11 @@ __global__ __launch_bounds__(512) void thin_cout_conv_kernel(const GatherDesc g,
   const int plane_bytes = halo_bytes >> 1;
 
   if constexpr (!WREG) {
-    for (int i = tid; i < wrows * (wrow_bytes >> 4); i += 512) {
+    for (int i = tid; i < TO_MAXCO * (wrow_bytes >> 4); i += 512) {
       const int row = i / (wrow_bytes >> 4), ch = i - row * (wrow_bytes >> 4);
-      *reinterpret_cast<u32x4*>(wl + row * wrow_bytes + ch * 16) = *reinterpret_cast<const u32x4*>(wgt + (size_t)row * g.K + ch * 8);
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (row < wrows) v = *reinterpret_cast<const u32x4*>(wgt + (size_t)row * g.K + ch * 8);
+      *reinterpret_cast<u32x4*>(wl + row * wrow_bytes + ch * 16) = v;
     }
   }
 
@@ -326,8 +328,8 @@ __global__ __launch_bounds__(512) void thin_cout_conv_kernel(const GatherDesc g,
       wf[f] = v;
     }
   }
-  const bool wlive = l16 < wrows;                                    // A rows >= wrows are zero registers, not LDS rows
-  const unsigned char* const wbase = wl + (wlive ? l16 : 0) * wrow_bytes + kg * 16;
+  const unsigned char* const wbase = wl + (l16 < TO_MAXCO ? l16 : 0) * wrow_bytes + kg * 16;
+  const bool wlive = l16 < TO_MAXCO;
   // byte address (plane 0, before the swizzle) of this lane's chunk of pixel (tile row `wave`, column l16) at tap (0,0); columns
   // 16..31 are 16 rows = 1024 bytes further (same swizzle bit)
   const int pix0 = (wave + (g.ys < 0 ? g.th - 1 : 0)) * hwd + l16 + (g.xs < 0 ? g.tw - 1 : 0);
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(512) void thin_cout_conv_kernel(const GatherDesc g,
       __syncthreads();
       if (tn < ntiles) issue_halo((it + 1) & 1, tn);
       hb = halo + (it & 1) * halo_bytes;
-    } else {                                                         // (a halo pair + weights over 160 KB: one buffer, load then compute)
+    } else {                                                         // 7x7: one 68 KB halo buffer next to 50 KB of weights
       __syncthreads();                                               // everyone is done with the previous tile
       issue_halo(0, t);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -421,10 +423,7 @@ hipError_t thin_cout_conv(const GatherDesc& g, const void* src, const void* wgt,
   const int halo_bytes = 2 * ((hwd * hht + 15) / 16) * 1024;          // two channel planes of 16-pixel groups
   if (2 * ((hwd * hht + 15) / 16) > 8 * TO_MAXG) return hipErrorNotSupported;
   const bool wreg = g.th == 3 && g.tw == 3;                            // 18 weight fragments in registers
-  // 7x7 (the stem's input gradient, 3 live rows of 6 272 B): only the live rows are kept -- 2 x 68 KB of halo + 18.4 KB fit, and
-  // tile t+1's halo streams in under tile t as in the 3x3 launches (with 8 rows, 50 KB, there was room for ONE halo buffer: every
-  // tile paid its cold HBM fetch in full -- 225 us per launch in the step against 111 us warm)
-  const size_t wbytes = wreg ? 0 : (size_t)wrows * g.K * 2;
+  const size_t wbytes = wreg ? 0 : (size_t)TO_MAXCO * g.K * 2;
   int nbuf = 2;
   if (2 * (size_t)halo_bytes + wbytes > 160 * 1024) nbuf = 1;
   const size_t lds = nbuf * (size_t)halo_bytes + wbytes;

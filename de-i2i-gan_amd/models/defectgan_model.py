@@ -228,7 +228,8 @@ class DefectGanModel(BaseModel):
             n = bg_data.shape[0]
             with ops.bn_running_deferred() as running, ops.bn_batch_groups(2):
                 running.pass_index = (0, 2)
-                fakes, probs = self.netG(torch.cat([bg_data, df_data], 0), head_labels, None)
+                reals = torch.cat([bg_data, df_data], 0)
+                fakes, probs = self.netG(reals, head_labels, None)
                 running.pass_index = (1, 3)
                 recovers, rec_probs = self.netG(fakes, tail_labels, None)
                 running.apply()
@@ -278,12 +279,27 @@ class DefectGanModel(BaseModel):
         for p in d_params:
             p.requires_grad_(False)
         policy = getattr(self.opt, "diff_aug", "")            # DiffAugment on what D sees (defectgan_model.py:200-203)
+        whole = paired and not policy
         try:
-            (fake_defects_src, fake_defects_cls), (fake_normals_src, fake_normals_cls) = \
-                self._netD_batched(diff_augment(fake_defects, policy), diff_augment(fake_normals, policy))
+            if whole:
+                fakes_src, fakes_cls = self.netD(fakes)
+            else:
+                (fake_defects_src, fake_defects_cls), (fake_normals_src, fake_normals_cls) = \
+                    self._netD_batched(diff_augment(fake_defects, policy), diff_augment(fake_normals, policy))
         finally:
             for p in d_params:
                 p.requires_grad_(True)
+        if whole:
+            # Every loss group of the reference is a mean of per-pass means over equally sized halves of what the paired passes hold
+            # as ONE tensor: the mean over the whole tensor is the same number (to the rounding of a differently ordered fp32 sum),
+            # without slicing the passes' outputs apart (a zero fill, a copy and an add per slice in backward).
+            gan_loss = self._cal_loss(fakes_src, 1.0, "bce")
+            clf_loss = self._cal_loss(fakes_cls, head_labels.view_as(fakes_cls), self.clf_loss_type)
+            rec_loss = self._cal_loss(recovers, reals, "l1")              # [recover_normals | recover_defects] vs [bg | df]
+            sd_cyc_loss = self._cal_loss(probs, rec_probs, "l1")      # (--cycle_gan never pairs: _forks_generator_chains)
+            sd_con_loss = self._mean([self._cal_loss(probs, None, "l1"), self._cal_loss(rec_probs, None, "l1")])
+            out = (gan_loss, clf_loss, rec_loss, sd_cyc_loss, sd_con_loss)
+            return out + (distill["latent"], distill["embed"]) if distill is not None else out
 
         gan_loss = [self._cal_loss(fake_defects_src, 1.0, "bce"), self._cal_loss(fake_normals_src, 1.0, "bce")]
         clf_loss = [self._cal_loss(fake_defects_cls, df_labels.view_as(fake_defects_cls), self.clf_loss_type),

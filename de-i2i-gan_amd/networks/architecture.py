@@ -408,11 +408,8 @@ class SPADE(nn.Module):
             return
         gb = self._gamma_beta(torch.cat(list(segmaps), 0), prec, True, 0, 0)
         self._gb_cache.clear()
-        off = 0
-        for sgm in segmaps:
-            n = sgm.shape[0]
-            self._gb_cache[self._table_key(sgm, prec)] = (sgm, gb[off:off + n])
-            off += n
+        for sgm, part in zip(segmaps, ops.split_rows(gb, [sgm.shape[0] for sgm in segmaps])):
+            self._gb_cache[self._table_key(sgm, prec)] = (sgm, part)
 
 
 class AdaIN(nn.Module):

@@ -1584,6 +1584,39 @@ def instance_norm_act(x, act="none", res=None, eps=1e-5):
     return _InstanceNormAct.apply(x, slope, res, float(eps))
 
 
+class _SplitRows(torch.autograd.Function):
+    """x -> consecutive row blocks of x (views, sizes given): what ``x[a:b]`` per block does, with ONE launch in backward (the
+    concatenation of the blocks' gradients) instead of a zero fill + a copy per block and an add per extra block."""
+
+    @staticmethod
+    def forward(ctx, x, *sizes):
+        ctx.set_materialize_grads(False)
+        ctx.sizes, ctx.meta = sizes, (x.shape, x.dtype, x.device)
+        outs, off = [], 0
+        for n in sizes:
+            outs.append(x.narrow(0, off, n))
+            off += n
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        shape, dtype, device = ctx.meta
+        if all(g is None for g in grads):
+            return (None,) + (None,) * len(ctx.sizes)
+        parts = [g if g is not None else torch.zeros((n,) + tuple(shape[1:]), dtype=dtype, device=device)
+                 for g, n in zip(grads, ctx.sizes)]
+        return (torch.cat(parts, 0),) + (None,) * len(ctx.sizes)
+
+
+def split_rows(x, sizes):
+    """The consecutive row blocks of ``x`` (dim 0) as views; see _SplitRows."""
+    if sum(sizes) != x.shape[0]:
+        raise ValueError(f"split_rows: blocks {list(sizes)} do not cover {x.shape[0]} rows")
+    if not x.requires_grad or not torch.is_grad_enabled():
+        return tuple(x.split(list(sizes), 0))
+    return _SplitRows.apply(x, *[int(n) for n in sizes])
+
+
 class _Scale(torch.autograd.Function):
     """x * s on an NHWC activation (stargan-v2's "/ sqrt(2)" after every residual add, core/model.py:67,121)"""
 

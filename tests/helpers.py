@@ -124,4 +124,14 @@ def unpair_generator(tape, n):
     for lo in (0, n):
         out.extend((k, t[lo:lo + n]) for k, t in heads)
         out.extend((k, t[lo:lo + n]) for k, t in tails)
-    return out + list(tape[j:])
+    # the paired form takes its L1 losses over the whole tensors: the reconstruction site holds [recover_normals - bg | recover_defects -
+    # df] (the reference evaluates the defects term first), the cycle site [df_prob - rec_df_prob | nm_prob - rec_nm_prob] (in order)
+    rest, seen = [], 0
+    for rec in tape[j:]:
+        if rec[0] == "l1" and len(rec) == 2 and rec[1].shape[0] == 2 * n:
+            halves = (rec[1][n:], rec[1][:n]) if seen == 0 else (rec[1][:n], rec[1][n:])
+            rest.extend(("l1", h) for h in halves)
+            seen += 1
+        else:
+            rest.append(rec)
+    return out + rest
