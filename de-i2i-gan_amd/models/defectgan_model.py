@@ -204,17 +204,33 @@ class DefectGanModel(BaseModel):
         return (ops.paired_passes and self._forks_generator_chains(bg_data, nm_feat, flag=True) and self.netG.training
                 and bg_data.shape == df_data.shape)
 
+    def _paired_label_sets(self, labels_in, nm_labels, df_labels):
+        """-> ([df | nm], [nm | df], same): the label tensors of the paired passes.  ``same``: they are the very tensors the last
+        call made for this incoming label tensor (the D step and the G step of one iteration get the same one) -- the SPADE class
+        tables are memoized per label TENSOR and parameter state, so the tables the D step computed serve the G step's passes (the
+        generator's parameters do not change in between).  The incoming tensor is held, so no other tensor can take its identity."""
+        st = getattr(self, "_label_sets", None)
+        if st is not None and st[0] is labels_in and st[1] == labels_in._version:
+            return st[2], st[3], True
+        head, tail = torch.cat([df_labels, nm_labels], 0), torch.cat([nm_labels, df_labels], 0)
+        self._label_sets = (labels_in, labels_in._version, head, tail)
+        return head, tail, False
+
     def _compute_generator_loss(self, bg_data, df_labels, df_data):
         """defectgan_model.py:173-249"""
+        labels_in = df_labels
         nm_labels, df_labels = self._get_labels(df_labels)
         nm_feat, df_feat = self._style_feats(bg_data, nm_labels, df_labels, df_data)
-        self.netG.clear_spade_cache()
         paired = self._pairs_generator_passes(bg_data, df_data, nm_feat)
         if paired:
-            head_labels, tail_labels = torch.cat([df_labels, nm_labels], 0), torch.cat([nm_labels, df_labels], 0)
-            self.netG.prime_spade((head_labels, tail_labels))
-        elif not os.environ.get("DEI2I_SPLIT_D") and nm_feat is None:
-            self.netG.prime_spade((df_labels, nm_labels))        # both label sets' SPADE tables in one pass
+            head_labels, tail_labels, same = self._paired_label_sets(labels_in, nm_labels, df_labels)
+            if not same:
+                self.netG.clear_spade_cache()
+            self.netG.prime_spade((head_labels, tail_labels))     # (a no-op for the modules whose tables the D step left)
+        else:
+            self.netG.clear_spade_cache()
+            if not os.environ.get("DEI2I_SPLIT_D") and nm_feat is None:
+                self.netG.prime_spade((df_labels, nm_labels))    # both label sets' SPADE tables in one pass
         sean = self.opt.style_norm_block_type == "sean"       # defectgan_model.py:177-182,192-197: what the four passes also feed
         if self._sean_distill():
             self.netG.enable_sean_distill_loss(True)
@@ -316,6 +332,7 @@ class DefectGanModel(BaseModel):
 
     def _compute_discriminator_loss(self, bg_data, df_labels, df_data):
         """defectgan_model.py:251-292"""
+        labels_in = df_labels
         nm_labels, df_labels = self._get_labels(df_labels)
         nm_feat, df_feat = self._style_feats(bg_data, nm_labels, df_labels, df_data)
         self.netG.clear_spade_cache()
@@ -331,7 +348,18 @@ class DefectGanModel(BaseModel):
                 # netG is in eval mode here (defectgan_model.py:87-90): BatchNorm uses running statistics and SPADE's / AdaIN's
                 # InstanceNorm is per sample, so one pass over both batches is the same function as two passes
                 feats = None if nm_feat is None else torch.cat([df_feat, nm_feat], 0)
-                fakes, _ = self.netG(torch.cat([bg_data, df_data], 0), torch.cat([df_labels, nm_labels], 0), feats)
+                both_labels = None
+                if (ops.paired_passes and self._forks_generator_chains(bg_data, nm_feat, flag=True) and bg_data.shape == df_data.shape
+                        and any(p.requires_grad for p in self.netG.parameters())):
+                    # the G step of this iteration will run its passes paired over the same label sets: compute the SPADE class
+                    # tables of both sets now, WITH their autograd history, and let that step find them (_paired_label_sets) --
+                    # one table computation per iteration instead of two (20 small convs and as many launches of glue)
+                    both_labels, tail_labels, _ = self._paired_label_sets(labels_in, nm_labels, df_labels)
+                    with torch.enable_grad():
+                        self.netG.prime_spade((both_labels, tail_labels))
+                if both_labels is None:
+                    both_labels = torch.cat([df_labels, nm_labels], 0)
+                fakes, _ = self.netG(torch.cat([bg_data, df_data], 0), both_labels, feats)
                 fake_defects, fake_normals = fakes.split([bg_data.shape[0], df_data.shape[0]])
         policy = getattr(self.opt, "diff_aug", "")            # defectgan_model.py:266-270: fakes first, then the real batches
         fake_defects, fake_normals = diff_augment(fake_defects.detach(), policy), diff_augment(fake_normals.detach(), policy)

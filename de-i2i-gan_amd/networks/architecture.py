@@ -374,6 +374,8 @@ class SPADE(nn.Module):
         # autograd sums the gradients of all its uses -- is computed once per (label tensor, weight state, grad mode).
         key = self._table_key(segmap, prec)
         hit = self._gb_cache.get(key)
+        if hit is None and not torch.is_grad_enabled():      # a table that carries history serves a no-grad pass as well
+            hit = self._gb_cache.get(self._table_key(segmap, prec, grad=True))
         if hit is None:
             gb = self._gamma_beta(segmap, prec, True, h, w)
             if len(self._gb_cache) >= 2:
@@ -392,10 +394,10 @@ class SPADE(nn.Module):
             return ops.spade_relu(x, self._gamma_beta(segmap, prec, False, h, w), up, 0, skip=skip)
         return ops.spade_relu(x, self._class_table(segmap, prec, h, w), up, 1, skip=skip)
 
-    def _table_key(self, segmap, prec):
+    def _table_key(self, segmap, prec, grad=None):
         params = (self.mlp_shared[0].weight, self.mlp_shared[0].bias, self.mlp_gamma.weight, self.mlp_gamma.bias,
                   self.mlp_beta.weight, self.mlp_beta.bias)
-        return (id(segmap), segmap._version, prec.code, torch.is_grad_enabled(),
+        return (id(segmap), segmap._version, prec.code, torch.is_grad_enabled() if grad is None else grad,
                 tuple(ops.PackedWeights._stamp(p) + (p.requires_grad,) for p in params))
 
     def prime(self, segmaps, prec):
@@ -406,6 +408,8 @@ class SPADE(nn.Module):
             return
         if len(segmaps) != 2 or any(s.dim() != 4 or s.shape[2] != 1 or s.shape[3] != 1 for s in segmaps):
             return
+        if all(self._table_key(sgm, prec) in self._gb_cache for sgm in segmaps):
+            return                                       # both tables are there already (same tensors, same parameter state)
         gb = self._gamma_beta(torch.cat(list(segmaps), 0), prec, True, 0, 0)
         self._gb_cache.clear()
         for sgm, part in zip(segmaps, ops.split_rows(gb, [sgm.shape[0] for sgm in segmaps])):
