@@ -98,9 +98,13 @@ class DefectGanGenerator(BaseNetwork):
 
     def prime_spade(self, label_tensors):
         """Batch the SPADE class-table computation of the label sets a loss graph is about to use (see SPADE.prime)."""
+        both = seg = None
         for m in self.modules():
             if hasattr(m, "prime") and hasattr(m, "_gb_cache"):
-                m.prime(label_tensors, self.prec)
+                if both is None and len(label_tensors) == 2 and all(t.dim() == 4 and t.shape[2:] == (1, 1) for t in label_tensors):
+                    both = torch.cat(list(label_tensors), 0)          # one concatenation and one 5x5 class image for all modules
+                    seg = ops.to_nhwc(both, self.prec, size=(5, 5))
+                m.prime(label_tensors, self.prec, both, seg)
 
     def clear_spade_cache(self):
         """Drop the memoized SPADE gamma/beta tables (they carry autograd history: a table must not outlive the loss
