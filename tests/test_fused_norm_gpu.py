@@ -626,3 +626,62 @@ def test_paired_generator_passes_equal_the_four_passes(pname):
             assert maxrel(bp[k], b1[k]) < tol_b, k
     if pname == "bf16":
         assert tp > 0              # the BatchNorm backward reductions still come out of the dgrad epilogue (per-group coefficients)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pname,C,H,W,N,epilogue", [("bf16", 256, 64, 64, 32, True), ("bf16", 64, 32, 32, 8, False), ("f32", 48, 16, 16, 4, False),
+                                                     ("f32", 6, 16, 16, 4, False)])
+def test_batchnorm_per_group_of_the_batch_equals_one_call_per_group(pname, C, H, W, N, epilogue):
+    """ops.bn_batch_groups(2): a training-mode BatchNorm + LeakyReLU (architecture.py:116-118) over a batch that carries two passes
+    takes its statistics, its apply and its backward per half of the batch -- against the same op called once per half (the
+    reference's form: one pass, one call): outputs, input gradients (behind a conv, so that on the halo-kernel shapes the backward
+    reductions come from the dgrad epilogue with per-group coefficients) and the replayed running statistics are the same BITS;
+    the parameter gradients are the same two-term fp32 sums.  C = 6 exercises the padded channel stride."""
+    from de_i2i_gan_amd import ops
+    from de_i2i_gan_amd.networks.architecture import Conv2d
+    prec = ops.BF16 if pname == "bf16" else ops.F32
+    torch.manual_seed(5)
+    cs = prec.pad(C)
+    x = nhwc((torch.randn(N, C, H, W) * 1.5 + 0.3).to(prec.dtype), cs).to(DEV)
+    conv = Conv2d(C, 32, 3, padding="same", padding_mode="reflect", bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(32, C, 3, 3) * math.sqrt(2.0 / (C * 9)))
+    conv = conv.to(DEV)
+    gy = torch.randn(N, H, W, prec.pad(32), device=DEV).to(prec.dtype)
+    res = {}
+    for grouped in (True, False):
+        bn_w = (torch.rand(C) + 0.5).to(DEV).requires_grad_(True)
+        bn_b = (torch.randn(C) * 0.1).to(DEV).requires_grad_(True)
+        torch.manual_seed(6)
+        bn_w.data.copy_(torch.rand(C) + 0.5)
+        bn_b.data.copy_(torch.randn(C) * 0.1)
+        rm, rv, nbt = torch.zeros(C, device=DEV), torch.ones(C, device=DEV), torch.zeros((), dtype=torch.int64, device=DEV)
+        conv.weight.grad = None
+        xg = x.clone().requires_grad_(True)
+        before = dict(ops.bwd_fused_counts)
+        with ops.bn_running_deferred() as running:
+            if grouped:
+                with ops.bn_batch_groups(2):
+                    running.pass_index = (0, 1)
+                    z = ops.batchnorm_act(xg, bn_w, bn_b, rm, rv, True, "leaky_relu", num_batches_tracked=nbt)
+                out = conv(z)
+            else:
+                zs = []
+                for g in range(2):
+                    running.pass_index = g
+                    zs.append(ops.batchnorm_act(xg[g * (N // 2):(g + 1) * (N // 2)], bn_w, bn_b, rm, rv, True, "leaky_relu",
+                                                num_batches_tracked=nbt))
+                z = torch.cat(zs, 0)
+                out = torch.cat([conv(t) for t in zs], 0)
+            running.apply()
+        out.backward(gy)
+        torch.cuda.synchronize()
+        took = ops.bwd_fused_counts["taken"] - before["taken"]
+        res[grouped] = (z.detach().clone(), xg.grad.clone(), bn_w.grad.clone(), bn_b.grad.clone(), rm.clone(), rv.clone(), int(nbt), took)
+    g_, s_ = res[True], res[False]
+    assert torch.equal(g_[0], s_[0])                     # the normalised activations
+    assert torch.equal(g_[1], s_[1])                     # dL/dx
+    assert maxrel(g_[2], s_[2]) < 1e-6 and maxrel(g_[3], s_[3]) < 1e-6
+    assert torch.equal(g_[4], s_[4]) and torch.equal(g_[5], s_[5]) and g_[6] == s_[6] == 2
+    if epilogue:
+        assert g_[7] == 1 and s_[7] == 2                 # one dgrad launch took both groups' reductions
