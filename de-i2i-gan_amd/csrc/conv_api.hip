@@ -9,6 +9,7 @@ namespace dei2i {
 int g_use_wgrad_v2 = 1;
 int g_use_wgrad_halo = 1;
 int g_use_wgrad_thin = 1;
+int g_dgrad_s2_ring = 1;          // option "dgrad_s2_ring": stride-2 reflect dgrads decomposed (interior into dx + ring rectangles)
 extern int g_halo_bn, g_halo_stages, g_halo16, g_halo16_stages, g_halo16_fold;
 
 static ConvShape to_shape(const dei2i_conv* c) {
@@ -462,6 +463,52 @@ int dei2i_conv2d_dgrad_input(const dei2i_conv* c, const void* dy, const void* wd
     else
       hipLaunchKernelGGL(fold_border_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)ext_scratch, (float*)dx, c->N,
                          c->H, c->W, c->CinS, p);
+    return (int)hipGetLastError();
+  }
+  if (reflect && g_dgrad_s2_ring && c->stride == 2 && c->kh == 4 && c->kw == 4 && p == 1 && !c->up && c->H % 2 == 0 && c->W % 2 == 0 &&
+      c->H >= 8 && c->W >= 8 && (size_t)c->N * c->H * c->W * c->CinS >= ((size_t)48 << 20)) {     // (the fold pass costs ~0.5 us per M elements, the ring ~30 us)
+    // The stride-2 4x4 convs of the encoder / discriminator (generator.py:107-116, discriminator.py:60-77), large frames: the same
+    // decomposition as above, per parity class.  The frame's interior is the zero-boundary dgrad on the input grid (four classes,
+    // one launch, straight into dx: no (H+2) x (W+2) frame tensor and no full-size fold pass over it -- up to 135 us per conv at
+    // 256 x 256 x 64 x 32 images); frame row 0 / H+1 and column 0 / W+1 are one-pixel rectangles of the two classes of their
+    // parity, two small launches into ext_scratch (dead taps skipped), folded onto rows 1 / H-2 and columns 1 / W-2 of dx.
+    ConvShape sh = to_shape(c);
+    GatherDesc fr[2][2], in4[4];
+    long long woff[2][2], woffs[4], off = 0;
+    for (int ay = 0; ay < 2; ++ay)
+      for (int ax = 0; ax < 2; ++ax) {
+        fr[ay][ax] = make_dgrad_desc(sh, c->CoutS, ay, ax);
+        woff[ay][ax] = off;
+        off += (long long)c->Cin * dgrad_taps(c->kh, 2, ay) * dgrad_taps(c->kw, 2, ax) * c->CoutS;
+      }
+    sh.pad_mode = PAD_ZERO;
+    for (int ay = 0; ay < 2; ++ay)
+      for (int ax = 0; ax < 2; ++ax) { in4[2 * ay + ax] = make_dgrad_desc(sh, c->CoutS, ay, ax); woffs[2 * ay + ax] = woff[ay][ax]; }
+    hipError_t e = gather_gemm_multi(c->dtype, in4, woffs, 4, dy, wd_packed, c->Cin, nullptr, dx, ws, ws_bytes, c->CinS, ACT_NONE, st);
+    if (e != hipSuccess) return (int)e;
+    // frame rows: hp = 0 is row 0 of the classes ay = 0, hp = H + 1 (odd) the last row of the classes ay = 1; all their columns
+    const GatherDesc rows[4] = {sub_rect_desc(fr[0][0], 0, 1, 0, fr[0][0].Wo), sub_rect_desc(fr[0][1], 0, 1, 0, fr[0][1].Wo),
+                                sub_rect_desc(fr[1][0], fr[1][0].Ho - 1, 1, 0, fr[1][0].Wo),
+                                sub_rect_desc(fr[1][1], fr[1][1].Ho - 1, 1, 0, fr[1][1].Wo)};
+    const long long wrows4[4] = {woff[0][0], woff[0][1], woff[1][0], woff[1][1]};
+    e = gather_gemm_multi(c->dtype, rows, wrows4, 4, dy, wd_packed, c->Cin, nullptr, ext_scratch, ws, ws_bytes, c->CinS, ACT_NONE, st, true);
+    if (e != hipSuccess) return (int)e;
+    // frame columns without the corners (they are in the rows): wp = 0 is column 0 of the classes ax = 0 (class ay = 0 without its
+    // row 0, class ay = 1 without its last row), wp = W + 1 the last column of the classes ax = 1
+    const GatherDesc cols[4] = {sub_rect_desc(fr[0][0], 1, fr[0][0].Ho - 1, 0, 1), sub_rect_desc(fr[1][0], 0, fr[1][0].Ho - 1, 0, 1),
+                                sub_rect_desc(fr[0][1], 1, fr[0][1].Ho - 1, fr[0][1].Wo - 1, 1),
+                                sub_rect_desc(fr[1][1], 0, fr[1][1].Ho - 1, fr[1][1].Wo - 1, 1)};
+    const long long wcols4[4] = {woff[0][0], woff[1][0], woff[0][1], woff[1][1]};
+    e = gather_gemm_multi(c->dtype, cols, wcols4, 4, dy, wd_packed, c->Cin, nullptr, ext_scratch, ws, ws_bytes, c->CinS, ACT_NONE, st, true);
+    if (e != hipSuccess) return (int)e;
+    const int vec = c->dtype == DT_BF16 ? 8 : 4;
+    const size_t total = (size_t)c->N * (2 * c->W + 2 * (c->H - 2)) * (c->CinS / vec);
+    if (c->dtype == DT_BF16)
+      hipLaunchKernelGGL(fold_border_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const bf16_t*)ext_scratch, (bf16_t*)dx,
+                         c->N, c->H, c->W, c->CinS, 1);
+    else
+      hipLaunchKernelGGL(fold_border_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const float*)ext_scratch, (float*)dx, c->N,
+                         c->H, c->W, c->CinS, 1);
     return (int)hipGetLastError();
   }
   const int rc = dei2i_conv2d_dgrad(c, dy, wd_packed, ext_scratch, ws, ws_bytes, s);

@@ -14,6 +14,7 @@ extern int g_use_wgrad_v2;
 extern int g_use_wgrad_halo;
 extern int g_wgrad_halo_cbw, g_wgrad_halo_abl;
 extern int g_use_wgrad_thin;
+extern int g_dgrad_s2_ring;
 extern int g_wt_splits_per_cu;
 extern int g_halo_mfma32;
 extern int g_halo_bn, g_halo_stages;
@@ -116,6 +117,7 @@ int dei2i_set_option(const char* name, int value) {
   if (std::string(name) == "wgrad_halo_abl") { g_wgrad_halo_abl = value; return 0; }
   if (std::string(name) == "wgrad_halo_cbw") { g_wgrad_halo_cbw = value == 1 ? 1 : 2; return 0; }
   if (std::string(name) == "wgrad_thin") { g_use_wgrad_thin = value; return 0; }
+  if (std::string(name) == "dgrad_s2_ring") { g_dgrad_s2_ring = value; return 0; }
   if (std::string(name) == "wgrad_thin_splits") { g_wt_splits_per_cu = value; return 0; }
   if (std::string(name) == "v2_ablate") { g_v2_ablate = value; return 0; }     // timing-only builds: 1 = no loads, 2 = no MFMA
   return DEI2I_ERR_BAD_ARG;

@@ -179,6 +179,67 @@ long long hc_conv_dgrad_decomposed(const int* p, const float* dy, const float* w
   return written;
 }
 
+// The same decomposition for the 4x4 stride-2 pad-1 reflect convs (dei2i_conv2d_dgrad_input, conv_api.hip): per parity class the
+// zero-boundary dgrad straight into dx; frame rows 0 / H+1 and columns 0 / W+1 as one-pixel rectangles of the classes of their
+// parity into ext; border fold.  Returns the number of ext elements written (must be the ring, nothing else, each once).
+long long hc_conv_dgrad_decomposed_s2(const int* p, const float* dy, const float* wd, float* ext, float* dx) {
+  ConvShape s = shape_of(p);
+  const int CinS = p[5], CoutS = p[6];
+  GatherDesc fr[2][2];
+  long long woff[2][2], off = 0;
+  for (int ay = 0; ay < 2; ++ay)
+    for (int ax = 0; ax < 2; ++ax) {
+      fr[ay][ax] = make_dgrad_desc(s, CoutS, ay, ax);
+      woff[ay][ax] = off;
+      off += (long long)s.Cin * dgrad_taps(s.kh, 2, ay) * dgrad_taps(s.kw, 2, ax) * CoutS;
+    }
+  ConvShape z = s;
+  z.pad_mode = PAD_ZERO;
+  for (int ay = 0; ay < 2; ++ay)
+    for (int ax = 0; ax < 2; ++ax) {
+      const GatherDesc g = make_dgrad_desc(z, CoutS, ay, ax);
+      if (g.M > 0) run_gather_gemm(g, dy, wd + woff[ay][ax], s.Cin, dx, CinS);
+    }
+  const GatherDesc rects[8] = {sub_rect_desc(fr[0][0], 0, 1, 0, fr[0][0].Wo), sub_rect_desc(fr[0][1], 0, 1, 0, fr[0][1].Wo),
+                               sub_rect_desc(fr[1][0], fr[1][0].Ho - 1, 1, 0, fr[1][0].Wo),
+                               sub_rect_desc(fr[1][1], fr[1][1].Ho - 1, 1, 0, fr[1][1].Wo),
+                               sub_rect_desc(fr[0][0], 1, fr[0][0].Ho - 1, 0, 1), sub_rect_desc(fr[1][0], 0, fr[1][0].Ho - 1, 0, 1),
+                               sub_rect_desc(fr[0][1], 1, fr[0][1].Ho - 1, fr[0][1].Wo - 1, 1),
+                               sub_rect_desc(fr[1][1], 0, fr[1][1].Ho - 1, fr[1][1].Wo - 1, 1)};
+  const long long woffs[8] = {woff[0][0], woff[0][1], woff[1][0], woff[1][1], woff[0][0], woff[1][0], woff[0][1], woff[1][1]};
+  long long written = 0;
+  for (int k = 0; k < 8; ++k) {
+    run_gather_gemm(rects[k], dy, wd + woffs[k], s.Cin, ext, CinS);
+    written += (long long)rects[k].M * CinS;
+  }
+  const int OH = s.H + 2, OW = s.W + 2, per_img = 2 * s.W + 2 * (s.H - 2);
+  for (int n = 0; n < s.N; ++n)
+    for (int q = 0; q < per_img; ++q) {
+      int h, w;
+      if (q < 2 * s.W) {
+        const int k = q / s.W;
+        w = q - k * s.W;
+        h = k < 1 ? 1 + k : s.H - 2 + (k - 1);
+      } else {
+        const int q2 = q - 2 * s.W;
+        const int k = q2 % 2;
+        const int hr = q2 / 2;
+        w = k < 1 ? 1 + k : s.W - 2 + (k - 1);
+        h = hr == 0 ? 0 : (hr <= s.H - 4 ? 1 + hr : s.H - 1);
+      }
+      int ys[6], xs[6];
+      const int ny = fold_sources(h, 0, s.H, 1, 1, ys), nx = fold_sources(w, 0, s.W, 1, 1, xs);
+      for (int c = 0; c < CinS; ++c) {
+        double acc = dx[(((long long)n * s.H + h) * s.W + w) * CinS + c];
+        for (int a = 0; a < ny; ++a)
+          for (int b = 0; b < nx; ++b)
+            if (a != 0 || b != 0) acc += ext[(((long long)n * OH + ys[a]) * OW + xs[b]) * CinS + c];
+        dx[(((long long)n * s.H + h) * s.W + w) * CinS + c] = (float)acc;
+      }
+    }
+  return written;
+}
+
 int hc_fastdiv_selftest(void) {
   const unsigned ds[] = {1, 2, 3, 4, 5, 7, 8, 9, 16, 25, 49, 64, 100, 147, 255, 256, 1000, 4096, 65536, 1048576, 16777215};
   const unsigned ns[] = {0, 1, 2, 3, 7, 8, 63, 64, 65, 999, 1000, 1001, 65535, 65536, 1048575, 16777216, 2147483647u};

@@ -101,6 +101,18 @@ def test_conv_geometry(hc, case):
         assert np.isnan(ext2[:, ~ring]).all() and not np.isnan(ext2[:, ring]).any()      # the ring and only the ring
         np.testing.assert_allclose(dx2[..., :cin], gx.permute(0, 2, 3, 1).numpy(), rtol=1e-4, atol=1e-4)
 
+    # ... and of the 4x4 stride-2 pad-1 reflect convs, per parity class
+    if mode == 1 and pad == 1 and s == 2 and k == 4 and not up and H >= 8 and H % 2 == 0 and W % 2 == 0:
+        ext2 = np.full((N, dims[2], dims[3], cins), np.nan, np.float32)
+        dx2 = np.full((N, H, W, cins), np.nan, np.float32)
+        hc.hc_conv_dgrad_decomposed_s2.restype = ctypes.c_longlong
+        written = hc.hc_conv_dgrad_decomposed_s2(ptr(p), ptr(gyn), ptr(wd), ptr(ext2), ptr(dx2))
+        ring = np.ones((dims[2], dims[3]), bool)
+        ring[1:1 + H, 1:1 + W] = False
+        assert written == N * int(ring.sum()) * cins
+        assert np.isnan(ext2[:, ~ring]).all() and not np.isnan(ext2[:, ring]).any()
+        np.testing.assert_allclose(dx2[..., :cin], gx.permute(0, 2, 3, 1).numpy(), rtol=1e-4, atol=1e-4)
+
     # wgrad
     dwp = np.zeros(cout * k * k * cins, np.float32)
     hc.hc_conv_wgrad(ptr(p), ptr(xn), ptr(gyn), ptr(dwp))

@@ -60,18 +60,22 @@ def maxrel(a, b):
 R, V2, V1 = {"halo_conv": 1, "gather_v1": 1}, {"gather_v2": 1}, {"gather_v1": 1}
 # "halo16_s2": the 16 x 32 tile kernel's stride-2 form (parity planes in LDS) -- taken for the 64-channel inputs, where it beats the
 # gather GEMM (conv_halo16.hip: halo16_s2_shape_ok)
+# V2R: the stride-2 reflect dgrad of a LARGE frame, decomposed (conv_api.hip dei2i_conv2d_dgrad_input): the four parity classes of the
+# zero-boundary dgrad in one launch straight into dx + two small launches for the frame's ring rows / columns (then the border fold)
+V2R = {"gather_v2": 1, "gather_v1": 2}
 R16 = {"halo16_conv": 1}                            # 16 x 32 tile kernel: interior, reflect ring and the four frame corners in ONE launch
 HOT = [
     ("res 256->256 3x3 @64^2 N=16", 256, 256, 3, 1, 1, False, 64, 64, 16, "none", "halo16_conv", R16, "wgrad_halo"),
     ("res 256->256 3x3 @64^2 N=8", 256, 256, 3, 1, 1, False, 64, 64, 8, "none", "halo_conv", R, "wgrad_halo"),
     ("dec0 256->128 up @128^2 N=16", 256, 128, 3, 1, 1, True, 64, 64, 16, "none", "halo16_conv", V2, "wgrad_halo"),
     ("dec1 128->64 up @256^2 N=16", 128, 64, 3, 1, 1, True, 128, 128, 16, "none", "halo16_conv", V2, "wgrad_halo"),
-    ("enc0 64->128 4x4 s2 @256^2 N=16", 64, 128, 4, 2, 1, False, 256, 256, 16, "none", "halo16_s2", V2, "wgrad_v1"),
+    ("enc0 64->128 4x4 s2 @256^2 N=16", 64, 128, 4, 2, 1, False, 256, 256, 16, "none", "halo16_s2", V2R, "wgrad_v1"),
     ("enc1 128->256 4x4 s2 @128^2 N=16", 128, 256, 4, 2, 1, False, 128, 128, 16, "none", "gather_v2", V2, "wgrad_v2"),
+    ("enc1 128->256 4x4 s2 @128^2 N=32 (the paired passes' batch)", 128, 256, 4, 2, 1, False, 128, 128, 32, "none", "gather_v2", V2R, "wgrad_v2"),
     ("stem 3->64 7x7 @256^2 N=16", 3, 64, 7, 1, 3, False, 256, 256, 16, "none", "thin_cin", {"thin_cout": 1, "gather_v1": 1}, "wgrad_thin"),
     ("heads 64->4 3x3 @256^2 N=16", 64, 4, 3, 1, 1, False, 256, 256, 16, "none", "thin_cout", {"thin_cin": 1, "gather_v1": 1}, "wgrad_halo"),
     ("D0 3->64 4x4 s2 @256^2 N=64 +LReLU", 3, 64, 4, 2, 1, False, 256, 256, 64, "leaky_relu", "thin_cin", V1, "wgrad_v1"),
-    ("D1 64->128 4x4 s2 @128^2 N=64 +LReLU", 64, 128, 4, 2, 1, False, 128, 128, 64, "leaky_relu", "halo16_s2", V2, "wgrad_v1"),
+    ("D1 64->128 4x4 s2 @128^2 N=64 +LReLU", 64, 128, 4, 2, 1, False, 128, 128, 64, "leaky_relu", "halo16_s2", V2R, "wgrad_v1"),
     ("D2 128->256 4x4 s2 @64^2 N=64 +LReLU", 128, 256, 4, 2, 1, False, 64, 64, 64, "leaky_relu", "gather_v2", V2, "wgrad_v2"),
     ("D3 256->512 4x4 s2 @32^2 N=64 +LReLU", 256, 512, 4, 2, 1, False, 32, 32, 64, "leaky_relu", "gather_v2", V2, "wgrad_v2"),   # 16x16 outputs: below the 16x32 tile
     ("D4 512->1024 4x4 s2 @16^2 N=64 +LReLU", 512, 1024, 4, 2, 1, False, 16, 16, 64, "leaky_relu", "gather_v2", V2, "wgrad_v2"),
