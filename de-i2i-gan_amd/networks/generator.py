@@ -99,8 +99,8 @@ class DefectGanGenerator(BaseNetwork):
     def prime_spade(self, label_tensors):
         """Batch the SPADE class-table computation of the label sets a loss graph is about to use (see SPADE.prime)."""
         both = seg = None
-        for m in self.modules():
-            if hasattr(m, "prime") and hasattr(m, "_gb_cache"):
+        for m in self._table_modules():
+            if hasattr(m, "prime"):
                 if both is None and len(label_tensors) == 2 and all(t.dim() == 4 and t.shape[2:] == (1, 1) for t in label_tensors):
                     both = torch.cat(list(label_tensors), 0)          # one concatenation and one 5x5 class image for all modules
                     seg = ops.to_nhwc(both, self.prec, size=(5, 5))
@@ -109,9 +109,16 @@ class DefectGanGenerator(BaseNetwork):
     def clear_spade_cache(self):
         """Drop the memoized SPADE gamma/beta tables (they carry autograd history: a table must not outlive the loss
         graph it was built in).  The model calls this at the start of every loss computation."""
-        for m in self.modules():
-            if hasattr(m, "_gb_cache"):
-                m._gb_cache.clear()
+        for m in self._table_modules():
+            m._gb_cache.clear()
+
+    def _table_modules(self):
+        """The modules that memoize a gamma / beta table (walked a few times per step: the list is made once; the module tree is fixed
+        after construction)."""
+        mods = self.__dict__.get("_table_modules_list")
+        if mods is None:
+            mods = self.__dict__["_table_modules_list"] = [m for m in self.modules() if hasattr(m, "_gb_cache")]
+        return mods
 
     def update_per_epoch(self, epoch):
         """generator.py:277-284"""

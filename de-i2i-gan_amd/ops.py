@@ -121,8 +121,20 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else c_void_p(t.data_ptr())
 
 
+# The current stream's handle straight from the C layer: ``torch.cuda.current_stream()`` builds a Stream object per call (~8 us of host
+# time, several hundred calls per step -- the short steps (MAE stage, recipe options) are host-bound).
+_raw_stream_of = torch._C._cuda_getCurrentRawStream
+_current_device = torch._C._cuda_getDevice
+
+
+def _stream_id(device=None) -> int:
+    """hipStream_t (as an int) of the current stream of ``device`` (None / index-less: the current device)"""
+    idx = getattr(device, "index", device)
+    return _raw_stream_of(_current_device() if idx is None else idx)
+
+
 def _stream():
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    return c_void_p(_raw_stream_of(_current_device()))
 
 
 _initialised = set()
@@ -144,7 +156,7 @@ def _workspace(device, nbytes: int, slot: str = "splitk") -> torch.Tensor:
     """Scratch of one kernel launch (split-K slabs, the padded dgrad frame, ...), reused launch after launch ON ONE STREAM: every
     stream that runs ops has its own set (two chains of a forked pass -- ``forked_chains`` -- must not share slabs)."""
     key = (torch.device(device), slot)
-    sid = torch.cuda.current_stream(device).cuda_stream
+    sid = _stream_id(torch.device(device))
     if sid != _default_stream_id(key[0]):
         key = key + (sid,)
     ws = _workspaces.get(key)
@@ -188,7 +200,7 @@ def _grad_target(param, shape, device, stream=None):
     #  a forked pass -- returns its own tensor and autograd sums them, with its own stream synchronisation)
     sid = 0
     if key is not None and torch.device(device).type == "cuda":
-        sid = (stream if stream is not None else torch.cuda.current_stream(device)).cuda_stream
+        sid = stream.cuda_stream if stream is not None else _stream_id(torch.device(device))
     if key is not None:
         slot = _grad_slots.get(key)
         if slot is not None and slot[0] == tid and slot[2] == tuple(shape) and slot[3] == sid:
@@ -380,10 +392,10 @@ class PackedWeights:
     def _mark_packed(self):
         ev = torch.cuda.Event()
         ev.record()
-        self._packed_on = (torch.cuda.current_stream().cuda_stream, ev)
+        self._packed_on = (_stream_id(), ev)
 
     def _await_pack(self):
-        if self._packed_on is not None and self._packed_on[0] != torch.cuda.current_stream().cuda_stream:
+        if self._packed_on is not None and self._packed_on[0] != _stream_id():
             torch.cuda.current_stream().wait_event(self._packed_on[1])
 
     @staticmethod
@@ -397,6 +409,9 @@ class PackedWeights:
         # -- its own address identifies the call, and the sources' stamps (moved by those later forwards) must not
         key = ((), prec.code, cins, couts, self._stamp(weight)) if per_call else \
             (tuple(self._stamp(s) for s in sources), prec.code, cins, couts, None)
+        if key == self._key and (self.fwd is not None or not need_fwd) and (self.dgrad is not None or not need_dgrad):
+            self._await_pack()        # the hit: nothing to build (this is the call of every conv of every pass)
+            return self.fwd, self.dgrad
         lib = _lib_for(weight)
         if key != self._key:
             self._key, self.fwd, self.dgrad, self.fp8 = key, None, None, None
