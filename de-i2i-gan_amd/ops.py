@@ -390,7 +390,9 @@ class PackedWeights:
         self._packed_on = None     # (stream id, event) of the last pack launch: another stream waits for it before reading
 
     def _mark_packed(self):
-        ev = torch.cuda.Event()
+        # (the event object is made once per cache: constructing one per pack launch -- every conv weight after every optimizer step --
+        #  was ~20 us of host time each; re-recording moves it to the newest pack launch, which is the one a reader has to wait for)
+        ev = self._packed_on[1] if self._packed_on is not None else torch.cuda.Event()
         ev.record()
         self._packed_on = (_stream_id(), ev)
 
