@@ -336,12 +336,14 @@ class SPADE(nn.Module):
         self._packed_gb = ops.PackedWeights()
         self._gb_cache = {}
 
-    def _gamma_beta(self, segmap, prec, class_mode, h, w, seg=None):
+    def _gamma_beta(self, segmap, prec, class_mode, h, w, seg=None, actv=None):
         """gamma|beta of the label map: (N,5,5,2C) border-class table (class mode) or (N,H,W,2C) dense.  ``seg``: the label map
-        already resized and laid out (the same for every SPADE module of a generator: prime_spade makes it once)."""
-        if seg is None:
-            seg = ops.to_nhwc(segmap, prec, size=(5, 5) if class_mode else (h, w))
-        actv = self.mlp_shared[0](seg, "relu")
+        already resized and laid out (the same for every SPADE module of a generator: prime_spade makes it once); ``actv``: this
+        module's ReLU(mlp_shared(seg)), computed by prime_spade's one conv over all modules' filters."""
+        if actv is None:
+            if seg is None:
+                seg = ops.to_nhwc(segmap, prec, size=(5, 5) if class_mode else (h, w))
+            actv = self.mlp_shared[0](seg, "relu")
         w_gb = torch.cat([self.mlp_gamma.weight, self.mlp_beta.weight], 0)
         b_gb = torch.cat([self.mlp_gamma.bias, self.mlp_beta.bias], 0)
         geom = ops.ConvGeom(self.hidden_nc, 2 * self.norm_nc, self.mlp_gamma.kernel_size, 1, self.mlp_gamma.padding, False, False)
@@ -402,7 +404,13 @@ class SPADE(nn.Module):
         return (id(segmap), segmap._version, prec.code, torch.is_grad_enabled() if grad is None else grad,
                 tuple(ops.PackedWeights._stamp(p) + (p.requires_grad,) for p in params))
 
-    def prime(self, segmaps, prec, both=None, seg=None):
+    def wants_prime(self, segmaps, prec):
+        """Will prime() compute tables for these label tensors?  (a module that runs in class mode and does not hold them yet)"""
+        return (getattr(self, "_ran_class_mode", False) and len(segmaps) == 2
+                and all(s_.dim() == 4 and s_.shape[2] == 1 and s_.shape[3] == 1 for s_ in segmaps)
+                and not all(self._table_key(sgm, prec) in self._gb_cache for sgm in segmaps))
+
+    def prime(self, segmaps, prec, both=None, seg=None, actv=None):
         """Compute the class tables of several (N,C,1,1) label tensors in ONE pass over their concatenation and memoize
         each tensor's slice: the same function as one pass per tensor (the table convs act per sample), with half the
         launches of the 5x5 table path (forward and backward) when a loss graph uses two label sets."""
@@ -412,7 +420,7 @@ class SPADE(nn.Module):
             return
         if all(self._table_key(sgm, prec) in self._gb_cache for sgm in segmaps):
             return                                       # both tables are there already (same tensors, same parameter state)
-        gb = self._gamma_beta(both if both is not None else torch.cat(list(segmaps), 0), prec, True, 0, 0, seg=seg)
+        gb = self._gamma_beta(both if both is not None else torch.cat(list(segmaps), 0), prec, True, 0, 0, seg=seg, actv=actv)
         self._gb_cache.clear()
         for sgm, part in zip(segmaps, ops.split_rows(gb, [sgm.shape[0] for sgm in segmaps])):
             self._gb_cache[self._table_key(sgm, prec)] = (sgm, part)

@@ -58,6 +58,7 @@ class DefectGanGenerator(BaseNetwork):
                                              up_scale=False, norm_layer=None, act_layer="sigmoid")
         self._head_dim = crt_dim
         self._packed_heads = ops.PackedWeights()
+        self._packed_label_path = {}               # packed copies of the SPADE modules' concatenated first-conv filters, per group
 
     def forward(self, x, labels, style_feat=None):
         with ops.fp8_forward(self.fp8):
@@ -98,13 +99,39 @@ class DefectGanGenerator(BaseNetwork):
 
     def prime_spade(self, label_tensors):
         """Batch the SPADE class-table computation of the label sets a loss graph is about to use (see SPADE.prime)."""
-        both = seg = None
-        for m in self._table_modules():
-            if hasattr(m, "prime"):
-                if both is None and len(label_tensors) == 2 and all(t.dim() == 4 and t.shape[2:] == (1, 1) for t in label_tensors):
-                    both = torch.cat(list(label_tensors), 0)          # one concatenation and one 5x5 class image for all modules
-                    seg = ops.to_nhwc(both, self.prec, size=(5, 5))
-                m.prime(label_tensors, self.prec, both, seg)
+        mods = [m for m in self._table_modules() if hasattr(m, "prime")]
+        if not mods:
+            return
+        if len(label_tensors) != 2 or not all(t.dim() == 4 and t.shape[2:] == (1, 1) for t in label_tensors):
+            for m in mods:
+                m.prime(label_tensors, self.prec)
+            return
+        both = torch.cat(list(label_tensors), 0)          # one concatenation and one 5x5 class image for all modules
+        seg = ops.to_nhwc(both, self.prec, size=(5, 5))
+        # The first conv of every module's label path (normalization.py:17-19: label_nc -> hidden_nc, 3x3, ReLU) reads the SAME class
+        # image: the modules that will run are served by ONE conv over their concatenated filters (each output channel of a conv is a
+        # function of its own filter only), their slices of its output handed to them -- one launch instead of one per module,
+        # forward, weight gradient and bias gradient alike.
+        live = [m for m in mods if m.wants_prime(label_tensors, self.prec)]
+        shared = {}
+        convs = [m.mlp_shared[0] for m in live]
+        if len(live) > 1 and all(type(c) is type(convs[0]) and c.out_channels == convs[0].out_channels and c.bias is not None
+                                 and c.weight.shape == convs[0].weight.shape and c.effective_weight()[0] is c.weight for c in convs):
+            # (the per-channel reduction kernels take 256 channel vectors at most: 2 048 channels in bf16, 1 024 in fp32)
+            per = max(1, (256 * (8 if self.prec is ops.BF16 else 4)) // convs[0].out_channels)
+            for lo in range(0, len(live), per):
+                grp, cv = live[lo:lo + per], convs[lo:lo + per]
+                if len(grp) < 2:
+                    continue
+                w_all = torch.cat([c.weight for c in cv], 0)
+                b_all = torch.cat([c.bias for c in cv], 0)
+                geom = ops.ConvGeom(cv[0].in_channels, w_all.shape[0], cv[0].kernel_size, 1, cv[0].padding, False, False)
+                cache = self._packed_label_path.setdefault(lo, ops.PackedWeights())
+                actv = ops.conv2d(seg, w_all, b_all, cache, geom, "relu", sources=tuple(c.weight for c in cv))
+                for m, part in zip(grp, actv.split(cv[0].out_channels, dim=-1)):
+                    shared[id(m)] = part
+        for m in mods:
+            m.prime(label_tensors, self.prec, both, seg, shared.get(id(m)))
 
     def clear_spade_cache(self):
         """Drop the memoized SPADE gamma/beta tables (they carry autograd history: a table must not outlive the loss
