@@ -30,6 +30,14 @@ class EpiNormDesc(Structure):
                 ("rstd", c_void_p), ("gb", c_void_p), ("a", c_void_p), ("b", c_void_p), ("partial", c_void_p)]
 
 
+class LabelMod(Structure):
+    """struct dei2i_label_mod: one SPADE module's entry in the batched label-path launches (csrc/label_path.hip)"""
+    _fields_ = [("gamma_weight", c_void_p), ("beta_weight", c_void_p), ("gamma_bias", c_void_p), ("beta_bias", c_void_p),
+                ("packed_fwd", c_void_p), ("packed_dgrad", c_void_p), ("gb", c_void_p), ("d_gamma_weight", c_void_p),
+                ("d_beta_weight", c_void_p), ("d_gamma_bias", c_void_p), ("d_beta_bias", c_void_p), ("C", c_int), ("in_off", c_int),
+                ("live", c_int), ("reserved", c_int)]
+
+
 class AdamRec(Structure):
     """struct dei2i_adam_rec"""
     _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_int64)]
@@ -99,6 +107,11 @@ SIGNATURES = {
     "dei2i_spectral_fwd": (c_int, [c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P]),
     "dei2i_spectral_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "dei2i_fold_bn_weight": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_float, _P, _P, _P]),
+    "dei2i_label_gb_packed_elems": (c_size_t, [c_int, c_int]),
+    "dei2i_label_gb_pack": (c_int, [_P, c_int, c_int, _P]),
+    "dei2i_label_gb_fwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
+    "dei2i_label_gb_dgrad": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
+    "dei2i_label_gb_wgrad": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     "dei2i_adam_step": (c_int, [_P, c_int, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_float, _P]),
     "dei2i_sgd_rmsprop_step": (c_int, [_P, c_int, c_int64, c_int, c_float, c_float, c_float, c_float, _P]),
     "dei2i_prof_enable": (c_int, [c_int, c_int]),

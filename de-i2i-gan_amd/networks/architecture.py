@@ -406,21 +406,25 @@ class SPADE(nn.Module):
 
     def wants_prime(self, segmaps, prec):
         """Will prime() compute tables for these label tensors?  (a module that runs in class mode and does not hold them yet)"""
-        return (getattr(self, "_ran_class_mode", False) and len(segmaps) == 2
+        return (getattr(self, "_ran_class_mode", True) and len(segmaps) == 2
                 and all(s_.dim() == 4 and s_.shape[2] == 1 and s_.shape[3] == 1 for s_ in segmaps)
                 and not all(self._table_key(sgm, prec) in self._gb_cache for sgm in segmaps))
 
-    def prime(self, segmaps, prec, both=None, seg=None, actv=None):
+    def prime(self, segmaps, prec, both=None, seg=None, actv=None, gb=None):
         """Compute the class tables of several (N,C,1,1) label tensors in ONE pass over their concatenation and memoize
         each tensor's slice: the same function as one pass per tensor (the table convs act per sample), with half the
         launches of the 5x5 table path (forward and backward) when a loss graph uses two label sets."""
-        if not getattr(self, "_ran_class_mode", False):
+        # (before the generator's first forward nobody knows which modules run -- norm_s of a block without a learned shortcut never
+        #  does --: all are served then, so that the first step takes the same kernels as every later one; the generator marks the
+        #  modules its first forward did not reach)
+        if not getattr(self, "_ran_class_mode", True):
             return
         if len(segmaps) != 2 or any(s.dim() != 4 or s.shape[2] != 1 or s.shape[3] != 1 for s in segmaps):
             return
         if all(self._table_key(sgm, prec) in self._gb_cache for sgm in segmaps):
             return                                       # both tables are there already (same tensors, same parameter state)
-        gb = self._gamma_beta(both if both is not None else torch.cat(list(segmaps), 0), prec, True, 0, 0, seg=seg, actv=actv)
+        if gb is None:        # (else: prime_spade computed this module's table in the batched launch, ops.label_gamma_beta)
+            gb = self._gamma_beta(both if both is not None else torch.cat(list(segmaps), 0), prec, True, 0, 0, seg=seg, actv=actv)
         self._gb_cache.clear()
         for sgm, part in zip(segmaps, ops.split_rows(gb, [sgm.shape[0] for sgm in segmaps])):
             self._gb_cache[self._table_key(sgm, prec)] = (sgm, part)

@@ -62,7 +62,13 @@ class DefectGanGenerator(BaseNetwork):
 
     def forward(self, x, labels, style_feat=None):
         with ops.fp8_forward(self.fp8):
-            return self._forward(x, labels, style_feat)
+            out = self._forward(x, labels, style_feat)
+        if not self.__dict__.get("_marked_table_modules"):           # once: the table modules the first forward did not reach never run
+            for m in self._table_modules():
+                if "_ran_class_mode" not in m.__dict__:
+                    m._ran_class_mode = False
+            self.__dict__["_marked_table_modules"] = True
+        return out
 
     def _forward(self, x, labels, style_feat=None):
         assert isinstance(x, torch.Tensor), "x must be Original Images: Torch.Tensor"
@@ -113,7 +119,7 @@ class DefectGanGenerator(BaseNetwork):
         # function of its own filter only), their slices of its output handed to them -- one launch instead of one per module,
         # forward, weight gradient and bias gradient alike.
         live = [m for m in mods if m.wants_prime(label_tensors, self.prec)]
-        shared = {}
+        shared, ready = {}, {}
         convs = [m.mlp_shared[0] for m in live]
         if len(live) > 1 and all(type(c) is type(convs[0]) and c.out_channels == convs[0].out_channels and c.bias is not None
                                  and c.weight.shape == convs[0].weight.shape and c.effective_weight()[0] is c.weight for c in convs):
@@ -128,10 +134,17 @@ class DefectGanGenerator(BaseNetwork):
                 geom = ops.ConvGeom(cv[0].in_channels, w_all.shape[0], cv[0].kernel_size, 1, cv[0].padding, False, False)
                 cache = self._packed_label_path.setdefault(lo, ops.PackedWeights())
                 actv = ops.conv2d(seg, w_all, b_all, cache, geom, "relu", sources=tuple(c.weight for c in cv))
-                for m, part in zip(grp, actv.split(cv[0].out_channels, dim=-1)):
-                    shared[id(m)] = part
+                second = [(m.mlp_gamma, m.mlp_beta) for m in grp]
+                if ops.label_path_batched and ops.label_gamma_beta_supported(actv, cv[0].out_channels, second):
+                    # ... and the second stage (hidden -> gamma | beta, per module on its slice of actv) as one launch for the group
+                    tables = ops.label_gamma_beta(actv, cv[0].out_channels, second, self._packed_label_path.setdefault(("gb", lo), {}))
+                    for m, gb in zip(grp, tables):
+                        ready[id(m)] = gb
+                else:
+                    for m, part in zip(grp, actv.split(cv[0].out_channels, dim=-1)):
+                        shared[id(m)] = part
         for m in mods:
-            m.prime(label_tensors, self.prec, both, seg, shared.get(id(m)))
+            m.prime(label_tensors, self.prec, both, seg, shared.get(id(m)), ready.get(id(m)))
 
     def clear_spade_cache(self):
         """Drop the memoized SPADE gamma/beta tables (they carry autograd history: a table must not outlive the loss

@@ -893,6 +893,7 @@ def chain_streams(device):
 # the concatenated batch is the same function as the g passes -- with half the launches, half the per-launch tails and
 # weight-gradient reductions, and every conv at twice the tile count.  The running statistics are updated per group through
 # ``bn_running_deferred`` (pass_index = one index per group), which replays them in the reference's pass order.
+label_path_batched = True        # SPADE's gamma | beta table convs of all modules in one launch per direction (csrc/label_path.hip)
 paired_passes = True             # the G loss's four generator passes as two passes over 2 x batch (models/defectgan_model.py)
 bn_groups = 1
 
@@ -1599,6 +1600,100 @@ def instance_norm_act(x, act="none", res=None, eps=1e-5):
     """act(InstanceNorm2d(x)) (+ res) on an NHWC activation with H, W >= 4; act: "none" | "relu" | "leaky_relu" """
     slope = {"none": 1.0, "relu": 0.0, "leaky_relu": 0.2}[act or "none"]
     return _InstanceNormAct.apply(x, slope, res, float(eps))
+
+
+# ---- SPADE's label path, second stage, batched over the modules of a generator (csrc/label_path.hip) ---------------------------
+def label_gamma_beta_supported(actv, hidden: int, convs) -> bool:
+    """Can ``label_gamma_beta`` take these modules?  (bf16, <= 16 modules, hidden a multiple of 32 up to 128, every norm_nc a multiple
+    of 16, plain convs with a bias)"""
+    if not (actv.is_cuda and actv.dtype == torch.bfloat16 and actv.dim() == 4 and tuple(actv.shape[1:3]) == (5, 5)):
+        return False
+    if not (1 <= len(convs) <= 16 and hidden % 32 == 0 and 32 <= hidden <= 128 and actv.shape[-1] == hidden * len(convs)):
+        return False
+    for g, b in convs:
+        if g.bias is None or b.bias is None or g.weight.shape != b.weight.shape or tuple(g.weight.shape[1:]) != (hidden, 3, 3):
+            return False
+        if g.weight.shape[0] % 16 != 0 or g.weight.dtype != torch.float32 or getattr(g.weight, "_dei2i_per_call", False):
+            return False
+    return True
+
+
+class _LabelGammaBeta(torch.autograd.Function):
+    """(gamma | beta tables of every module) = conv3x3(actv slice; mlp_gamma | mlp_beta) + bias, all modules in one launch per direction
+    (normalization.py:20-22,33-35 on the 5 x 5 class image).  actv: (N, 5, 5, modules * hidden), module i reads channels
+    [i * hidden, (i + 1) * hidden).  params: (gamma.weight, gamma.bias, beta.weight, beta.bias) per module."""
+
+    @staticmethod
+    def forward(ctx, actv, hidden, cache, *params):
+        _require_gpu(actv, "label_gamma_beta")
+        actv = actv.contiguous()
+        n_img, _, _, ctot = actv.shape
+        nmod = len(params) // 4
+        lib, st, dev = _lib_for(actv), _stream(), actv.device
+        stamps = tuple(PackedWeights._stamp(params[4 * i + k]) for i in range(nmod) for k in (0, 2))
+        if cache.get("stamps") != stamps:               # filters moved (an optimizer step): both bf16 layouts of every module, one launch
+            cache["packed"] = [(torch.empty(lib.dei2i_label_gb_packed_elems(params[4 * i].shape[0], hidden), dtype=torch.bfloat16, device=dev),
+                                torch.empty(lib.dei2i_label_gb_packed_elems(params[4 * i].shape[0], hidden), dtype=torch.bfloat16, device=dev))
+                               for i in range(nmod)]
+            cache["stamps"] = None
+        packed = cache["packed"]
+        mods = (L.LabelMod * nmod)()
+        outs = []
+        for i in range(nmod):
+            gw, gbias, bw, bbias = (t.detach() for t in params[4 * i:4 * i + 4])
+            c = gw.shape[0]
+            gb = torch.empty((n_img, 5, 5, 2 * c), dtype=torch.bfloat16, device=dev)
+            outs.append(gb)
+            mods[i] = L.LabelMod(gw.data_ptr(), bw.data_ptr(), gbias.data_ptr(), bbias.data_ptr(), packed[i][0].data_ptr(),
+                                 packed[i][1].data_ptr(), gb.data_ptr(), None, None, None, None, c, i * hidden, 1, 0)
+        if cache["stamps"] is None:
+            L.check(lib.dei2i_label_gb_pack(mods, nmod, hidden, st), "label_gb_pack")
+            cache["stamps"] = stamps
+        L.check(lib.dei2i_label_gb_fwd(mods, nmod, hidden, ctot, n_img, _p(actv), st), "label_gb_fwd")
+        ctx.hidden, ctx.packed, ctx.nmod = hidden, packed, nmod
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(actv, *params)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dgbs):
+        actv, *params = ctx.saved_tensors
+        hidden, nmod = ctx.hidden, ctx.nmod
+        n_img, _, _, ctot = actv.shape
+        lib, st, dev = _lib_for(actv), _stream(), actv.device
+        mods = (L.LabelMod * nmod)()
+        grads, keep = [], []
+        for i in range(nmod):
+            c = params[4 * i].shape[0]
+            g = dgbs[i]
+            if g is not None:
+                g = g.contiguous()
+                if g.dtype != torch.bfloat16 or tuple(g.shape) != (n_img, 5, 5, 2 * c):
+                    raise RuntimeError("label_gamma_beta: the table gradient does not match the table")
+                keep.append(g)
+            dgw, dbw = torch.empty_like(params[4 * i]), torch.empty_like(params[4 * i + 2])
+            dgbias, dbbias = torch.empty_like(params[4 * i + 1]), torch.empty_like(params[4 * i + 3])
+            grads += [dgw, dgbias, dbw, dbbias]
+            mods[i] = L.LabelMod(None, None, None, None, ctx.packed[i][0].data_ptr(), ctx.packed[i][1].data_ptr(),
+                                 g.data_ptr() if g is not None else None, dgw.data_ptr(), dbw.data_ptr(), dgbias.data_ptr(), dbbias.data_ptr(),
+                                 c, i * hidden, 1 if g is not None else 0, 0)
+        dactv = None
+        if ctx.needs_input_grad[0]:
+            dactv = torch.empty_like(actv)
+            L.check(lib.dei2i_label_gb_dgrad(mods, nmod, hidden, ctot, n_img, _p(dactv), st), "label_gb_dgrad")
+        L.check(lib.dei2i_label_gb_wgrad(mods, nmod, hidden, ctot, n_img, _p(actv), st), "label_gb_wgrad")
+        # (a module whose table got no gradient -- it did not run in this loss graph -- hands None to its filters, like the unfused graph)
+        return (dactv, None, None) + tuple(gr if (ctx.needs_input_grad[3 + k] and dgbs[k // 4] is not None) else None
+                                           for k, gr in enumerate(grads))
+
+
+def label_gamma_beta(actv, hidden: int, convs, cache: dict):
+    """-> [(N, 5, 5, 2 * norm_nc) gamma | beta table per module]; ``convs``: (mlp_gamma, mlp_beta) conv modules per SPADE module, in the
+    order of their channel slices in ``actv``; ``cache``: a dict the caller keeps (the packed filters live there between steps)."""
+    params = []
+    for g, b in convs:
+        params += [g.weight, g.bias, b.weight, b.bias]
+    return list(_LabelGammaBeta.apply(actv, int(hidden), cache, *params))
 
 
 class _SplitRows(torch.autograd.Function):

@@ -239,6 +239,38 @@ int dei2i_spectral_bwd(int Cout, int K, const float* G, const float* w_eff, cons
 int dei2i_fold_bn_weight(int Cout, int K, const float* W, const float* bn_weight, const float* bn_bias, const float* running_mean,
                          const float* running_var, float eps, float* w_eff, float* b_eff, dei2i_stream s);
 
+/* ---- SPADE's label path, second stage, for all modules of a generator at once (csrc/label_path.hip) ----
+ * normalization.py:17-37 with a constant label map (the 5 x 5 class image of networks/architecture.py SPADE): gamma | beta =
+ * conv3x3(actv; mlp_gamma | mlp_beta) + bias per module, every module reading `hidden` channels at its offset `in_off` of ONE activation
+ * tensor actv (N, 5, 5, ctot) bf16 (the modules' mlp_shared convs run as one conv over their concatenated filters).  bf16 only.
+ * One table entry per module (<= 16); C = norm_nc (multiple of 16), hidden in {32, 64, 96, 128}.
+ *   pack : gamma_weight / beta_weight (C, hidden, 3, 3 fp32) -> packed_fwd, packed_dgrad (dei2i_label_gb_packed_elems(C, hidden) bf16 each)
+ *   fwd  : gb (N, 5, 5, 2C) bf16 = [gamma | beta]
+ *   dgrad: dactv (N, 5, 5, ctot) bf16, the module's channel slice written from gb = dL/d(gb) (zeros when live == 0)
+ *   wgrad: d_gamma_weight / d_beta_weight (C, hidden, 3, 3 fp32), d_gamma_bias / d_beta_bias (C) written in full, from gb = dL/d(gb) */
+typedef struct dei2i_label_mod {
+  const float* gamma_weight;
+  const float* beta_weight;
+  const float* gamma_bias;
+  const float* beta_bias;
+  void* packed_fwd;
+  void* packed_dgrad;
+  void* gb;
+  float* d_gamma_weight;
+  float* d_beta_weight;
+  float* d_gamma_bias;
+  float* d_beta_bias;
+  int C;
+  int in_off;
+  int live;
+  int reserved;
+} dei2i_label_mod;
+size_t dei2i_label_gb_packed_elems(int C, int hidden);
+int dei2i_label_gb_pack(const dei2i_label_mod* mods, int n, int hidden, dei2i_stream s);
+int dei2i_label_gb_fwd(const dei2i_label_mod* mods, int n, int hidden, int ctot, int N, const void* actv, dei2i_stream s);
+int dei2i_label_gb_dgrad(const dei2i_label_mod* mods, int n, int hidden, int ctot, int N, void* dactv, dei2i_stream s);
+int dei2i_label_gb_wgrad(const dei2i_label_mod* mods, int n, int hidden, int ctot, int N, const void* actv, dei2i_stream s);
+
 /* ---- in-library kernel timing (bench.py roofline leg): HIP events around every launch of one kernel family ---- */
 #define DEI2I_PROF_GATHER_GEMM 0  /* the other conv forward / dgrad kernels: gather GEMM v1 / v2, thin convs */
 #define DEI2I_PROF_WGRAD 1

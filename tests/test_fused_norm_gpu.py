@@ -685,3 +685,53 @@ def test_batchnorm_per_group_of_the_batch_equals_one_call_per_group(pname, C, H,
     assert torch.equal(g_[4], s_[4]) and torch.equal(g_[5], s_[5]) and g_[6] == s_[6] == 2
     if epilogue:
         assert g_[7] == 1 and s_[7] == 2                 # one dgrad launch took both groups' reductions
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,hidden,Cs,dead", [(64, 128, [256, 256, 128, 64], False), (5, 64, [32, 16, 48], True), (3, 32, [16], False)])
+def test_label_path_batched_equals_the_per_module_convs(N, hidden, Cs, dead):
+    """ops.label_gamma_beta (csrc/label_path.hip): the gamma | beta table convs of several SPADE modules (normalization.py:20-22,33-35 on
+    the 5 x 5 class image), each on its channel slice of one activation tensor, in one launch per direction -- against one generic conv
+    per module (SPADE._gamma_beta's form): the same bf16 operands with fp32 accumulation in another order.  ``dead``: the last module's
+    table gets no gradient (a module whose table a loss graph does not use): its filters get no gradient, its slice of the activation
+    gradient is zero."""
+    from de_i2i_gan_amd import ops
+    from de_i2i_gan_amd.networks.architecture import Conv2d
+    torch.manual_seed(3)
+    nm = len(Cs)
+    actv0 = torch.relu(torch.randn(N, 5, 5, nm * hidden)).bfloat16().to(DEV)
+    convs = [(Conv2d(hidden, C, 3, padding="same").to(DEV), Conv2d(hidden, C, 3, padding="same").to(DEV)) for C in Cs]
+    gys = [torch.randn(N, 5, 5, 2 * C, device=DEV).bfloat16() for C in Cs]
+    live = nm - 1 if dead else nm
+    assert ops.label_gamma_beta_supported(actv0, hidden, convs)
+    params = [p for g, b in convs for p in (g.weight, g.bias, b.weight, b.bias)]
+
+    a = actv0.clone().requires_grad_(True)
+    cache = {}
+    tabs = ops.label_gamma_beta(a, hidden, convs, cache)
+    torch.autograd.backward(tabs[:live], gys[:live])
+    got_tabs, got_da = [t.detach().clone() for t in tabs], a.grad.clone()
+    got_p = [p.grad.clone() if p.grad is not None else None for p in params]
+    for p in params:
+        p.grad = None
+    again = ops.label_gamma_beta(actv0, hidden, convs, cache)            # the packed filters are reused (same stamps): same bits
+    assert all(torch.equal(x, y) for x, y in zip(again, got_tabs))
+
+    a2 = actv0.clone().requires_grad_(True)
+    refs = []
+    for i, ((g, b), C) in enumerate(zip(convs, Cs)):
+        geom = ops.ConvGeom(hidden, 2 * C, 3, 1, 1, False, False)
+        refs.append(ops.conv2d(a2[..., i * hidden:(i + 1) * hidden], torch.cat([g.weight, b.weight], 0), torch.cat([g.bias, b.bias], 0),
+                               ops.PackedWeights(), geom, "none", sources=(g.weight, b.weight)))
+    torch.autograd.backward(refs[:live], gys[:live])
+    torch.cuda.synchronize()
+    for i in range(nm):
+        assert rel_l2(got_tabs[i], refs[i]) < 3e-3 and maxrel(got_tabs[i], refs[i]) < 2e-2, (i, rel_l2(got_tabs[i], refs[i]))
+    assert rel_l2(got_da, a2.grad) < 4e-3, rel_l2(got_da, a2.grad)
+    if dead:
+        assert float(got_da[..., (nm - 1) * hidden:].abs().max()) == 0.0
+    for k, p in enumerate(params):
+        if p.grad is None:                           # the dead module's filters: no gradient in either form
+            assert k // 4 == nm - 1 and got_p[k] is None
+        else:
+            assert rel_l2(got_p[k], p.grad) < (2e-4 if p.dim() == 4 else 1e-5), (k, rel_l2(got_p[k], p.grad))
