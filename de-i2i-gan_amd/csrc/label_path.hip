@@ -91,147 +91,175 @@ __global__ __launch_bounds__(256) void label_gb_pack_kernel(const LabelPack pk) 
   }
 }
 
-// ---- forward: workgroup = (module, 64 output channels) x (2 samples); wave = 16 output channels x 2 samples x 2 pixel blocks ----
+// LDS image of the class images of LP_IMG samples WITH their zero ring (7 x 7 pixels each): pixel pitch LP_PITCH bytes (128 channels + 16:
+// a 16-pixel fragment read at any tap shift spreads over the banks)
+constexpr int LP_IMG = 4;
+constexpr int LP_PITCH = 128 * 2 + 16;
+constexpr int LP_RING = 49;
+
+// stage `nch` channels (multiple of 8, <= 128) starting at `src + c0` (pixel stride `cstride` elements) of samples n0 .. n0 + LP_IMG - 1
+template <int DUMMY = 0>
+DEI2I_D void lp_stage_ring(unsigned char* lds, const bf16_t* src, size_t cstride, int c0, int nch, int n0, int N, int tid) {
+  const int vpp = nch / 8;                               // vectors per pixel
+  const int total = LP_IMG * LP_RING * vpp;
+  for (int v0 = tid; v0 < total; v0 += 4 * 256) {        // four loads in flight per thread
+    u32x4 val[4];
+    int dst[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int v = v0 + u * 256;
+      val[u] = u32x4{0u, 0u, 0u, 0u};
+      dst[u] = -1;
+      if (v < total) {
+        const int pix = v / vpp, c = v - pix * vpp;
+        const int i = pix / LP_RING, r = pix - i * LP_RING;
+        const int ry = r / 7, rx = r - ry * 7;
+        dst[u] = pix * LP_PITCH + c * 16;
+        if (n0 + i < N && ry >= 1 && ry <= 5 && rx >= 1 && rx <= 5)
+          val[u] = lp_ld16(src + ((size_t)(n0 + i) * LP_PIX + (ry - 1) * 5 + (rx - 1)) * cstride + c0 + c * 8);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (dst[u] >= 0) *reinterpret_cast<u32x4*>(lds + dst[u]) = val[u];
+  }
+}
+
+// ---- forward: workgroup = (module, 128 output channels) x LP_IMG samples; wave = 32 output channels x LP_IMG samples x 2 pixel blocks ----
 __global__ __launch_bounds__(256) void label_gb_fwd_kernel(const LabelPack pk, const bf16_t* __restrict__ actv) {
+  __shared__ __attribute__((aligned(16))) unsigned char img[LP_IMG * LP_RING * LP_PITCH];
   const int m = lp_module_of(pk, blockIdx.x);
   const LabelMod& md = pk.m[m];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, kg = lane >> 4;
   const int C2 = 2 * md.C, H = pk.hidden;
-  const int co0 = (blockIdx.x - md.blk0) * 64 + wave * 16;
-  if (co0 >= C2) return;                               // wave-uniform
-  const int n0 = blockIdx.y * 2;
-  f32x4 acc[2][2];
+  const int co0 = (blockIdx.x - md.blk0) * 128 + wave * 32;
+  const int n0 = blockIdx.y * LP_IMG;
+  lp_stage_ring(img, actv, (size_t)pk.ctot, md.in_off, H, n0, pk.N, tid);
+  __syncthreads();
+  if (co0 >= C2) return;                               // wave-uniform (after the barrier)
+  f32x4 acc[2][LP_IMG][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc[i][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bf16_t* wrow = md.wf + (size_t)(co0 + l16) * 9 * H + kg * 8;
-  const bool wlive = co0 + l16 < C2;
-  int py[2], px[2];
+    for (int i = 0; i < LP_IMG; ++i)
 #pragma unroll
-  for (int b = 0; b < 2; ++b) { const int p = b * 16 + l16; py[b] = p / 5; px[b] = p - py[b] * 5; }
+      for (int b = 0; b < 2; ++b) acc[j][i][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int rpix[2];                                         // ring-image pixel of this lane's output pixel (pixels 25..31: pixel 24, never stored)
+#pragma unroll
+  for (int b = 0; b < 2; ++b) { const int p = min(b * 16 + l16, LP_PIX - 1); rpix[b] = (p / 5 + 1) * 7 + (p % 5) + 1; }
+  const bf16_t* wrow[2];
+  bool wlive[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { wlive[j] = co0 + j * 16 + l16 < C2; wrow[j] = md.wf + (size_t)(co0 + j * 16 + (wlive[j] ? l16 : 0)) * 9 * H + kg * 8; }
 #pragma unroll 1
   for (int tap = 0; tap < 9; ++tap) {
-    const int ty = tap / 3 - 1, tx = tap - (tap / 3) * 3 - 1;
-    int spix[2];
+    const int toff = (tap / 3 - 1) * 7 + (tap - (tap / 3) * 3 - 1);
+    u32x4 a[4][2];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int sy = py[b] + ty, sx = px[b] + tx;
-      spix[b] = (b * 16 + l16 < LP_PIX && sy >= 0 && sy < 5 && sx >= 0 && sx < 5) ? sy * 5 + sx : -1;
-    }
-    // every load of the tap first (<= 4 filter + 16 activation vectors in flight: the kernel is a chain of L2 round trips), then the MFMAs
-    u32x4 a[4], v[4][2][2];
+    for (int k = 0; k < 4; ++k)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      a[k] = u32x4{0u, 0u, 0u, 0u};
-      if (wlive && k * 32 < H) a[k] = lp_ld16(wrow + (size_t)tap * H + k * 32);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          v[k][i][b] = u32x4{0u, 0u, 0u, 0u};
-          if (k * 32 < H && n0 + i < pk.N && spix[b] >= 0)
-            v[k][i][b] = lp_ld16(actv + ((size_t)(n0 + i) * LP_PIX + spix[b]) * pk.ctot + md.in_off + k * 32 + kg * 8);
-        }
-    }
+      for (int j = 0; j < 2; ++j) {
+        a[k][j] = u32x4{0u, 0u, 0u, 0u};
+        if (k * 32 < H && wlive[j]) a[k][j] = lp_ld16(wrow[j] + (size_t)tap * H + k * 32);
+      }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (k * 32 < H) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < LP_IMG; ++i)
 #pragma unroll
-          for (int b = 0; b < 2; ++b)
-            acc[i][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[k]), __builtin_bit_cast(bf16x8, v[k][i][b]), acc[i][b], 0, 0, 0);
+          for (int b = 0; b < 2; ++b) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(img + (i * LP_RING + rpix[b] + toff) * LP_PITCH + k * 64 + kg * 16);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[j][i][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[k][j]), __builtin_bit_cast(bf16x8, v), acc[j][i][b], 0, 0, 0);
+          }
       }
     }
   }
-  // D: lane (pixel = l16, kg) holds output channels co0 + 4 kg .. + 3 of its pixel
-  const int co = co0 + 4 * kg;
-  if (co >= C2) return;
-  float bias[4];
+  // D: lane (pixel = l16, kg) holds output channels 4 kg .. + 3 of its 16-channel block
 #pragma unroll
-  for (int e = 0; e < 4; ++e) bias[e] = co + e < md.C ? md.gbias[co + e] : md.bbias[co + e - md.C];
+  for (int j = 0; j < 2; ++j) {
+    const int co = co0 + j * 16 + 4 * kg;
+    if (co >= C2) continue;
+    float bias[4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int n = n0 + i;
-    if (n >= pk.N) continue;
+    for (int e = 0; e < 4; ++e) bias[e] = co + e < md.C ? md.gbias[co + e] : md.bbias[co + e - md.C];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int p = b * 16 + l16;
-      if (p >= LP_PIX) continue;
-      u32x2 o;
-      o.x = (uint32_t)f32_to_bf16(acc[i][b][0] + bias[0]) | ((uint32_t)f32_to_bf16(acc[i][b][1] + bias[1]) << 16);
-      o.y = (uint32_t)f32_to_bf16(acc[i][b][2] + bias[2]) | ((uint32_t)f32_to_bf16(acc[i][b][3] + bias[3]) << 16);
-      *reinterpret_cast<u32x2*>(md.gb + ((size_t)n * LP_PIX + p) * C2 + co) = o;
+    for (int i = 0; i < LP_IMG; ++i) {
+      const int n = n0 + i;
+      if (n >= pk.N) continue;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int p = b * 16 + l16;
+        if (p >= LP_PIX) continue;
+        u32x2 o;
+        o.x = (uint32_t)f32_to_bf16(acc[j][i][b][0] + bias[0]) | ((uint32_t)f32_to_bf16(acc[j][i][b][1] + bias[1]) << 16);
+        o.y = (uint32_t)f32_to_bf16(acc[j][i][b][2] + bias[2]) | ((uint32_t)f32_to_bf16(acc[j][i][b][3] + bias[3]) << 16);
+        *reinterpret_cast<u32x2*>(md.gb + ((size_t)n * LP_PIX + p) * C2 + co) = o;
+      }
     }
   }
 }
 
-// ---- input gradient: workgroup = (module, 64 activation channels) x (2 samples) ------------------------------------------------
+// ---- input gradient: workgroup = (module, 64 activation channels) x LP_IMG samples; wave = 16 channels; dgb staged 128 channels at a time ----
 __global__ __launch_bounds__(256) void label_gb_dgrad_kernel(const LabelPack pk, bf16_t* __restrict__ dactv) {
+  __shared__ __attribute__((aligned(16))) unsigned char img[LP_IMG * LP_RING * LP_PITCH];
   const int m = lp_module_of(pk, blockIdx.x);
   const LabelMod& md = pk.m[m];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, kg = lane >> 4;
   const int C2 = 2 * md.C, H = pk.hidden;
   const int ci0 = (blockIdx.x - md.blk0) * 64 + wave * 16;
-  if (ci0 >= H) return;
-  const int n0 = blockIdx.y * 2;
-  f32x4 acc[2][2];
+  const int n0 = blockIdx.y * LP_IMG;
+  const bool wave_live = ci0 < H;
+  f32x4 acc[LP_IMG][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < LP_IMG; ++i)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[i][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (md.live) {
-    const bf16_t* wrow = md.wd + (size_t)(ci0 + l16) * 9 * C2 + kg * 8;
+  if (md.live) {                                       // workgroup-uniform
+    int rpix[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) { const int q = min(b * 16 + l16, LP_PIX - 1); rpix[b] = (q / 5 + 1) * 7 + (q % 5) + 1; }
     const bool wlive = ci0 + l16 < H;
-    int qy[2], qx[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) { const int q = b * 16 + l16; qy[b] = q / 5; qx[b] = q - qy[b] * 5; }
+    const bf16_t* wrow = md.wd + (size_t)(ci0 + (wlive ? l16 : 0)) * 9 * C2 + kg * 8;
 #pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
-      const int ty = tap / 3 - 1, tx = tap - (tap / 3) * 3 - 1;
-      int spix[2];
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {                      // gb[p] took actv[p + t]: actv[q] fed gb[q - t]
-        const int sy = qy[b] - ty, sx = qx[b] - tx;
-        spix[b] = (b * 16 + l16 < LP_PIX && sy >= 0 && sy < 5 && sx >= 0 && sx < 5) ? sy * 5 + sx : -1;
-      }
+    for (int kc = 0; kc < C2; kc += 128) {
+      const int nch = min(128, C2 - kc);
+      __syncthreads();                                 // the previous chunk's reads are done
+      lp_stage_ring(img, md.gb, (size_t)C2, kc, nch, n0, pk.N, tid);
+      __syncthreads();
+      if (!wave_live) continue;
 #pragma unroll 1
-      for (int kc = 0; kc < C2; kc += 128) {             // four k-blocks per trip: their loads first, then the MFMAs
-        u32x4 a[4], v[4][2][2];
+      for (int tap = 0; tap < 9; ++tap) {              // gb[p] took actv[p + t]: actv[q] fed gb[q - t]
+        const int toff = -((tap / 3 - 1) * 7 + (tap - (tap / 3) * 3 - 1));
+        u32x4 a[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const int kb = kc + k * 32;
           a[k] = u32x4{0u, 0u, 0u, 0u};
-          if (wlive && kb < C2) a[k] = lp_ld16(wrow + (size_t)tap * C2 + kb);
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-              v[k][i][b] = u32x4{0u, 0u, 0u, 0u};
-              if (kb < C2 && n0 + i < pk.N && spix[b] >= 0)
-                v[k][i][b] = lp_ld16(md.gb + ((size_t)(n0 + i) * LP_PIX + spix[b]) * C2 + kb + kg * 8);
-            }
+          if (k * 32 < nch && wlive) a[k] = lp_ld16(wrow + (size_t)tap * C2 + kc + k * 32);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          if (kc + k * 32 < C2) {
+          if (k * 32 < nch) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < LP_IMG; ++i)
 #pragma unroll
-              for (int b = 0; b < 2; ++b)
-                acc[i][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[k]), __builtin_bit_cast(bf16x8, v[k][i][b]), acc[i][b], 0, 0, 0);
+              for (int b = 0; b < 2; ++b) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(img + (i * LP_RING + rpix[b] + toff) * LP_PITCH + k * 64 + kg * 16);
+                acc[i][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[k]), __builtin_bit_cast(bf16x8, v), acc[i][b], 0, 0, 0);
+              }
           }
         }
       }
     }
   }
   const int ci = ci0 + 4 * kg;
-  if (ci >= H) return;
+  if (!wave_live || ci >= H) return;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < LP_IMG; ++i) {
     const int n = n0 + i;
     if (n >= pk.N) continue;
 #pragma unroll
@@ -249,8 +277,10 @@ __global__ __launch_bounds__(256) void label_gb_dgrad_kernel(const LabelPack pk,
 // ---- weight + bias gradient: workgroup = (module, tap, 128 output channels); wave = 32 output channels x all hidden channels --------
 // Per stage LP_G samples: the dgb tile [LP_G x 32 pixels][128 co] and the tap-shifted activation tile [LP_G x 32 pixels][hidden] in LDS
 // (pixels 25..31 of a sample and out-of-image sources are zeros), then 2 LP_G reduction blocks of 16 pixels, fragments read transposed.
+// The next stage's vectors are requested before the current stage is reduced (they wait in registers).
 constexpr int LP_G = 3;          // (2 x 3 x 32 rows x 272 B = 51 KB of static LDS)
 constexpr int LP_ROWB = 128 * 2 + 16;    // row pitch in bytes (+16: rows 4 apart land in different banks for the transposed reads)
+constexpr int LP_VPT = LP_G * 32 * 32 / 256;             // staged vectors per thread at hidden = 128
 
 __global__ __launch_bounds__(256) void label_gb_wgrad_kernel(const LabelPack pk, const bf16_t* __restrict__ actv) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * LP_G * 32 * LP_ROWB];
@@ -270,7 +300,6 @@ __global__ __launch_bounds__(256) void label_gb_wgrad_kernel(const LabelPack pk,
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-  float bsum = 0.f;                                     // tap 4 (no shift), thread t < 128: column sum of dgb channel cob + t
   const int lr = lane & 31, lh = lane >> 5;
   const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_half = (lane >> 4) & 1;
   auto tr_read = [&](const unsigned char* base, int o0, int o1) {
@@ -282,41 +311,55 @@ __global__ __launch_bounds__(256) void label_gb_wgrad_kernel(const LabelPack pk,
     return r;
   };
   const int a_colb = (wave * 32 + 16 * tr_half + 4 * tr_p) * 2;
-#pragma unroll 1
-  for (int n0 = 0; n0 < pk.N; n0 += LP_G) {
-    // stage: 16-byte vectors, (LP_G * 32 rows) x (16 + H / 8) per row; a thread's <= 12 loads go out together, then its LDS stores
-    const int va = 16, vb = H / 8, nvec = LP_G * 32 * (va + vb);
-    constexpr int LP_VPT = LP_G * 32 * 32 / 256;         // vectors per thread at hidden = 128
-    u32x4 val[LP_VPT];
-    int dst[LP_VPT];
+  // the staging roles of this thread: vector v = tid + 256 u -> (row, column); fixed for the launch, only the sample changes
+  const int va = 16, vb = H / 8, nvec = LP_G * 32 * (va + vb);
+  int dst[LP_VPT], soff[LP_VPT], simg[LP_VPT];          // LDS byte offset (-1: none), source element offset within a sample (-1: zeros), sample
 #pragma unroll
-    for (int u = 0; u < LP_VPT; ++u) {
-      const int v = tid + u * 256;
-      val[u] = u32x4{0u, 0u, 0u, 0u};
-      dst[u] = -1;
-      if (v < nvec) {
-        const int row = v / (va + vb), c = v - row * (va + vb);
-        const int i = row / 32, p = row - i * 32, n = n0 + i;
-        if (c < va) {
-          const int co = cob + c * 8;
-          dst[u] = row * LP_ROWB + c * 16;
-          if (md.live && n < pk.N && p < LP_PIX && co < C2) val[u] = lp_ld16(md.gb + ((size_t)n * LP_PIX + p) * C2 + co);
-        } else {
-          const int cc = c - va;
-          const int py = p / 5, px = p - py * 5, sy = py + ty, sx = px + tx;
-          dst[u] = LP_G * 32 * LP_ROWB + row * LP_ROWB + cc * 16;           // (sb follows sa)
-          if (n < pk.N && p < LP_PIX && sy >= 0 && sy < 5 && sx >= 0 && sx < 5)
-            val[u] = lp_ld16(actv + ((size_t)n * LP_PIX + sy * 5 + sx) * pk.ctot + md.in_off + cc * 8);
-        }
+  for (int u = 0; u < LP_VPT; ++u) {
+    const int v = tid + u * 256;
+    dst[u] = soff[u] = -1;
+    simg[u] = 0;
+    if (v < nvec) {
+      const int row = v / (va + vb), c = v - row * (va + vb);
+      const int i = row / 32, p = row - i * 32;
+      simg[u] = i;
+      if (c < va) {
+        dst[u] = row * LP_ROWB + c * 16;
+        if (md.live && p < LP_PIX && cob + c * 8 < C2) soff[u] = p * C2 + cob + c * 8;
+      } else {
+        const int cc = c - va, py = p / 5, px = p - py * 5, sy = py + ty, sx = px + tx;
+        dst[u] = LP_G * 32 * LP_ROWB + row * LP_ROWB + cc * 16;
+        if (p < LP_PIX && sy >= 0 && sy < 5 && sx >= 0 && sx < 5) soff[u] = (sy * 5 + sx) * pk.ctot + md.in_off + cc * 8;
+        simg[u] |= 0x100;                               // (flag: the activation tile)
       }
     }
+  }
+  u32x4 val[LP_VPT];
+  auto request = [&](int n0) {
+#pragma unroll
+    for (int u = 0; u < LP_VPT; ++u) {
+      val[u] = u32x4{0u, 0u, 0u, 0u};
+      const int n = n0 + (simg[u] & 0xff);
+      if (soff[u] >= 0 && n < pk.N)
+        val[u] = (simg[u] & 0x100) ? lp_ld16(actv + (size_t)n * LP_PIX * pk.ctot + soff[u]) : lp_ld16(md.gb + (size_t)n * LP_PIX * C2 + soff[u]);
+    }
+  };
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};                   // tap 4 (no shift): column sums of dgb -- thread t sums channel cob + (t & 127), rows t >> 7 mod 2
+  request(0);
+#pragma unroll 1
+  for (int n0 = 0; n0 < pk.N; n0 += LP_G) {
 #pragma unroll
     for (int u = 0; u < LP_VPT; ++u)
       if (dst[u] >= 0) *reinterpret_cast<u32x4*>(smem + dst[u]) = val[u];
     __syncthreads();
-    if (tap == 4 && tid < 128) {
-      const bf16_t* col = reinterpret_cast<const bf16_t*>(sa) + tid;
-      for (int row = 0; row < LP_G * 32; ++row) bsum += bf16_to_f32(col[row * (LP_ROWB / 2)]);
+    if (n0 + LP_G < pk.N) request(n0 + LP_G);            // in flight under this stage's reduction
+    if (tap == 4) {
+      const bf16_t* col = reinterpret_cast<const bf16_t*>(sa) + (tid & 127);
+#pragma unroll 4
+      for (int row = tid >> 7; row < LP_G * 32; row += 8) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bs[e] += bf16_to_f32(col[(row + 2 * e) * (LP_ROWB / 2)]);
+      }
     }
     if (cob + wave * 32 < C2) {                         // wave-uniform
 #pragma unroll 1
@@ -348,15 +391,21 @@ __global__ __launch_bounds__(256) void label_gb_wgrad_kernel(const LabelPack pk,
         for (int r = 0; r < 4; ++r) {
           const int co = co_w + 8 * q + 4 * lh + r;
           if (co >= C2) continue;
-          float* dst = co < C ? md.dgw + ((size_t)co * H + ci) * 9 + tap : md.dbw + ((size_t)(co - C) * H + ci) * 9 + tap;
-          *dst = acc[j][4 * q + r];
+          float* dstp = co < C ? md.dgw + ((size_t)co * H + ci) * 9 + tap : md.dbw + ((size_t)(co - C) * H + ci) * 9 + tap;
+          *dstp = acc[j][4 * q + r];
         }
     }
   }
-  if (tap == 4 && tid < 128) {
-    const int co = cob + tid;
-    if (co < C) md.dgbias[co] = bsum;
-    else if (co < C2) md.dbbias[co - C] = bsum;
+  if (tap == 4) {                                       // the two row halves of a channel meet through LDS (all reductions are done)
+    float* red = reinterpret_cast<float*>(smem);
+    red[tid] = (bs[0] + bs[1]) + (bs[2] + bs[3]);
+    __syncthreads();
+    if (tid < 128) {
+      const float sum = red[tid] + red[tid + 128];
+      const int co = cob + tid;
+      if (co < C) md.dgbias[co] = sum;
+      else if (co < C2) md.dbbias[co - C] = sum;
+    }
   }
 }
 
@@ -405,11 +454,11 @@ int dei2i_label_gb_pack(const dei2i_label_mod* mods, int n, int hidden, dei2i_st
 int dei2i_label_gb_fwd(const dei2i_label_mod* mods, int n, int hidden, int ctot, int N, const void* actv, dei2i_stream s) {
   LabelPack pk;
   int blocks;
-  if (!actv || !lp_build(mods, n, hidden, ctot, N, [](const dei2i_label_mod& md, int) { return (2 * md.C + 63) / 64; }, pk, blocks))
+  if (!actv || !lp_build(mods, n, hidden, ctot, N, [](const dei2i_label_mod& md, int) { return (2 * md.C + 127) / 128; }, pk, blocks))
     return DEI2I_ERR_BAD_ARG;
   for (int i = 0; i < n; ++i)
     if (!mods[i].packed_fwd || !mods[i].gamma_bias || !mods[i].beta_bias || !mods[i].gb) return DEI2I_ERR_BAD_ARG;
-  hipLaunchKernelGGL(label_gb_fwd_kernel, dim3(blocks, (N + 1) / 2), dim3(256), 0, (hipStream_t)s, pk, (const bf16_t*)actv);
+  hipLaunchKernelGGL(label_gb_fwd_kernel, dim3(blocks, (N + LP_IMG - 1) / LP_IMG), dim3(256), 0, (hipStream_t)s, pk, (const bf16_t*)actv);
   return (int)hipGetLastError();
 }
 
@@ -419,7 +468,7 @@ int dei2i_label_gb_dgrad(const dei2i_label_mod* mods, int n, int hidden, int cto
   if (!dactv || !lp_build(mods, n, hidden, ctot, N, [](const dei2i_label_mod&, int h) { return (h + 63) / 64; }, pk, blocks)) return DEI2I_ERR_BAD_ARG;
   for (int i = 0; i < n; ++i)
     if (mods[i].live && (!mods[i].packed_dgrad || !mods[i].gb)) return DEI2I_ERR_BAD_ARG;
-  hipLaunchKernelGGL(label_gb_dgrad_kernel, dim3(blocks, (N + 1) / 2), dim3(256), 0, (hipStream_t)s, pk, (bf16_t*)dactv);
+  hipLaunchKernelGGL(label_gb_dgrad_kernel, dim3(blocks, (N + LP_IMG - 1) / LP_IMG), dim3(256), 0, (hipStream_t)s, pk, (bf16_t*)dactv);
   return (int)hipGetLastError();
 }
 
