@@ -107,6 +107,11 @@ SIGNATURES = {
     "dei2i_spectral_fwd": (c_int, [c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P]),
     "dei2i_spectral_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "dei2i_fold_bn_weight": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_float, _P, _P, _P]),
+    "dei2i_bn_finalize_train_groups": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_float, c_float, _P, _P, _P, _P, _P]),
+    "dei2i_affine_act_groups_fwd": (c_int, [c_int, c_int, c_size_t, c_int, _P, _P, _P, _P, c_int, _P, _P, c_float, _P]),
+    "dei2i_affine_act_stats_groups_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P, _P]),
+    "dei2i_bn_bwd_partial_groups": (c_int, [c_int, c_int, c_size_t, c_int, _P, _P, _P, _P, _P, _P, c_int, _P, _P]),
+    "dei2i_bn_bwd_apply_groups": (c_int, [c_int, c_int, c_size_t, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_int, _P, _P, _P, c_int, _P, _P]),
     "dei2i_label_gb_packed_elems": (c_size_t, [c_int, c_int]),
     "dei2i_label_gb_pack": (c_int, [_P, c_int, c_int, _P]),
     "dei2i_label_gb_fwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),

@@ -56,6 +56,13 @@ __global__ void affine_act_kernel(const T* __restrict__ x, const float* __restri
                                   const T* __restrict__ res, T* __restrict__ out, size_t nvec, int cv, int act,
                                   unsigned char* __restrict__ out8, float scale8) {
   constexpr int VEC = Elem<T>::VEC;
+  {                                                    // blockIdx.y: a group of the batch (nvec vectors, its own row of coefficients)
+    const size_t grp = blockIdx.y;
+    x += grp * nvec * VEC; out += grp * nvec * VEC;
+    if (res != nullptr) res += grp * nvec * VEC;
+    a += grp * (size_t)cv * VEC; b += grp * (size_t)cv * VEC;
+    if (out8 != nullptr) out8 += grp * nvec * 8;
+  }
   float av[VEC], bv[VEC];
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (INVARIANT) {
@@ -361,6 +368,28 @@ int dei2i_affine_act_fwd(int dtype, size_t pixels, int C, const void* x, const f
   } else {
     if (inv) hipLaunchKernelGGL((affine_act_kernel<float, true>), dim3(grid), dim3(256), 0, st, (const float*)x, a, b, (const float*)res, (float*)out, nvec, cv, act, o8, e4m3_scale);
     else hipLaunchKernelGGL((affine_act_kernel<float, false>), dim3(grid), dim3(256), 0, st, (const float*)x, a, b, (const float*)res, (float*)out, nvec, cv, act, o8, e4m3_scale);
+  }
+  return (int)hipGetLastError();
+}
+
+/* `groups` groups of `pixels` pixels each, coefficient rows a, b: (groups, C) -- one launch (grid.y = group) */
+int dei2i_affine_act_groups_fwd(int dtype, int groups, size_t pixels, int C, const void* x, const float* a, const float* b, const void* res,
+                                int act, void* out, void* out_e4m3, float e4m3_scale, dei2i_stream s) {
+  const int vec = vec_of(dtype);
+  if (groups <= 0 || pixels == 0 || C <= 0 || C % vec || !x || !a || !b || !out) return DEI2I_ERR_BAD_ARG;
+  if (out_e4m3 != nullptr && (dtype != DT_BF16 || !(e4m3_scale > 0.f))) return DEI2I_ERR_BAD_ARG;
+  unsigned char* o8 = (unsigned char*)out_e4m3;
+  const size_t nvec = pixels * (size_t)(C / vec);
+  const int cv = C / vec;
+  const bool inv = (256 % cv) == 0;
+  const unsigned grid = grid_for(nvec, 256, EW_CAP);
+  hipStream_t st = (hipStream_t)s;
+  if (dtype == DT_BF16) {
+    if (inv) hipLaunchKernelGGL((affine_act_kernel<bf16_t, true>), dim3(grid, groups), dim3(256), 0, st, (const bf16_t*)x, a, b, (const bf16_t*)res, (bf16_t*)out, nvec, cv, act, o8, e4m3_scale);
+    else hipLaunchKernelGGL((affine_act_kernel<bf16_t, false>), dim3(grid, groups), dim3(256), 0, st, (const bf16_t*)x, a, b, (const bf16_t*)res, (bf16_t*)out, nvec, cv, act, o8, e4m3_scale);
+  } else {
+    if (inv) hipLaunchKernelGGL((affine_act_kernel<float, true>), dim3(grid, groups), dim3(256), 0, st, (const float*)x, a, b, (const float*)res, (float*)out, nvec, cv, act, o8, e4m3_scale);
+    else hipLaunchKernelGGL((affine_act_kernel<float, false>), dim3(grid, groups), dim3(256), 0, st, (const float*)x, a, b, (const float*)res, (float*)out, nvec, cv, act, o8, e4m3_scale);
   }
   return (int)hipGetLastError();
 }

@@ -116,9 +116,15 @@ __global__ __launch_bounds__(256) void bn_finalize_train_kernel(const float* __r
                                          const float* __restrict__ weight, const float* __restrict__ bias,
                                          float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
                                          float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ a,
-                                         float* __restrict__ b, long long* __restrict__ num_batches_tracked) {
-  const int c = blockIdx.x;
-  if (c == 0 && threadIdx.x == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;   // nn.BatchNorm2d's counter
+                                         float* __restrict__ b, long long* __restrict__ num_batches_tracked,
+                                         int running_stride) {
+  // blockIdx.y: a GROUP of the batch with statistics of its own (ops.bn_batch_groups: several passes in one batch) -- N images and
+  // N * chunks records per group, one row of C per group in mean / rstd / a / b, the running buffers `running_stride` floats apart
+  const int c = blockIdx.x, grp = blockIdx.y;
+  partial += (size_t)grp * N * chunks * 2 * C;
+  mean += (size_t)grp * C; rstd += (size_t)grp * C; a += (size_t)grp * C; b += (size_t)grp * C;
+  if (rmean != nullptr) { rmean += (size_t)grp * running_stride; rvar += (size_t)grp * running_stride; }
+  if (c == 0 && grp == 0 && threadIdx.x == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;   // nn.BatchNorm2d's counter
   double sq[2];
   combine_records<2>(partial, 0, N * chunks, C, c, sq);
   if (threadIdx.x != 0) return;
@@ -173,7 +179,10 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
   extern __shared__ float smem[];
   const int cv = C / VEC, rpp = 256 / cv;
   const int tid = threadIdx.x, vcol = tid % cv, prow = tid / cv;
-  const int chunk = blockIdx.x;
+  const int chunk = blockIdx.x, grp = blockIdx.y;       // blockIdx.y: a group of the batch (`pixels` pixels, own coefficients, own records)
+  dz += (size_t)grp * pixels * C; y += (size_t)grp * pixels * C;
+  a += (size_t)grp * C; b += (size_t)grp * C; mean += (size_t)grp * C; rstd += (size_t)grp * C;
+  partial += (size_t)grp * chunks * 2 * C;
   const size_t rows_per_chunk = (pixels + chunks - 1) / chunks;
   const size_t rbeg = (size_t)chunk * rows_per_chunk;
   const size_t rend = rbeg + rows_per_chunk < pixels ? rbeg + rows_per_chunk : pixels;
@@ -226,6 +235,28 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   }
 }
 
+// The same for `groups` groups of the batch: per group its own sums (gsum[g][0][c] = dweight, gsum[g][1][c] = dbias: what the apply kernel
+// of the group needs), the parameters' gradient = their total over the groups (written, or added when `accumulate`).
+__global__ __launch_bounds__(256) void bn_bwd_finalize_groups_kernel(const float* __restrict__ partial, int chunks, int C, int groups,
+                                                                     float* __restrict__ gsum, float* __restrict__ dweight,
+                                                                     float* __restrict__ dbias, int accumulate) {
+  const int c = blockIdx.x;
+  double tw = 0.0, tb = 0.0;
+  for (int g = 0; g < groups; ++g) {
+    double sq[2];
+    __syncthreads();                                   // (combine_records' scratch is reused)
+    combine_records<2>(partial + (size_t)g * chunks * 2 * C, 0, chunks, C, c, sq);
+    if (threadIdx.x == 0) {
+      gsum[((size_t)g * 2 + 0) * C + c] = (float)sq[1];
+      gsum[((size_t)g * 2 + 1) * C + c] = (float)sq[0];
+      tw += (double)(float)sq[1]; tb += (double)(float)sq[0];
+    }
+  }
+  if (threadIdx.x != 0) return;
+  if (accumulate) { dweight[c] += (float)tw; dbias[c] += (float)tb; }
+  else { dweight[c] = (float)tw; dbias[c] = (float)tb; }
+}
+
 // dy = a*(g - sum_g/M - xhat*sum_gx/M) with g = dz*act'(a*y+b), xhat = (y-mean)*rstd, folded per channel into
 //   dy = a*g + c2*(y - mean) + c3,   c2 = -a*rstd*sum_gx/M,  c3 = -a*sum_g/M        (eval mode: c2 = c3 = 0)
 template <typename T, bool INVARIANT>
@@ -234,8 +265,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            int act, int train, const float* __restrict__ dweight,
                                                            const float* __restrict__ dbias, float inv_count,
-                                                           T* __restrict__ dy, size_t nvec, int cv) {
+                                                           T* __restrict__ dy, size_t nvec, int cv, int sum_stride) {
   constexpr int VEC = Elem<T>::VEC;
+  {                                                    // blockIdx.y: a group of the batch (nvec vectors, own coefficients and sums)
+    const size_t grp = blockIdx.y;
+    dz += grp * nvec * VEC; y += grp * nvec * VEC; dy += grp * nvec * VEC;
+    const size_t co = grp * (size_t)cv * VEC;
+    a += co; b += co; mean += co; rstd += co;
+    dweight += grp * sum_stride; dbias += grp * sum_stride;
+  }
   float av[VEC], bv[VEC], mv[VEC], c2[VEC], c3[VEC];
   auto load_coef = [&](int c) {
     float rv[VEC], dw[VEC], db[VEC];
@@ -649,7 +687,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void affine_act_stats_kernel(const T* __restrict__ x, const float* __restrict__ a,
                                                                const float* __restrict__ b, const T* __restrict__ res,
                                                                T* __restrict__ out, float* __restrict__ partial, int HW, int C,
-                                                               int chunks, int act) {
+                                                               int chunks, int act, int group_images) {
   constexpr int VEC = Elem<T>::VEC;
   extern __shared__ float smem[];
   const int cv = C / VEC, rpp = 256 / cv;
@@ -662,8 +700,9 @@ __global__ __launch_bounds__(256) void affine_act_stats_kernel(const T* __restri
   for (int e = 0; e < VEC; ++e) v[0][e] = v[1][e] = 0.f;
   if (prow < rpp) {
     float av[VEC], bv[VEC];
-    ldcoef<VEC>(a + vcol * VEC, av);
-    ldcoef<VEC>(b + vcol * VEC, bv);
+    const size_t crow = group_images > 0 ? (size_t)(n / group_images) * C : 0;      // coefficients per group of the batch
+    ldcoef<VEC>(a + crow + vcol * VEC, av);
+    ldcoef<VEC>(b + crow + vcol * VEC, bv);
     const size_t base = (size_t)n * HW * C + (size_t)vcol * VEC;
     auto one = [&](int r, const u32x4& xq, const u32x4& rq) {
       float f[VEC], rr[VEC], o[VEC];
@@ -801,7 +840,7 @@ int dei2i_bn_finalize_train(int N, int HW, int C, const float* partial, const fl
   if (N <= 0 || HW <= 0 || C <= 0 || !partial || !weight || !bias || !mean || !rstd || !a || !b) return DEI2I_ERR_BAD_ARG;
   hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(C), dim3(combine_threads(N * dei2i_moments_chunks(HW))), 0, (hipStream_t)s, partial, N,
                      dei2i_moments_chunks(HW), C, (double)N * (double)HW, weight, bias, running_mean, running_var, momentum,
-                     eps, mean, rstd, a, b, num_batches_tracked);
+                     eps, mean, rstd, a, b, num_batches_tracked, 0);
   return (int)hipGetLastError();
 }
 
@@ -811,7 +850,19 @@ int dei2i_bn_finalize_train_chunks(int N, int HW, int C, int chunks, const float
   if (N <= 0 || HW <= 0 || C <= 0 || chunks <= 0 || !partial || !weight || !bias || !mean || !rstd || !a || !b) return DEI2I_ERR_BAD_ARG;
   hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(C), dim3(combine_threads(N * chunks)), 0, (hipStream_t)s, partial, N, chunks, C,
                      (double)N * (double)HW, weight, bias, running_mean, running_var, momentum, eps, mean, rstd, a, b,
-                     num_batches_tracked);
+                     num_batches_tracked, 0);
+  return (int)hipGetLastError();
+}
+
+int dei2i_bn_finalize_train_groups(int groups, int N, int HW, int C, int chunks, const float* partial, const float* weight, const float* bias,
+                                   float* running_mean, float* running_var, int running_stride, float momentum, float eps, float* mean,
+                                   float* rstd, float* a, float* b, dei2i_stream s) {
+  if (groups <= 0 || N <= 0 || HW <= 0 || C <= 0 || chunks <= 0 || !partial || !weight || !bias || !mean || !rstd || !a || !b ||
+      (running_mean == nullptr) != (running_var == nullptr) || (running_mean != nullptr && groups > 1 && running_stride < C))
+    return DEI2I_ERR_BAD_ARG;
+  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(C, groups), dim3(combine_threads(N * chunks)), 0, (hipStream_t)s, partial, N, chunks, C,
+                     (double)N * (double)HW, weight, bias, running_mean, running_var, momentum, eps, mean, rstd, a, b,
+                     (long long*)nullptr, running_stride);
   return (int)hipGetLastError();
 }
 
@@ -821,10 +872,23 @@ int dei2i_affine_act_stats_fwd(int dtype, int N, int HW, int C, const void* x, c
   const int chunks = dei2i_moments_chunks(HW);
   if (dtype == DT_BF16)
     hipLaunchKernelGGL(affine_act_stats_kernel<bf16_t>, dim3(chunks, N), dim3(256), combine_lds(dtype, 2), (hipStream_t)s,
-                       (const bf16_t*)x, a, b, (const bf16_t*)res, (bf16_t*)out, partial, HW, C, chunks, act);
+                       (const bf16_t*)x, a, b, (const bf16_t*)res, (bf16_t*)out, partial, HW, C, chunks, act, 0);
   else
     hipLaunchKernelGGL(affine_act_stats_kernel<float>, dim3(chunks, N), dim3(256), combine_lds(dtype, 2), (hipStream_t)s,
-                       (const float*)x, a, b, (const float*)res, (float*)out, partial, HW, C, chunks, act);
+                       (const float*)x, a, b, (const float*)res, (float*)out, partial, HW, C, chunks, act, 0);
+  return (int)hipGetLastError();
+}
+
+int dei2i_affine_act_stats_groups_fwd(int dtype, int groups, int N, int HW, int C, const void* x, const float* a, const float* b,
+                                      const void* res, int act, void* out, float* partial, dei2i_stream s) {
+  if (groups <= 0 || N <= 0 || N % groups != 0 || HW <= 0 || !cv_ok(dtype, C) || !x || !a || !b || !out || !partial) return DEI2I_ERR_BAD_ARG;
+  const int chunks = dei2i_moments_chunks(HW);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(affine_act_stats_kernel<bf16_t>, dim3(chunks, N), dim3(256), combine_lds(dtype, 2), (hipStream_t)s,
+                       (const bf16_t*)x, a, b, (const bf16_t*)res, (bf16_t*)out, partial, HW, C, chunks, act, N / groups);
+  else
+    hipLaunchKernelGGL(affine_act_stats_kernel<float>, dim3(chunks, N), dim3(256), combine_lds(dtype, 2), (hipStream_t)s,
+                       (const float*)x, a, b, (const float*)res, (float*)out, partial, HW, C, chunks, act, N / groups);
   return (int)hipGetLastError();
 }
 
@@ -913,6 +977,49 @@ int dei2i_bn_bwd_partial(int dtype, size_t pixels, int C, const void* dz, const 
   return (int)hipGetLastError();
 }
 
+int dei2i_bn_bwd_partial_groups(int dtype, int groups, size_t pixels, int C, const void* dz, const void* y, const float* a, const float* b,
+                                const float* mean, const float* rstd, int act, float* partial, dei2i_stream s) {
+  if (groups <= 0 || pixels == 0 || !cv_ok(dtype, C) || !dz || !y || !a || !b || !mean || !rstd || !partial) return DEI2I_ERR_BAD_ARG;
+  const int chunks = dei2i_bn_bwd_chunks(pixels);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(bn_bwd_partial_kernel<bf16_t>, dim3(chunks, groups), dim3(256), combine_lds(dtype, 2), (hipStream_t)s,
+                       (const bf16_t*)dz, (const bf16_t*)y, a, b, mean, rstd, act, partial, pixels, C, chunks);
+  else
+    hipLaunchKernelGGL(bn_bwd_partial_kernel<float>, dim3(chunks, groups), dim3(256), combine_lds(dtype, 2), (hipStream_t)s,
+                       (const float*)dz, (const float*)y, a, b, mean, rstd, act, partial, pixels, C, chunks);
+  return (int)hipGetLastError();
+}
+
+/* `groups` groups of `pixels` pixels each, coefficient rows (groups, C), records (groups, chunks, 2, C): two launches for all groups.
+ * group_sums: (groups, 2, C) floats of scratch (each group's own sums, read by its share of the apply launch); dweight / dbias (C): the
+ * total over the groups, written -- or added to when `accumulate` (a further use of the same parameters in this backward pass). */
+int dei2i_bn_bwd_apply_groups(int dtype, int groups, size_t pixels, int C, const void* dz, const void* y, const float* a, const float* b,
+                              const float* mean, const float* rstd, int act, int train, const float* partial, int chunks,
+                              float* group_sums, float* dweight, float* dbias, int accumulate, void* dy, dei2i_stream s) {
+  const int vec = dtype == DT_BF16 ? 8 : 4;
+  if (groups <= 0 || pixels == 0 || !cv_ok(dtype, C) || !dz || !y || !a || !b || !mean || !rstd || !partial || !group_sums || !dweight ||
+      !dbias || !dy || chunks <= 0)
+    return DEI2I_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)s;
+  hipLaunchKernelGGL(bn_bwd_finalize_groups_kernel, dim3(C), dim3(combine_threads(chunks)), 0, st, partial, chunks, C, groups, group_sums,
+                     dweight, dbias, accumulate);
+  const size_t nvec = pixels * (size_t)(C / vec);
+  const unsigned grid = grid_for((nvec + 1) / 2, 256, 256u * 8u);
+  const float inv = 1.f / (float)pixels;
+  const int cv = C / vec;
+  const bool invc = (256 % cv) == 0;
+  const float* gw = group_sums;
+  const float* gb = group_sums + C;
+  if (dtype == DT_BF16) {
+    if (invc) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, true>), dim3(grid, groups), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)y, a, b, mean, rstd, act, train, gw, gb, inv, (bf16_t*)dy, nvec, cv, 2 * C);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, false>), dim3(grid, groups), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)y, a, b, mean, rstd, act, train, gw, gb, inv, (bf16_t*)dy, nvec, cv, 2 * C);
+  } else {
+    if (invc) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, true>), dim3(grid, groups), dim3(256), 0, st, (const float*)dz, (const float*)y, a, b, mean, rstd, act, train, gw, gb, inv, (float*)dy, nvec, cv, 2 * C);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<float, false>), dim3(grid, groups), dim3(256), 0, st, (const float*)dz, (const float*)y, a, b, mean, rstd, act, train, gw, gb, inv, (float*)dy, nvec, cv, 2 * C);
+  }
+  return (int)hipGetLastError();
+}
+
 int dei2i_bn_bwd_apply(int dtype, size_t pixels, int C, const void* dz, const void* y, const float* a, const float* b,
                        const float* mean, const float* rstd, int act, int train, const float* partial, int chunks,
                        float* dweight, float* dbias, float* acc_dweight, float* acc_dbias, void* dy, dei2i_stream s) {
@@ -929,11 +1036,11 @@ int dei2i_bn_bwd_apply(int dtype, size_t pixels, int C, const void* dz, const vo
   const int cv = C / vec;
   const bool invc = (256 % cv) == 0;
   if (dtype == DT_BF16) {
-    if (invc) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)y, a, b, mean, rstd, act, train, (const float*)dweight, (const float*)dbias, inv, (bf16_t*)dy, nvec, cv);
-    else hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)y, a, b, mean, rstd, act, train, (const float*)dweight, (const float*)dbias, inv, (bf16_t*)dy, nvec, cv);
+    if (invc) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)y, a, b, mean, rstd, act, train, (const float*)dweight, (const float*)dbias, inv, (bf16_t*)dy, nvec, cv, 0);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)y, a, b, mean, rstd, act, train, (const float*)dweight, (const float*)dbias, inv, (bf16_t*)dy, nvec, cv, 0);
   } else {
-    if (invc) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, true>), dim3(grid), dim3(256), 0, st, (const float*)dz, (const float*)y, a, b, mean, rstd, act, train, (const float*)dweight, (const float*)dbias, inv, (float*)dy, nvec, cv);
-    else hipLaunchKernelGGL((bn_bwd_apply_kernel<float, false>), dim3(grid), dim3(256), 0, st, (const float*)dz, (const float*)y, a, b, mean, rstd, act, train, (const float*)dweight, (const float*)dbias, inv, (float*)dy, nvec, cv);
+    if (invc) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, true>), dim3(grid), dim3(256), 0, st, (const float*)dz, (const float*)y, a, b, mean, rstd, act, train, (const float*)dweight, (const float*)dbias, inv, (float*)dy, nvec, cv, 0);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<float, false>), dim3(grid), dim3(256), 0, st, (const float*)dz, (const float*)y, a, b, mean, rstd, act, train, (const float*)dweight, (const float*)dbias, inv, (float*)dy, nvec, cv, 0);
   }
   return (int)hipGetLastError();
 }

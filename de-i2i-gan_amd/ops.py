@@ -953,6 +953,23 @@ class bn_running_deferred:
         self.updates.append((index, running_mean, running_var, num_batches_tracked, zm, zv, momentum))
         return zm, zv
 
+    def take_groups(self, running_mean, running_var, num_batches_tracked, momentum, groups):
+        """take() for every group at once, the buffers evenly spaced in ONE block -- (groups, 2, n): group g's mean at row (g, 0), its
+        variance at (g, 1) -- so that one finalize launch serves all groups (dei2i_bn_finalize_train_groups: stride 2 n)."""
+        dev, n = running_mean.device, running_mean.numel()
+        arena, off = bn_running_deferred._arenas.get(dev), self._used.get(dev, 0)
+        if arena is None or off + 2 * n * groups > arena.numel() or running_mean.dtype != torch.float32:
+            block = torch.zeros(groups * 2 * n, dtype=torch.float32, device=dev)
+            self._want = getattr(self, "_want", 0) + 2 * n * groups
+        else:
+            block = arena[off:off + 2 * n * groups]
+            self._used[dev] = off + 2 * n * groups
+        block = block.view(groups, 2, n)
+        for g in range(groups):
+            index = self.pass_index[g] if isinstance(self.pass_index, (tuple, list)) else self.pass_index
+            self.updates.append((index, running_mean, running_var, num_batches_tracked, block[g, 0], block[g, 1], momentum))
+        return block
+
     def apply(self):
         """running <- (1 - m) * running + (m * batch) for every recorded update, passes in index order (on the current stream,
         which must already wait for the streams the passes ran on)"""
@@ -998,6 +1015,11 @@ def _bn_coefs_grouped(lib, y, prec, weight, bias, running_mean, running_var, mom
         partial = torch.empty((n, chunks, 2, c), dtype=torch.float32, device=dev)
         L.check(lib.dei2i_moments_partial(prec.code, n, h * w, c, _p(y), _p(partial), st), "moments_partial")
     ng = n // groups
+    if nf == c and running_mean.dtype == torch.float32:
+        block = deferred.take_groups(running_mean, running_var, num_batches_tracked, float(momentum), groups)       # (groups, 2, c)
+        L.check(lib.dei2i_bn_finalize_train_groups(groups, ng, h * w, c, chunks, _p(partial), _p(w32), _p(b32), _p(block[0, 0]), _p(block[0, 1]),
+                                                   2 * c, momentum, eps, _p(mean), _p(rstd), _p(a), _p(b), st), "bn_finalize_train_groups")
+        return a, b, mean, rstd, nf
     if nf < c:                                   # padded channel stride (see _bn_coefs): c-sized vectors for the kernel
         w32, b32 = (torch.cat([v, v.new_zeros(c - nf)]) for v in (w32, b32))
     for g in range(groups):
@@ -1078,6 +1100,11 @@ def _bn_backward(lib, prec, dout, y, a, b, mean, rstd, act, training, weight, bi
     a, b, mean, rstd = (t.view(groups, c) for t in (a, b, mean, rstd))
     if have is not None:
         partial, chunks = have[0], ng * have[1]          # (n, records per image, 2, c): a group's records are contiguous
+    elif groups > 1:
+        chunks = lib.dei2i_bn_bwd_chunks(pixels)
+        partial = torch.empty((groups * chunks, 2, c), dtype=torch.float32, device=y.device)
+        L.check(lib.dei2i_bn_bwd_partial_groups(prec.code, groups, pixels, c, _p(dout), _p(y), _p(a), _p(b), _p(mean), _p(rstd), act,
+                                                _p(partial), st), "bn_bwd_partial_groups")
     else:
         chunks = lib.dei2i_bn_bwd_chunks(pixels)
         partial = torch.empty((groups * chunks, 2, c), dtype=torch.float32, device=y.device)
@@ -1105,7 +1132,16 @@ def _bn_backward(lib, prec, dout, y, a, b, mean, rstd, act, training, weight, bi
             dw_ptr, db_ptr = tmp.data_ptr(), tmp.data_ptr() + 4 * c
     dy = torch.empty_like(y)
     parts = partial.view(groups, -1)
-    for g in range(groups):
+    if groups > 1:
+        # every group in two launches: the groups' own sums (read by their share of the apply launch) go to scratch, their total to the
+        # parameters' gradient -- written, or added when an earlier use of the parameters in this pass holds the tensor already
+        gsum = torch.empty((groups, 2, c), dtype=torch.float32, device=y.device)
+        accumulate = acc_ptrs[0] is not None
+        tgt_w, tgt_b = (acc_ptrs[0], acc_ptrs[1]) if accumulate else (c_void_p(dw_ptr), c_void_p(db_ptr))
+        L.check(lib.dei2i_bn_bwd_apply_groups(prec.code, groups, pixels, c, _p(dout), _p(y), _p(a), _p(b), _p(mean), _p(rstd), act,
+                                              1 if training else 0, _p(partial), chunks, _p(gsum), tgt_w, tgt_b, 1 if accumulate else 0,
+                                              _p(dy), st), "bn_bwd_apply_groups")
+    for g in range(groups if groups == 1 else 0):
         if g == 1:                # the later groups add into where the first one's sums went
             if acc_ptrs[0] is None:
                 acc_ptrs = (c_void_p(dw_ptr), c_void_p(db_ptr))
@@ -1149,7 +1185,14 @@ class _BatchNormAct(torch.autograd.Function):
             chunks = lib.dei2i_moments_chunks(h * w)
             partial = torch.empty((n, chunks, 2, c), dtype=torch.float32, device=dev)
             _stats_stash.append((partial, chunks))
-        for g in range(groups):                           # (one launch per group of the batch: bn_batch_groups)
+        if groups > 1:                                    # every group in one launch (grid.y = group; coefficient rows (groups, c))
+            if partial is not None:
+                L.check(lib.dei2i_affine_act_stats_groups_fwd(prec.code, groups, n, h * w, c, _p(y), _p(av), _p(bv), _p(res), act, _p(out),
+                                                              _p(partial), st), "affine_act_stats_groups")
+            else:
+                L.check(lib.dei2i_affine_act_groups_fwd(prec.code, groups, ng * h * w, c, _p(y), _p(av), _p(bv), _p(res), act, _p(out), _p(xq),
+                                                        FP8_ACT_SCALE, st), "affine_act_groups")
+        for g in range(groups if groups == 1 else 0):
             lo = g * ng
             rg = res[lo:] if res is not None else None
             if partial is not None:

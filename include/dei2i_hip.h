@@ -239,6 +239,24 @@ int dei2i_spectral_bwd(int Cout, int K, const float* G, const float* w_eff, cons
 int dei2i_fold_bn_weight(int Cout, int K, const float* W, const float* bn_weight, const float* bn_bias, const float* running_mean,
                          const float* running_var, float eps, float* w_eff, float* b_eff, dei2i_stream s);
 
+/* ---- BatchNorm over a batch that carries several passes: statistics, apply and backward per GROUP of the batch, one launch for all
+ * groups (the paired generator passes of the G loss: defectgan_model.py:185-190 as two passes over 2 x batch).  Same kernels and
+ * argument meaning as the one-group entry points above (finalize_train_chunks, affine_act / affine_act_stats, bn_bwd_partial / apply); N /
+ * pixels are PER GROUP, the groups are consecutive in the activation tensors, mean / rstd / a / b hold one row of C per group, the
+ * statistics records one block per group; running_mean / running_var of group g at + g * running_stride floats. ---- */
+int dei2i_bn_finalize_train_groups(int groups, int N, int HW, int C, int chunks, const float* partial, const float* weight, const float* bias,
+                                   float* running_mean, float* running_var, int running_stride, float momentum, float eps, float* mean,
+                                   float* rstd, float* a, float* b, dei2i_stream s);
+int dei2i_affine_act_groups_fwd(int dtype, int groups, size_t pixels, int C, const void* x, const float* a, const float* b, const void* res,
+                                int act, void* out, void* out_e4m3, float e4m3_scale, dei2i_stream s);
+int dei2i_affine_act_stats_groups_fwd(int dtype, int groups, int N, int HW, int C, const void* x, const float* a, const float* b,
+                                      const void* res, int act, void* out, float* partial, dei2i_stream s);   /* N: the whole batch */
+int dei2i_bn_bwd_partial_groups(int dtype, int groups, size_t pixels, int C, const void* dz, const void* y, const float* a, const float* b,
+                                const float* mean, const float* rstd, int act, float* partial, dei2i_stream s);
+int dei2i_bn_bwd_apply_groups(int dtype, int groups, size_t pixels, int C, const void* dz, const void* y, const float* a, const float* b,
+                              const float* mean, const float* rstd, int act, int train, const float* partial, int chunks,
+                              float* group_sums, float* dweight, float* dbias, int accumulate, void* dy, dei2i_stream s);
+
 /* ---- SPADE's label path, second stage, for all modules of a generator at once (csrc/label_path.hip) ----
  * normalization.py:17-37 with a constant label map (the 5 x 5 class image of networks/architecture.py SPADE): gamma | beta =
  * conv3x3(actv; mlp_gamma | mlp_beta) + bias per module, every module reading `hidden` channels at its offset `in_off` of ONE activation
