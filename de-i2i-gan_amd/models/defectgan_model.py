@@ -123,7 +123,10 @@ class DefectGanModel(BaseModel):
         elif self.opt.style_norm_block_type == "adain":          # :377-379
             predicted, _ = self.netG(self.mask_token(imgs, masks), labels, self.netE(imgs, labels))
         else:
-            predicted, _ = self.netG(self.mask_token(imgs, masks), self._expand_seg(labels))
+            seg = self._expand_seg(labels)
+            if seg.shape[2:] == (1, 1):
+                self.netG.prime_spade((seg,))                # every SPADE module's class table in the batched launches (label_path.hip)
+            predicted, _ = self.netG(self.mask_token(imgs, masks), seg)
         return predicted, masks
 
     def _upload_mask(self, masks):

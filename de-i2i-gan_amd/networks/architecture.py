@@ -406,7 +406,7 @@ class SPADE(nn.Module):
 
     def wants_prime(self, segmaps, prec):
         """Will prime() compute tables for these label tensors?  (a module that runs in class mode and does not hold them yet)"""
-        return (getattr(self, "_ran_class_mode", True) and len(segmaps) == 2
+        return (getattr(self, "_ran_class_mode", True) and len(segmaps) in (1, 2)
                 and all(s_.dim() == 4 and s_.shape[2] == 1 and s_.shape[3] == 1 for s_ in segmaps)
                 and not all(self._table_key(sgm, prec) in self._gb_cache for sgm in segmaps))
 
@@ -419,7 +419,7 @@ class SPADE(nn.Module):
         #  modules its first forward did not reach)
         if not getattr(self, "_ran_class_mode", True):
             return
-        if len(segmaps) != 2 or any(s.dim() != 4 or s.shape[2] != 1 or s.shape[3] != 1 for s in segmaps):
+        if len(segmaps) not in (1, 2) or any(s.dim() != 4 or s.shape[2] != 1 or s.shape[3] != 1 for s in segmaps):
             return
         if all(self._table_key(sgm, prec) in self._gb_cache for sgm in segmaps):
             return                                       # both tables are there already (same tensors, same parameter state)

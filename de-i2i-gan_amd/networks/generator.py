@@ -108,11 +108,12 @@ class DefectGanGenerator(BaseNetwork):
         mods = [m for m in self._table_modules() if hasattr(m, "prime")]
         if not mods:
             return
-        if len(label_tensors) != 2 or not all(t.dim() == 4 and t.shape[2:] == (1, 1) for t in label_tensors):
+        if len(label_tensors) not in (1, 2) or not all(t.dim() == 4 and t.shape[2:] == (1, 1) for t in label_tensors):
             for m in mods:
                 m.prime(label_tensors, self.prec)
             return
-        both = torch.cat(list(label_tensors), 0)          # one concatenation and one 5x5 class image for all modules
+        # one concatenation and one 5x5 class image for all modules
+        both = torch.cat(list(label_tensors), 0) if len(label_tensors) > 1 else label_tensors[0]
         seg = ops.to_nhwc(both, self.prec, size=(5, 5))
         # The first conv of every module's label path (normalization.py:17-19: label_nc -> hidden_nc, 3x3, ReLU) reads the SAME class
         # image: the modules that will run are served by ONE conv over their concatenated filters (each output channel of a conv is a
