@@ -58,8 +58,11 @@ class Conv2d(nn.Module):
             nn.init.uniform_(self.bias, -bound, bound)
 
     def geom(self, up=False):
-        return ops.ConvGeom(self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding,
-                            self.padding_mode == "reflect" and self.padding > 0, up)
+        g = self.__dict__.setdefault("_geoms", {}).get(up)
+        if g is None:
+            g = self._geoms[up] = ops.ConvGeom(self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding,
+                                               self.padding_mode == "reflect" and self.padding > 0, up)
+        return g
 
     def forward(self, x, act="none", up=False, stats=False):
         """``stats``: a BatchNorm / InstanceNorm reads the output next (its statistics come from the conv epilogue)."""

@@ -372,9 +372,20 @@ class ConvGeom:
     up: bool = False      # nearest x2 upsample fused in front of the conv (architecture.py:203)
 
 
+_descs = {}
+
+
 def _desc(prec: Precision, g: ConvGeom, n: int, h: int, w: int, cins: int, couts: int) -> L.ConvDesc:
-    return L.ConvDesc(prec.code, n, h, w, g.cin, g.cout, cins, couts, g.k, g.k, g.stride, g.pad,
-                      L.PAD_REFLECT if g.reflect else L.PAD_ZERO, 1 if g.up else 0)
+    """The conv descriptor of (geometry, shape): made once (a ctypes structure costs ~3 us to build, a step asks ~500 times; the
+    library only reads it)."""
+    key = (prec.code, g, n, h, w, cins, couts)
+    d = _descs.get(key)
+    if d is None:
+        if len(_descs) > 4096:
+            _descs.clear()
+        d = _descs[key] = L.ConvDesc(prec.code, n, h, w, g.cin, g.cout, cins, couts, g.k, g.k, g.stride, g.pad,
+                                     L.PAD_REFLECT if g.reflect else L.PAD_ZERO, 1 if g.up else 0)
+    return d
 
 
 class PackedWeights:
