@@ -68,6 +68,8 @@ def parse():
                          "(ddp: collectives and MB per step, side-stream occupancy, exposed ms, step time with / without the reducer)")
     ap.add_argument("--comm-dtype", default="fp32", choices=["fp32", "bf16"],
                     help="gradient all-reduce message type (parallel.GradReducer comm_dtype; bf16 halves the bytes on xGMI)")
+    ap.add_argument("--ddp-no-overlap", action="store_true", help="A/B: issue every gradient collective after backward (GradReducer overlap=False)")
+    ap.add_argument("--ddp-no-measure", action="store_true", help="A/B: no event brackets around the collectives (GradReducer measure=False)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child process of the default run
     ap.add_argument("--spawn-selftest", default=None, help=argparse.SUPPRESS)             # tests: rendezvous of the spawned ranks over gloo, no GPU
     return ap.parse_args()
@@ -282,7 +284,8 @@ def main():
             step()
         torch.cuda.synchronize()
         plain_ms = 1e3 * (time.perf_counter() - t0) / args.steps
-    red = attach_ddp(tr, measure=True, force_collectives=args.force_collectives, comm_dtype=args.comm_dtype) \
+    red = attach_ddp(tr, measure=not args.ddp_no_measure, force_collectives=args.force_collectives, comm_dtype=args.comm_dtype,
+                     overlap=not args.ddp_no_overlap) \
         if (world > 1 or args.force_collectives) else None
 
     def sync():
