@@ -482,6 +482,8 @@ def main():
         # after backward's last kernel (the optimizer waits for it) -- stream events, measured inside the timed region
         ddp.update({"collectives_per_step": red_stats["collectives"] / (args.steps + args.warmup),
                     "allreduce_mb_per_step": red_stats["bytes"] / (args.steps + args.warmup) / 1e6,
+                    "host_ms_per_step_in_reduce": red_stats.get("reduce_host_ms", 0.0) / (args.steps + args.warmup),
+                    "host_ms_per_step_issuing_collectives": red_stats.get("launch_host_ms", 0.0) / (args.steps + args.warmup),
                     "comm_dtype": args.comm_dtype})
         if plain_ms is not None:
             ddp.update({"ranks": 1, "step_ms_without_reducer": plain_ms, "step_ms_with_reducer": ms_per_step,

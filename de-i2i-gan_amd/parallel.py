@@ -29,6 +29,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional
 
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -96,6 +98,13 @@ class GradReducer:
             self._launch(grads, flat=True)
 
     def _launch(self, grads: List[torch.Tensor], flat) -> None:
+        t_host = time.perf_counter()
+        try:
+            self._launch_inner(grads, flat)
+        finally:
+            self.stats["launch_host_ms"] = self.stats.get("launch_host_ms", 0.0) + 1e3 * (time.perf_counter() - t_host)
+
+    def _launch_inner(self, grads: List[torch.Tensor], flat) -> None:
         dev = grads[0].device
         side = self._comm_stream(dev)
         if side is not None:
@@ -143,6 +152,7 @@ class GradReducer:
         over ranks.  Use ``FusedAdam.grad_scale = 1/world`` (set by ``attach_ddp``) for the average."""
         if not self.active:
             return
+        t_host = time.perf_counter()
         if self.measure and torch.cuda.is_available():
             ev = torch.cuda.Event(enable_timing=True)
             ev.record(torch.cuda.current_stream())
@@ -168,6 +178,7 @@ class GradReducer:
         for dev, side in self._side.items():
             torch.cuda.current_stream(dev).wait_stream(side)    # optimizer kernels run after the reduced grads land
         self._inflight = []
+        self.stats["reduce_host_ms"] = self.stats.get("reduce_host_ms", 0.0) + 1e3 * (time.perf_counter() - t_host)
         if self.measure:
             self._span_marks.append(len(self._spans))
 
